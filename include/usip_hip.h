@@ -1,0 +1,75 @@
+/*
+ * include/usip_hip.h -- C ABI of libusip_hip.so, the MI355X (gfx950) implementation of the
+ * USIP detector hot path.  This is the drop-in boundary: plain pointers and sizes, no torch
+ * types.  The reference reaches the same operators through two pybind11/torch extensions and
+ * through ATen calls in its Python modules; each entry point below cites what it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer on the current HIP device unless the name ends in
+ *     `_cpu`; buffers are caller-owned, contiguous, row-major, and never aliased;
+ *   - nothing is allocated, nothing synchronises: kernels are enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream) and the call returns;
+ *   - return value: 0 on success, USIP_EINVAL for a bad argument, otherwise the hipError_t
+ *     of the failed launch (positive);
+ *   - outputs are fully written (callers need not pre-zero them) unless stated;
+ *   - int32 indices, fp32 values; index outputs are bit-exact with the reference, float outputs
+ *     agree to fp32 rounding (<= 1e-5 relative).
+ */
+#ifndef USIP_HIP_H
+#define USIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USIP_OK      0
+#define USIP_EINVAL (-1)
+
+/* Library identification: "usip_hip <version> gfx950". */
+const char* usip_version(void);
+
+/* ------------------------------------------------------------------ a-1  index_max
+ * Replaces index_max.forward_cuda / forward_cuda_shared_mem
+ * (models/index_max_ext/index_max.cpp:132-148 -> index_max_cuda.cu:9-25, :29-61, :65-98).
+ *   max_idx[b,c,k] = lowest n with index[b,n]==k attaining max data[b,c,n], provided that
+ *   maximum is strictly greater than -1000; otherwise (empty node, sub-floor values, NaN) 0.
+ * data f32 [B,C,N], index i32 [B,N] with values in [0,K), max_idx i32 [B,C,K] (fully written).
+ * Lifts the reference's limits (B <= 1024 threads, B*K*4 <= 48 KB shared memory). */
+int usip_index_max_f32(const float* data, const int32_t* index, int32_t* max_idx,
+                       int B, int C, int N, int K, void* stream);
+
+/* Host twins: index_max.forward_cpu (index_max.cpp:73-112) and forward_multi_thread_cpu
+ * (index_max.cpp:33-70; channels split over num_threads std::threads).  HOST pointers. */
+int usip_index_max_f32_cpu(const float* data, const int32_t* index, int32_t* max_idx,
+                           int B, int C, int N, int K, int num_threads);
+
+/* ------------------------------------------------------------------ a-2  ball_query
+ * Replaces ball_query.forward_cuda_shared_mem
+ * (models/ball_query_ext/ball_query.cpp:33-39 -> ball_query_cuda.cu:10-49, :53-70).
+ *   per (b,m): the first K indices n (ascending) with dist[b,m,n] <= radius; if 0 < u < K hits,
+ *   out[u+i] = out[i % u]; if u == 0 the row is all zeros.
+ * dist f32 [B,M,N], out_idx i32 [B,M,K] (fully written). radius is a C float as in the kernel. */
+int usip_ball_query_f32(const float* dist, int32_t* out_idx, float radius, int K,
+                        int B, int M, int N, void* stream);
+
+/* ------------------------------------------------------------------ pairwise distances
+ * Replaces the materialised torch.norm(a.unsqueeze(3) - b.unsqueeze(2), dim=1) in front of
+ * ball_query (models/networks.py:694-696, :355-357):
+ *   dist[b,m,n] = sqrt(fma(dz,dz, fma(dy,dy, dx*dx))), d* = a[b,*,m] - x[b,*,n]
+ * (the arithmetic order of the pinned oracle platform, bit-exact with it).
+ * a f32 [B,3,M], x f32 [B,3,N] -> dist f32 [B,M,N]. */
+int usip_pairwise_dist_f32(const float* a, const float* x, float* dist,
+                           int B, int M, int N, void* stream);
+
+/* f-2  Fused coords-in ball query: same result as usip_pairwise_dist_f32 followed by
+ * usip_ball_query_f32, without ever writing the B x M x N matrix. */
+int usip_ball_query_coords_f32(const float* node, const float* x, int32_t* out_idx, float radius,
+                               int K, int B, int M, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USIP_HIP_H */

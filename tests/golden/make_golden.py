@@ -1,0 +1,343 @@
+"""tests/golden/make_golden.py -- regenerates the golden fixtures in this directory.
+
+Runs ONLY in the build container, where the reference is mounted at /root/reference:
+it imports the reference's own Python modules (models.networks / layers / losses,
+util.som) and its own index_max C++ (built unmodified into oracle/_ref/, see
+oracle/build_ref.py), feeds them seeded inputs + closed-form weights
+(usip_amd.synth.fill_parameters) and stores inputs and outputs as small .npz files.
+Fixtures are data (numbers); no reference source text is stored.
+
+Shims needed to import the reference here: an empty `torchvision`
+module (util/som.py:12 imports it, never uses it on this path); `index_max` = the
+reference's own CPU entry point; `ball_query` = oracle/usip_oracle.c (the reference has
+no CPU ball_query: that part of every fixture is "parity unpinned", flagged per file).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import native                      # noqa: E402
+from oracle.build_ref import load_ref_index_max  # noqa: E402
+from usip_amd import synth                     # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def import_reference():
+    import matplotlib
+    matplotlib.use("Agg")
+    ref_im = load_ref_index_max()
+    assert ref_im is not None, "reference index_max could not be built"
+    sys.modules["torchvision"] = types.ModuleType("torchvision")
+    im = types.ModuleType("index_max")
+    im.forward_cpu = ref_im.forward_cpu
+    im.forward_multi_thread_cpu = ref_im.forward_multi_thread_cpu
+    im.forward_cuda_shared_mem = lambda d, i, K: ref_im.forward_cpu(d.contiguous(), i.contiguous(), K)
+    im.forward_cuda = im.forward_cuda_shared_mem
+    sys.modules["index_max"] = im
+    bq = types.ModuleType("ball_query")
+    bq.forward_cuda_shared_mem = lambda dist, r, K: torch.from_numpy(
+        native.ball_query(dist.detach().contiguous().numpy(), float(r), int(K)))
+    bq.forward_cuda = bq.forward_cuda_shared_mem
+    sys.modules["ball_query"] = bq
+    sys.path.insert(0, "/root/reference")
+    from models import networks, losses, layers   # noqa
+    from util import som                           # noqa
+    return ref_im, networks, losses, layers, som
+
+
+class Opt:
+    """Attribute bag standing in for the argparse namespace (kitti/options_detector.py:14-60)."""
+    def __init__(self, **kw):
+        self.activation = "relu"
+        self.normalization = "batch"
+        self.bn_momentum = 0.1
+        self.bn_momentum_decay_step = None
+        self.bn_momentum_decay = 0.6
+        self.k = 1
+        self.__dict__.update(kw)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("%-34s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------- native ops
+def gen_index_max(ref_im):
+    rng = np.random.default_rng(101)
+    cases = {}
+
+    def add(tag, data, index, K):
+        d, i = torch.from_numpy(data), torch.from_numpy(index)
+        out = ref_im.forward_cpu(d, i, K).numpy()
+        out_mt = ref_im.forward_multi_thread_cpu(d, i, K, 3).numpy()
+        assert np.array_equal(out, out_mt)       # the reference's only parity statement
+        cases[tag + "_data"], cases[tag + "_index"] = data, index
+        cases[tag + "_K"], cases[tag + "_out"] = np.int32(K), out
+
+    B, C, N, K = 3, 7, 1000, 37
+    add("random", rng.normal(0, 1, (B, C, N)).astype(np.float32),
+        rng.integers(0, K, (B, N)).astype(np.int32), K)
+    # ties: quantised values -> lowest n among the maxima must win
+    add("ties", rng.integers(-3, 4, (B, C, N)).astype(np.float32),
+        rng.integers(0, K, (B, N)).astype(np.int32), K)
+    # floor: values at / below -1000 never win (strict >), all-below-floor node -> 0
+    d = rng.normal(-1000, 2, (B, C, N)).astype(np.float32)
+    d[:, :, ::7] = -1000.0
+    add("floor", d, rng.integers(0, K, (B, N)).astype(np.int32), K)
+    # empty nodes: only even nodes are ever assigned
+    add("empty", rng.normal(0, 1, (B, C, N)).astype(np.float32),
+        (2 * rng.integers(0, K // 2, (B, N))).astype(np.int32), K)
+    # NaN never wins
+    d = rng.normal(0, 1, (2, 3, 200)).astype(np.float32)
+    d[:, :, 5::11] = np.nan
+    add("nan", d, rng.integers(0, 8, (2, 200)).astype(np.int32), 8)
+    # ragged / tiny
+    add("tiny", rng.normal(0, 1, (1, 1, 1)).astype(np.float32), np.zeros((1, 1), np.int32), 1)
+    add("n_lt_wave", rng.normal(0, 1, (2, 2, 13)).astype(np.float32),
+        rng.integers(0, 5, (2, 13)).astype(np.int32), 5)
+    save("index_max_cases.npz", **cases)
+
+
+def gen_dist_ball():
+    """torch.norm distance matrices (pinned: torch CPU) + ball_query rows from the C
+    restatement (UNPINNED: no executable reference exists for ball_query)."""
+    rng = np.random.default_rng(202)
+    B, M, N, K = 2, 48, 1500, 16
+    x = synth.make_cloud(rng, N, "slab:12")[None].repeat(B, 0)
+    x[1] = synth.make_cloud(rng, N, "slab:12")
+    node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+    node[0, :, 0] = 1000.0                        # a node with an empty ball
+    tx, tn = torch.from_numpy(x), torch.from_numpy(node)
+    dist = torch.norm(tn.unsqueeze(3) - tx.unsqueeze(2), dim=1).numpy()
+    out, prefix = native.ball_query(dist, 2.0, K, return_prefix=True)
+    hits = (dist <= 2.0).sum(-1)
+    assert (hits == 0).any() and ((hits > 0) & (hits < K)).any() and (hits >= K).any()
+    save("dist_ball_cases.npz", x=x, node=node, dist=dist, radius=np.float32(2.0), K=np.int32(K),
+         ball_idx_unpinned=out, prefix_len_unpinned=prefix)
+
+
+def gen_som(som):
+    rng = np.random.default_rng(303)
+    B, N, M = 3, 900, 40
+    x = np.stack([synth.make_cloud(rng, N, "sphere") for _ in range(B)])
+    node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+    node[1, :, 3] = 50.0                           # a node no point is nearest to
+    mask, mask_row_max, min_idx = som.query_topk(torch.from_numpy(node), torch.from_numpy(x), M, k=1)
+    save("som_cases.npz", x=x, node=node, min_idx=min_idx.numpy().astype(np.int32),
+         mask_row_max=mask_row_max.numpy().astype(np.int32),
+         count=mask.sum(dim=1).numpy().astype(np.int32))
+
+
+# --------------------------------------------------------------------------- modules
+def load_filled(module, head_std=0.05):
+    sd = module.state_dict()
+    filled = synth.fill_parameters({k: tuple(v.shape) for k, v in sd.items()}, head_std)
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(sd[k].shape)
+                            for k, v in filled.items()})
+
+
+def grad_digest(module):
+    """Per-parameter gradient digests: first 48 flat entries, L2 norm, sum."""
+    d = {}
+    for k, p in module.named_parameters():
+        g = p.grad.detach().numpy().ravel()
+        d["grad_head/" + k] = g[:48].copy()
+        d["grad_norm/" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        d["grad_sum/" + k] = np.float64(g.astype(np.float64).sum())
+    return d
+
+
+def gen_layers(layers):
+    rng = np.random.default_rng(404)
+    out = {}
+    # MyConv2d 1x1 + BN + ReLU, train mode (layers.py:172-216)
+    conv = layers.MyConv2d(7, 12, kernel_size=(1, 1), stride=1, padding=0, bias=True,
+                           activation="relu", normalization="batch", momentum=0.1)
+    load_filled(conv)
+    conv.train()
+    x = torch.from_numpy(rng.normal(0, 1, (3, 7, 10, 6)).astype(np.float32)).requires_grad_(True)
+    gy = torch.from_numpy(rng.normal(0, 1, (3, 12, 10, 6)).astype(np.float32))
+    y = conv(x)
+    y.backward(gy)
+    out.update(conv2d_x=x.detach().numpy(), conv2d_gy=gy.numpy(), conv2d_y=y.detach().numpy(),
+               conv2d_gx=x.grad.numpy(), conv2d_gw=conv.conv.weight.grad.numpy(),
+               conv2d_gb=conv.conv.bias.grad.numpy(), conv2d_ggamma=conv.norm.weight.grad.numpy(),
+               conv2d_gbeta=conv.norm.bias.grad.numpy(),
+               conv2d_running_mean=conv.norm.running_mean.numpy(),
+               conv2d_running_var=conv.norm.running_var.numpy())
+    conv.eval()
+    out["conv2d_y_eval"] = conv(x.detach()).detach().numpy()
+    # EquivariantLayer (layers.py:248-303)
+    eq = layers.EquivariantLayer(6, 9, activation="relu", normalization="batch", momentum=0.1)
+    load_filled(eq)
+    eq.train()
+    x1 = torch.from_numpy(rng.normal(0, 1, (4, 6, 50)).astype(np.float32)).requires_grad_(True)
+    g1 = torch.from_numpy(rng.normal(0, 1, (4, 9, 50)).astype(np.float32))
+    y1 = eq(x1)
+    y1.backward(g1)
+    out.update(eq_x=x1.detach().numpy(), eq_gy=g1.numpy(), eq_y=y1.detach().numpy(),
+               eq_gx=x1.grad.numpy(), eq_gw=eq.conv.weight.grad.numpy())
+    # GeneralKNNFusionModule (layers.py:375-440), small widths
+    knn = layers.GeneralKNNFusionModule(3 + 8, (16, 16), (24, 24), activation="relu",
+                                        normalization="batch", momentum=0.1)
+    load_filled(knn)
+    knn.train()
+    q = torch.from_numpy(np.stack([synth.make_cloud(rng, 30, "sphere") for _ in range(2)]))
+    f = torch.from_numpy(rng.normal(0, 1, (2, 8, 30)).astype(np.float32)).requires_grad_(True)
+    gk = torch.from_numpy(rng.normal(0, 1, (2, 24, 30)).astype(np.float32))
+    yk = knn(query=q, database=q, x=f, K=5)
+    yk.backward(gk)
+    out.update(knn_q=q.numpy(), knn_f=f.detach().numpy(), knn_gy=gk.numpy(), knn_y=yk.detach().numpy(),
+               knn_gf=f.grad.numpy(), knn_gw0=knn.layers_before[0].conv.weight.grad.numpy(),
+               knn_gw_after0=knn.layers_after[0].conv.weight.grad.numpy())
+    save("layers_cases.npz", **out)
+
+
+def gen_losses(losses):
+    rng = np.random.default_rng(505)
+    opt = Opt()
+    B, M, N = 3, 40, 300
+    src = torch.from_numpy(rng.normal(0, 1, (B, 3, M)).astype(np.float32)).requires_grad_(True)
+    dst = torch.from_numpy(rng.normal(0, 1, (B, 3, M + 7)).astype(np.float32)).requires_grad_(True)
+    ss = torch.from_numpy(rng.uniform(0.05, 1.5, (B, M)).astype(np.float32)).requires_grad_(True)
+    sd = torch.from_numpy(rng.uniform(0.05, 1.5, (B, M + 7)).astype(np.float32)).requires_grad_(True)
+    loss, pure, weighted = losses.ChamferLoss_Brute(opt)(src, dst, ss, sd)
+    loss.backward()
+    out = dict(pc_src=src.detach().numpy(), pc_dst=dst.detach().numpy(), pc_ss=ss.detach().numpy(),
+               pc_sd=sd.detach().numpy(), pc_loss=loss.detach().numpy(), pc_pure=pure.numpy(),
+               pc_weighted=weighted.numpy(), pc_gsrc=src.grad.numpy(), pc_gdst=dst.grad.numpy(),
+               pc_gss=ss.grad.numpy(), pc_gsd=sd.grad.numpy())
+    kp = torch.from_numpy(rng.normal(0, 1, (B, 3, M)).astype(np.float32))
+    pc = torch.from_numpy(rng.normal(0, 1, (B, 3, N)).astype(np.float32))
+    kp[0, :, 0] = pc[0, :, 5]                       # exact coincidence: zero sub-gradient of norm
+    kp.requires_grad_(True)
+    d = losses.KeypointOnPCLoss(opt)(kp, pc, None)
+    gd = torch.from_numpy(rng.normal(0, 1, (B, M)).astype(np.float32))
+    d.backward(gd)
+    out.update(ss_kp=kp.detach().numpy(), ss_pc=pc.numpy(), ss_d=d.detach().numpy(),
+               ss_gd=gd.numpy(), ss_gkp=kp.grad.numpy())
+    save("losses_cases.npz", **out)
+
+
+def run_step(net, losses_mod, opt, batch, alpha):
+    """ModelDetector.optimize without the Adam update, driven on the reference's modules
+    directly (ModelDetector itself calls torch.cuda.synchronize(), keypoint_detector.py:134)."""
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    B = t["src_pc"].shape[0]
+    net.train()
+    node_r, kp, sg, _ = net(torch.cat((t["src_pc"], t["dst_pc"]), 0),
+                            torch.cat((t["src_sn"], t["dst_sn"]), 0),
+                            torch.cat((t["src_node"], t["dst_node"]), 0), True, None)
+    kp_s, kp_d = kp[:B], kp[B:]
+    kp_t = torch.matmul(t["R"], kp_s)
+    kp_t = kp_t * t["scale"].unsqueeze(1).unsqueeze(2)
+    kp_t = kp_t + t["shift"]
+    net.zero_grad()
+    lc, pure, weighted = losses_mod.ChamferLoss_Brute(opt)(kp_t, kp_d, sg[:B], sg[B:])
+    crit = losses_mod.KeypointOnPCLoss(opt)
+    l_src = torch.mean(crit(kp_s, t["src_pc"], None)) * alpha
+    l_dst = torch.mean(crit(kp_d, t["dst_pc"], None)) * alpha
+    loss = lc + l_src + l_dst
+    loss.backward()
+    out = dict(node=node_r.detach().numpy(), keypoints=kp.detach().numpy(), sigmas=sg.detach().numpy(),
+               loss=loss.detach().numpy(), loss_chamfer=lc.detach().numpy(), chamfer_pure=pure.numpy(),
+               chamfer_weighted=weighted.numpy(), loss_on_pc_src=l_src.detach().numpy(),
+               loss_on_pc_dst=l_dst.detach().numpy())
+    out.update(grad_digest(net))
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["buf/" + k] = v.numpy().copy()
+    return out
+
+
+def capture_indices(networks_mod, som_mod):
+    """Record the index tensors the forward computes, by wrapping the shim entry points."""
+    rec = {}
+    im, bq = sys.modules["index_max"], sys.modules["ball_query"]
+    orig_im, orig_bq = im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem
+    orig_topk = torch.topk
+
+    def im_wrap(d, i, K):
+        r = orig_im(d, i, K)
+        rec["index_max_%d" % sum(k.startswith("index_max_") for k in rec)] = r.numpy().copy()
+        rec["min_idx"] = i.numpy().copy()
+        return r
+
+    def bq_wrap(d, r_, K):
+        r = orig_bq(d, r_, K)
+        rec["ball_idx"] = r.numpy().copy()
+        return r
+
+    def topk_wrap(*a, **kw):
+        r = orig_topk(*a, **kw)
+        if kw.get("sorted", True) and kw.get("largest", True) is False:
+            rec["knn_I"] = r[1].numpy().astype(np.int32).copy()
+        return r
+    im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem = im_wrap, bq_wrap
+    torch.topk = topk_wrap
+
+    def restore():
+        im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem = orig_im, orig_bq
+        torch.topk = orig_topk
+    return rec, restore
+
+
+def gen_detectors(networks, losses, som):
+    # config 1: RPN_Detector, ModelNet plumbing size (BASELINE.json configs[0])
+    opt = Opt(surface_normal_len=3, node_knn_k_1=32, loss_sigma_lower_bound=1e-4)
+    batch = synth.make_pair_batch(seed=1234, pairs=2, n=1024, m=64, cs=3, kind="sphere")
+    net = networks.RPN_Detector(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=1.0)
+    restore()
+    save("detector_som_cfg1.npz", cfg_model="som", cfg_knn=np.int32(32), cfg_sigma_lb=np.float32(1e-4),
+         cfg_alpha=np.float32(1.0), **{"in/" + k: v for k, v in batch.items()},
+         **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+    # micro config: RPN_Detector_Ball, KITTI-like parameters at small size (ball_idx unpinned)
+    opt = Opt(surface_normal_len=4, node_knn_k_1=16, loss_sigma_lower_bound=1e-3)
+    batch = synth.make_pair_batch(seed=4321, pairs=2, n=2048, m=64, cs=4, kind="slab:14")
+    net = networks.RPN_Detector_Ball(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=0.01)
+    restore()
+    save("detector_ball_micro.npz", cfg_model="ball", cfg_knn=np.int32(16), cfg_sigma_lb=np.float32(1e-3),
+         cfg_alpha=np.float32(0.01), **{"in/" + k: v for k, v in batch.items()},
+         **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+    # micro config: RPN_Detector at KITTI-like parameters (Cs=4, Kn=16)
+    opt = Opt(surface_normal_len=4, node_knn_k_1=16, loss_sigma_lower_bound=1e-3)
+    batch = synth.make_pair_batch(seed=777, pairs=1, n=1536, m=48, cs=4, kind="slab:14")
+    net = networks.RPN_Detector(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=0.01)
+    restore()
+    save("detector_som_micro.npz", cfg_model="som", cfg_knn=np.int32(16), cfg_sigma_lb=np.float32(1e-3),
+         cfg_alpha=np.float32(0.01), **{"in/" + k: v for k, v in batch.items()},
+         **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+
+if __name__ == "__main__":
+    ref_im, networks, losses, layers, som = import_reference()
+    gen_index_max(ref_im)
+    gen_dist_ball()
+    gen_som(som)
+    gen_layers(layers)
+    gen_losses(losses)
+    gen_detectors(networks, losses, som)

@@ -1,0 +1,151 @@
+"""GPU parity tests of the native operators (through the C ABI) against the oracle and the
+golden vectors.  Integer/index outputs: bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import native
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from usip_amd import ops
+    return ops
+
+
+# ------------------------------------------------------------------ index_max
+@pytest.mark.parametrize("tag", ["random", "ties", "floor", "empty", "nan", "tiny", "n_lt_wave"])
+def test_index_max_golden(tag):
+    g = load_golden("index_max_cases.npz")
+    d = torch.from_numpy(g[tag + "_data"]).to(DEV)
+    i = torch.from_numpy(g[tag + "_index"]).to(DEV)
+    import usip_amd
+    im, _ = usip_amd.install()
+    for fn in (im.forward_cuda, im.forward_cuda_shared_mem):
+        out = fn(d, i, int(g[tag + "_K"]))
+        assert out.dtype == torch.int32 and out.is_cuda
+        assert np.array_equal(out.cpu().numpy(), g[tag + "_out"])
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 1024, 64), (4, 128, 5000, 64), (3, 6, 1001, 33), (16, 64, 16384, 512),
+                                   (1, 3, 4096, 4096), (2, 8, 8192, 8192)])
+def test_index_max_vs_oracle(shape):
+    B, C, N, K = shape
+    rng = np.random.default_rng(B * 1000 + C)
+    data = rng.normal(0, 1, (B, C, N)).astype(np.float32)
+    data[:, :, ::5] = np.round(data[:, :, ::5])            # plenty of exact ties, incl. +-0
+    data[0, 0, :7] = -0.0
+    idx = rng.integers(0, K, (B, N)).astype(np.int32)
+    want = native.index_max(data, idx, K)
+    got = _ops().index_max(torch.from_numpy(data).to(DEV), torch.from_numpy(idx).to(DEV), K)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_index_max_full_size_properties():
+    """BASELINE config 3 size (B'=16, C=128, N=16384, M=512): size-independent properties.
+    (1) every returned n is assigned to its node and attains the node's max; (2) idempotence
+    under a permutation of channels."""
+    B, C, N, K = 16, 128, 16384, 512
+    g = torch.Generator(device="cpu").manual_seed(5)
+    data = torch.randn(B, C, N, generator=g).to(DEV)
+    idx = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32).to(DEV)
+    out = _ops().index_max(data, idx, K).long()
+    assigned = torch.gather(idx.long().unsqueeze(1).expand(B, C, N), 2, out)       # node of the winner
+    node_ids = torch.arange(K, device=DEV).view(1, 1, K).expand(B, C, K)
+    counts = torch.zeros(B, K, device=DEV).scatter_add_(1, idx.long(), torch.ones(B, N, device=DEV))
+    nonempty = (counts > 0).unsqueeze(1).expand(B, C, K)
+    assert torch.equal(assigned[nonempty], node_ids[nonempty])
+    seg_max = torch.full((B, C, K), -float("inf"), device=DEV).scatter_reduce_(
+        2, idx.long().unsqueeze(1).expand(B, C, N), data, reduce="amax")
+    assert torch.equal(torch.gather(data, 2, out)[nonempty], seg_max[nonempty])
+    assert int(out[~nonempty].abs().sum()) == 0
+    perm = torch.randperm(C, device=DEV)
+    out_p = _ops().index_max(data[:, perm].contiguous(), idx, K).long()
+    assert torch.equal(out_p, out[:, perm])
+
+
+# ------------------------------------------------------------------ pairwise distance + ball_query
+def test_pairwise_dist_golden_bit_exact():
+    g = load_golden("dist_ball_cases.npz")
+    d = _ops().pairwise_dist(torch.from_numpy(g["node"]).to(DEV), torch.from_numpy(g["x"]).to(DEV))
+    assert np.array_equal(d.cpu().numpy(), g["dist"])
+
+
+def test_ball_query_golden():
+    g = load_golden("dist_ball_cases.npz")
+    import usip_amd
+    _, bq = usip_amd.install()
+    dist = torch.from_numpy(g["dist"]).to(DEV)
+    for fn in (bq.forward_cuda_shared_mem, bq.forward_cuda):
+        out = fn(dist, float(g["radius"]), int(g["K"]))
+        assert out.dtype == torch.int32
+        assert np.array_equal(out.cpu().numpy(), g["ball_idx_unpinned"])
+    fused = _ops().ball_query_coords(torch.from_numpy(g["node"]).to(DEV), torch.from_numpy(g["x"]).to(DEV),
+                                     float(g["radius"]), int(g["K"]))
+    assert np.array_equal(fused.cpu().numpy(), g["ball_idx_unpinned"])
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 1024, 64), (4, 64, 5000, 32), (3, 17, 1001, 7), (16, 512, 4096, 64),
+                                   (1, 8, 16384, 64), (2, 100, 16384, 64), (1, 2, 300, 1), (2, 3, 64, 128)])
+@pytest.mark.parametrize("density", ["sparse", "dense", "mixed"])
+def test_ball_query_vs_oracle(shape, density):
+    B, M, N, K = shape
+    rng = np.random.default_rng(B + M + N)
+    dist = rng.uniform(0, 10, (B, M, N)).astype(np.float32)
+    r = {"sparse": 0.002, "dense": 6.0, "mixed": 0.08}[density]
+    if density == "mixed":
+        dist[:, ::3] += 20.0                               # every third row: empty ball
+        dist[:, 1::3, N // 2:] = 0.0                       # hits only in the second half
+    dist[0, 0, -1] = np.float32(r)                         # boundary: <= is inclusive
+    dist[-1, -1, 0] = np.nan
+    want = native.ball_query(dist, r, K)
+    got = _ops().ball_query(torch.from_numpy(dist).to(DEV), r, K)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind,N,M", [("slab:20", 8192, 256), ("cube", 4096, 64), ("sphere", 1000, 33)])
+def test_fused_coords_equals_dist_then_query(kind, N, M):
+    from usip_amd import synth
+    rng = np.random.default_rng(11)
+    B, K = 3, 64
+    x = np.stack([synth.make_cloud(rng, N, kind) for _ in range(B)])
+    node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+    r = 2.0 if kind != "sphere" else 0.3
+    tx, tn = torch.from_numpy(x).to(DEV), torch.from_numpy(node).to(DEV)
+    dist = _ops().pairwise_dist(tn, tx)
+    assert np.array_equal(dist.cpu().numpy(), native.pairwise_dist(node, x))
+    a = _ops().ball_query(dist, r, K)
+    b = _ops().ball_query_coords(tn, tx, r, K)
+    assert torch.equal(a, b)
+    assert np.array_equal(a.cpu().numpy(), native.ball_query(dist.cpu().numpy(), r, K))
+
+
+def test_ball_query_full_size_properties():
+    """BASELINE config 3 size (B'=16, M=512, N=16384, K=64) on 'slab' clouds: every listed index
+    is inside the ball, strictly ascending over the genuine hits, cyclic beyond them, and the
+    number of genuine hits equals min(K, #inside)."""
+    from usip_amd import synth
+    B, M, N, K, r = 16, 512, 16384, 64, 2.0
+    rng = np.random.default_rng(3)
+    x = np.stack([synth.make_cloud(rng, N, "slab") for _ in range(B)])
+    node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+    tx, tn = torch.from_numpy(x).to(DEV), torch.from_numpy(node).to(DEV)
+    dist = _ops().pairwise_dist(tn, tx)
+    out = _ops().ball_query(dist, r, K).long()
+    inside = dist <= r
+    n_in = inside.sum(-1)
+    u = torch.clamp(n_in, max=K)
+    assert bool(torch.gather(inside, 2, out)[n_in > 0].all())
+    j = torch.arange(K, device=DEV).view(1, 1, K)
+    genuine = j < u.unsqueeze(-1)
+    asc = (out[..., 1:] > out[..., :-1]) | ~genuine[..., 1:]
+    assert bool(asc.all())
+    cyc = torch.gather(out, 2, j % torch.clamp(u, min=1).unsqueeze(-1))
+    assert torch.equal(out, torch.where(u.unsqueeze(-1) > 0, cyc, torch.zeros_like(out)))
+    # the genuine hits are the FIRST ones: rank of out[j] among the inside points is j
+    rank = torch.cumsum(inside.long(), -1) - 1
+    assert torch.equal(torch.gather(rank, 2, out)[genuine], j.expand_as(out)[genuine])
+    assert torch.equal(_ops().ball_query_coords(tn, tx, r, K).long(), out)

@@ -1,0 +1,53 @@
+"""ctypes loader of libusip_hip.so -- the only way the product reaches its kernels.
+
+There is no fallback: if the library is missing or fails to load, every operator raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libusip_hip.so")
+_lib = None
+
+_f32p = ctypes.c_void_p
+_i32p = ctypes.c_void_p
+_int = ctypes.c_int
+_flt = ctypes.c_float
+_stream = ctypes.c_void_p
+
+# name -> argtypes; must list every symbol include/usip_hip.h declares (tests check this).
+SIGNATURES = {
+    "usip_version": ([], ctypes.c_char_p),
+    "usip_index_max_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _stream], _int),
+    "usip_index_max_f32_cpu": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _int], _int),
+    "usip_ball_query_f32": ([_f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),
+    "usip_pairwise_dist_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_ball_query_coords_f32": ([_f32p, _f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "usip_amd: %s is missing. Build it with `python -m usip_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        try:
+            l = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError("usip_amd: cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (args, res) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise RuntimeError("usip_amd: %s: invalid argument (USIP_EINVAL)" % what)
+    raise RuntimeError("usip_amd: %s: HIP error %d" % (what, rc))

@@ -1,0 +1,47 @@
+// usip_amd/csrc/common.h -- shared device/host helpers for libusip_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/usip_hip.h"
+
+#define USIP_WAVE 64
+
+#define USIP_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+static inline int usip_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Number of lanes below `lane` whose bit is set in a 64-bit wave mask.
+__device__ __forceinline__ int usip_mbcnt(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+// The distance the whole path uses, in the arithmetic order of the pinned oracle platform
+// (torch CPU norm: FMA chain over channels 0,1,2, then a correctly rounded sqrt).
+__device__ __forceinline__ float usip_sqdist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float s = dx * dx;                 // -ffp-contract=off: never fused by the compiler
+    s = __builtin_fmaf(dy, dy, s);     // v_fma_f32
+    s = __builtin_fmaf(dz, dz, s);
+    return s;
+}
+__device__ __forceinline__ float usip_dist(float ax, float ay, float az, float bx, float by, float bz)
+{
+    // sqrtf is the correctly rounded IEEE sqrt under hipcc's default
+    // -fhip-fp32-correctly-rounded-divide-sqrt (HIP's __fsqrt_rn is the 1-ulp native sqrt).
+    return sqrtf(usip_sqdist(ax, ay, az, bx, by, bz));
+}
+
+// 16-byte streaming (non-temporal) load: data that is read exactly once.
+typedef float usip_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 usip_load_stream4(const float* p)
+{
+    usip_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const usip_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}

@@ -1,0 +1,115 @@
+// usip_amd/csrc/index_max.hip -- SOM-node arg-max (index_max) on gfx950 (MI355X).
+//
+// Semantics: models/index_max_ext/index_max_cuda.cu:29-61 / index_max.cpp:98-109 of the
+// reference: per (b,c,k) the LOWEST n among the points assigned to node k (index[b,n]==k)
+// whose value is the maximum, if that maximum is strictly above -1000; otherwise 0.
+//
+// The reference gives each (b,c) row to ONE thread that walks N points serially (C blocks x
+// B threads, uncoalesced).  Here a workgroup owns CH channel rows of one cloud: all 256 lanes
+// stream the rows with 16-B loads (coalesced, the index row is read once for the CH rows)
+// and fold every point into a per-node table in LDS with ONE 64-bit ds_max per point:
+//     key = (order-preserving bits of the value) << 32 | ~n
+// so the LDS atomic max implements "greater value wins, then lower n wins" exactly, with no
+// ordering dependence between lanes -- bit-identical to the serial loop.  The table starts at
+// key(-1000, n = none); values <= -1000 and NaN are filtered before the atomic (strict >).
+// HBM-bound by design: data + index in, B*C*K ints out.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned ordered_bits(float v)
+{
+    unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);       // monotone: a < b  <=>  ord(a) < ord(b)
+}
+
+constexpr float FLOOR = -1000.0f;                               // index_max_cuda.cu:37
+
+__device__ __forceinline__ void fold(unsigned long long* table, int k, float v, int n)
+{
+    if (v > FLOOR) {                                             // false for NaN as well
+        v += 0.0f;                                               // -0.0 -> +0.0: they compare equal
+        unsigned long long key = ((unsigned long long)ordered_bits(v) << 32) | (unsigned)(~n);
+        atomicMax(&table[k], key);                               // LDS ds_max_u64, no return
+    }
+}
+
+template <int CH, bool VEC>
+__global__ __launch_bounds__(256) void index_max_kernel(
+    const float* __restrict__ data, const int32_t* __restrict__ index, int32_t* __restrict__ out,
+    int C, int N, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned long long table[];   // [CH][K]
+    const int cgroups = C / CH;
+    const int b = blockIdx.x / cgroups;
+    const int c0 = (blockIdx.x % cgroups) * CH;
+    const unsigned long long init = ((unsigned long long)ordered_bits(FLOOR) << 32) | 0xffffffffull;
+    for (int i = threadIdx.x; i < CH * K; i += 256) table[i] = init;
+    __syncthreads();
+
+    const int32_t* idx = index + (long long)b * N;
+    const float* rows = data + ((long long)b * C + c0) * N;
+    if (VEC) {
+        for (int n = threadIdx.x * 4; n < N; n += 1024) {
+            int4 k4 = *reinterpret_cast<const int4*>(idx + n);
+            float4 v[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                v[c] = usip_load_stream4(rows + (long long)c * N + n);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                unsigned long long* t = table + c * K;
+                fold(t, k4.x, v[c].x, n);
+                fold(t, k4.y, v[c].y, n + 1);
+                fold(t, k4.z, v[c].z, n + 2);
+                fold(t, k4.w, v[c].w, n + 3);
+            }
+        }
+    } else {
+        for (int n = threadIdx.x; n < N; n += 256) {
+            int k = idx[n];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) fold(table + c * K, k, rows[(long long)c * N + n], n);
+        }
+    }
+    __syncthreads();
+    int32_t* o = out + ((long long)b * C + c0) * K;
+    for (int i = threadIdx.x; i < CH * K; i += 256) {
+        unsigned long long key = table[i];
+        o[i] = (key == init) ? 0 : (int32_t)(~(unsigned)key);
+    }
+}
+
+template <int CH>
+int launch(const float* data, const int32_t* index, int32_t* out, int B, int C, int N, int K, hipStream_t st)
+{
+    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(index) & 15u) == 0);
+    const size_t lds = (size_t)CH * K * sizeof(unsigned long long);
+    dim3 grid((unsigned)(B * (C / CH))), block(256);
+    if (vec)
+        hipLaunchKernelGGL((index_max_kernel<CH, true>), grid, block, lds, st, data, index, out, C, N, K);
+    else
+        hipLaunchKernelGGL((index_max_kernel<CH, false>), grid, block, lds, st, data, index, out, C, N, K);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+}  // namespace
+
+extern "C" int usip_index_max_f32(const float* data, const int32_t* index, int32_t* max_idx,
+                                  int B, int C, int N, int K, void* stream)
+{
+    if (B < 0 || C < 0 || N < 0 || K < 0) return USIP_EINVAL;
+    if ((long long)B * C * K == 0) return USIP_OK;
+    if (!max_idx || (N > 0 && (!data || !index))) return USIP_EINVAL;
+    if ((long long)B * C > 0x7fffffffLL) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // table = CH*K*8 B of LDS (160 KiB per CU): share the index row between CH channel rows
+    // while the grid still has >= ~4 workgroups per CU.
+    const long long rows = (long long)B * C;
+    if (K > 8192) return USIP_EINVAL;                            // 64 KiB table
+    if (C % 4 == 0 && rows / 4 >= 1024 && K <= 2048) return launch<4>(data, index, max_idx, B, C, N, K, st);
+    if (C % 2 == 0 && rows / 2 >= 1024 && K <= 4096) return launch<2>(data, index, max_idx, B, C, N, K, st);
+    return launch<1>(data, index, max_idx, B, C, N, K, st);
+}

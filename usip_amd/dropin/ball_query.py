@@ -1,0 +1,20 @@
+"""`ball_query` -- same two entry points as the reference extension
+(models/ball_query_ext/ball_query.cpp:45-48), backed by libusip_hip.so."""
+try:
+    from usip_amd import ops as _ops
+except ImportError:          # imported as a top-level module with usip_amd/dropin on sys.path
+    import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))))
+    from usip_amd import ops as _ops
+
+
+def forward_cuda_shared_mem(node_to_point_dist, radius, K):
+    """ball_query.cpp:33-39. dist f32 [B,M,N] on the device -> i32 [B,M,K]."""
+    return _ops.ball_query(node_to_point_dist, radius, K)
+
+
+def forward_cuda(node_to_point_dist, radius, K):
+    """The reference's forward_cuda is an unimplemented stub that prints and returns garbage
+    (ball_query.cpp:23-31); here it is an alias of the working entry point."""
+    return _ops.ball_query(node_to_point_dist, radius, K)

@@ -1,0 +1,102 @@
+"""Tensor-level wrappers over the C ABI (include/usip_hip.h).
+
+Every function takes contiguous device tensors, allocates its outputs with torch (device
+memory + stream plumbing only), enqueues the HIP kernels on torch's CURRENT stream and
+returns without synchronising.  Host tensors raise RuntimeError: there is no CPU path here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need(t: torch.Tensor, name: str, dtype):
+    # mirrors CHECK_INPUT of the reference (index_max.cpp:119-121, ball_query.cpp:10-12):
+    # device + contiguous, reported as RuntimeError; dtype is checked too (the reference
+    # would read garbage).
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA tensor/variable" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+
+
+def _ptr(t: torch.Tensor):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def index_max(data: torch.Tensor, index: torch.Tensor, K: int) -> torch.Tensor:
+    """a-1: data f32 [B,C,N], index i32 [B,N] -> i32 [B,C,K] (index_max_cuda.cu:83-98)."""
+    _need(data, "data", torch.float32)
+    _need(index, "index", torch.int32)
+    if data.dim() != 3 or index.dim() != 2 or index.shape[0] != data.shape[0] or index.shape[1] != data.shape[2]:
+        raise RuntimeError("index_max: expected data [B,C,N] and index [B,N]")
+    B, C, N = data.shape
+    out = torch.empty((B, C, int(K)), dtype=torch.int32, device=data.device)
+    with torch.cuda.device(data.device):
+        _lib.check(_lib.lib().usip_index_max_f32(_ptr(data), _ptr(index), _ptr(out), B, C, N, int(K),
+                                                 _stream(data)), "usip_index_max_f32")
+    return out
+
+
+def ball_query(dist: torch.Tensor, radius: float, K: int) -> torch.Tensor:
+    """a-2: dist f32 [B,M,N] -> i32 [B,M,K] (ball_query_cuda.cu:53-70)."""
+    _need(dist, "node_to_point_dist", torch.float32)
+    if dist.dim() != 3:
+        raise RuntimeError("ball_query: expected dist [B,M,N]")
+    B, M, N = dist.shape
+    out = torch.empty((B, M, int(K)), dtype=torch.int32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        _lib.check(_lib.lib().usip_ball_query_f32(_ptr(dist), _ptr(out), float(radius), int(K), B, M, N,
+                                                  _stream(dist)), "usip_ball_query_f32")
+    return out
+
+
+def pairwise_dist(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """|a[b,:,m] - x[b,:,n]| -> f32 [B,M,N]; a [B,3,M], x [B,3,N]."""
+    _need(a, "a", torch.float32)
+    _need(x, "x", torch.float32)
+    if a.dim() != 3 or x.dim() != 3 or a.shape[1] != 3 or x.shape[1] != 3 or a.shape[0] != x.shape[0]:
+        raise RuntimeError("pairwise_dist: expected a [B,3,M], x [B,3,N]")
+    B, _, M = a.shape
+    N = x.shape[2]
+    out = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().usip_pairwise_dist_f32(_ptr(a), _ptr(x), _ptr(out), B, M, N, _stream(a)),
+                   "usip_pairwise_dist_f32")
+    return out
+
+
+def ball_query_coords(node: torch.Tensor, x: torch.Tensor, radius: float, K: int) -> torch.Tensor:
+    """f-2: fused pairwise_dist + ball_query; node [B,3,M], x [B,3,N] -> i32 [B,M,K]."""
+    _need(node, "node", torch.float32)
+    _need(x, "x", torch.float32)
+    if node.dim() != 3 or x.dim() != 3 or node.shape[1] != 3 or x.shape[1] != 3 or node.shape[0] != x.shape[0]:
+        raise RuntimeError("ball_query_coords: expected node [B,3,M], x [B,3,N]")
+    B, _, M = node.shape
+    N = x.shape[2]
+    out = torch.empty((B, M, int(K)), dtype=torch.int32, device=node.device)
+    with torch.cuda.device(node.device):
+        _lib.check(_lib.lib().usip_ball_query_coords_f32(_ptr(node), _ptr(x), _ptr(out), float(radius), int(K),
+                                                         B, M, N, _stream(node)), "usip_ball_query_coords_f32")
+    return out
+
+
+def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:
+    """index_max.forward_cpu / forward_multi_thread_cpu (index_max.cpp:33-112): HOST tensors."""
+    for t, name, dt in ((data, "data", torch.float32), (index, "index", torch.int32)):
+        if t.is_cuda or not t.is_contiguous() or t.dtype != dt:
+            raise RuntimeError("%s must be a contiguous CPU %s tensor" % (name, dt))
+    B, C, N = data.shape
+    out = torch.empty((B, C, int(K)), dtype=torch.int32)
+    _lib.check(_lib.lib().usip_index_max_f32_cpu(_ptr(data), _ptr(index), _ptr(out), B, C, N, int(K),
+                                                 int(num_threads)), "usip_index_max_f32_cpu")
+    return out
