@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- detector fwd+bwd throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model ball|som] [--pairs 8]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = ModelDetector.optimize (models/keypoint_detector.py:158-207): siamese forward on
+B' = 2*pairs clouds, rigid transform, probabilistic chamfer + 2x keypoint-on-pc, backward,
+gradient all-reduce (N > 1), Adam update.  Workload = BASELINE.json configs[2], the
+configuration the metric is quoted on ("KITTI detector, N=16384, M=512, K=64, batch=8 on 1
+MI355X"): 8 pairs -> 16 clouds per GPU, Cs=4, node_knn_k_1=16; the K=64 model is
+RPN_Detector_Ball.  Weak scaling: every rank owns 8 pairs.  Synthetic "slab" clouds, seeds
+1234+rank; random-init weights (seeded, identical on every rank).
+
+Rank 0 prints ONE JSON line; `roofline` is for the kernel with the largest share of the timed
+region (HIP events on the launch stream, usip_amd/prof.py), `kernels` lists the others, and
+`cpu_baseline` is the oracle's PyTorch-CPU restatement of the same step timed on this box's
+host cores on a bounded sample (1 pair).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_F32_TFLOPS = 157.3         # f32-in MFMA / f32 vector peak
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="ball", choices=["ball", "som"])
+    ap.add_argument("--pairs", type=int, default=8, help="pairs per GPU (B); the detector sees 2B clouds")
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--m", type=int, default=512)
+    ap.add_argument("--cloud", default="slab")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, model):
+    """The oracle (PyTorch-CPU restatement, proven equal to the reference by the golden fixtures)
+    on a bounded sample: 1 pair = 2 clouds of the same workload, 1 warm-up + 2 timed steps."""
+    import numpy as np
+    from oracle import detector as od
+    from usip_amd import synth
+    from usip_amd.networks import detector_param_shapes
+    # ATen's strided reductions oversubscribe badly on a many-core host (62 s/step with 256
+    # threads vs ~5 s with 8-16): use at most 16 threads and report that count.
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    shapes = detector_param_shapes(model, 4)
+    filled = synth.fill_parameters(shapes)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
+         if not ("running_" in k or "num_batches" in k)}
+    bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
+    batch = {k: torch.from_numpy(v) for k, v in
+             synth.make_pair_batch(99, 1, args.n, args.m, 4, args.cloud).items()}
+    times = []
+    for i in range(3):
+        for p in P.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        od.detector_step(P, bufs, batch, model, 16, 1e-3, 0.01)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return dict(value=2.0 / t, unit="point-clouds/s", cores=cores, kind="port",
+                sample="1 pair (2 clouds) N=%d M=%d model=%s, oracle/detector.py fwd+losses+bwd, "
+                       "median of 2 after 1 warm-up (%.2f s/step)" % (args.n, args.m, model, t))
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from usip_amd import prof, synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=16)
+    torch.manual_seed(0)                                   # identical replicas, no broadcast needed
+    st = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer)
+    batch = batch_to_device(synth.make_pair_batch(1234 + rank, args.pairs, args.n, args.m, 4, args.cloud), dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        st.step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    if not args.no_kernel_timing:
+        prof.reset()
+        prof.enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st.step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof.enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(st.last["loss"].item())
+
+    if rank == 0:
+        clouds = world * 2 * args.pairs * args.steps
+        out = {
+            "metric": "point-clouds/sec detector fwd+bwd", "value": clouds / elapsed, "unit": "point-clouds/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "KITTI detector N=%d M=%d K=64 batch=%d pairs/GPU (BASELINE configs[2])"
+                                   % (args.n, args.m, args.pairs),
+                       "detector": "RPN_Detector_Ball" if args.model == "ball" else "RPN_Detector",
+                       "clouds_per_gpu": 2 * args.pairs, "surface_normal_len": 4, "node_knn_k_1": 16,
+                       "ball_radius": 2, "ball_k": 64, "cloud": args.cloud,
+                       "step": "fwd+losses+bwd" + ("+allreduce" if world > 1 else "") +
+                               ("" if args.no_optimizer else "+adam"),
+                       "parallelism": "dp%d" % world},
+            "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,
+        }
+        if not args.no_kernel_timing:
+            summ = prof.summary()
+            kernels = []
+            for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
+                mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
+                ach = r["TFLOPs"] if mfma else r["GBps"]
+                peak = PEAK_F32_TFLOPS if mfma else PEAK_HBM_GBPS
+                kernels.append({"kernel": name, "calls_per_step": r["calls"] / args.steps,
+                                "avg_us": round(r["avg_us"], 2),
+                                "share_of_step": round(r["total_ms"] / (elapsed * 1e3), 4),
+                                "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 3), "peak": peak,
+                                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
+                                "traffic": None})
+            if kernels:
+                top = dict(kernels[0])
+                out["roofline"] = {k: top[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+                out["roofline"]["kernel"] = top["kernel"]
+                out["roofline"]["avg_us"] = top["avg_us"]
+                out["kernels"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.model)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,29 @@ int usip_pairwise_dist_f32(const float* a, const float* x, float* dist,
 int usip_ball_query_coords_f32(const float* node, const float* x, int32_t* out_idx, float radius,
                                int K, int B, int M, int N, void* stream);
 
+/* ------------------------------------------------------------------ a-3 / a-4  SOM front end
+ * Replaces util/som.py:31-54 (query_topk with k = 1) and models/networks.py:85-108.
+ *   min_idx[b,n] = argmin_m (dx*dx + dy*dy) + dz*dz   (first minimum; squared distance summed
+ *                  in channel order without FMA, as ATen's pow-then-sum does)
+ * x f32 [B,3,N], node f32 [B,3,M] -> min_idx i32 [B,N].  The reference's dense one-hot `mask`
+ * [B,N,M] is never built; `mask_row_max` is (count > 0). */
+int usip_som_assign_f32(const float* x, const float* node, int32_t* min_idx,
+                        int B, int N, int M, void* stream);
+
+/* cluster_mean[b,:,m] = sum_{n: min_idx[b,n]==m} x[b,:,n] / (count[b,m] + 1e-5)  (networks.py:95-96),
+ * count i32 [B,M], and (if x_decentered != NULL) x_decentered[b,:,n] = x - cluster_mean[.., min_idx]
+ * (networks.py:103-107).  Deterministic (fixed-order) summation. */
+int usip_som_cluster_f32(const float* x, const int32_t* min_idx, float* cluster_mean,
+                         int32_t* count, float* x_decentered, int B, int N, int M, void* stream);
+
+/* ------------------------------------------------------------------ a-9 / a-10  chamfer core
+ * min_d[b,i] = min_j |a[b,:,i] - b[b,:,j]|_2 and arg[b,i] = FIRST j attaining it, exactly what
+ * torch.min(torch.norm(a.unsqueeze(3) - b.unsqueeze(2), dim=1), dim=2) returns
+ * (models/losses.py:62-66, :81, :86, :135-143) without materialising the B x Ma x Nb matrix.
+ * a f32 [B,3,Ma], b f32 [B,3,Nb] -> min_d f32 [B,Ma], arg i32 [B,Ma]. */
+int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
+                     int B, int Ma, int Nb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,10 +55,11 @@ def shared_mlp(x: torch.Tensor, P: Params, bufs: Optional[Params], prefix: str, 
     parameters (PointNet's last layer and mlp3 do not: layers.py:534-535, networks.py:68)."""
     w = P[prefix + ".conv.weight"]
     b = P[prefix + ".conv.bias"]
-    w2 = w.reshape(w.shape[0], w.shape[1])
-    shape = x.shape
-    y = torch.matmul(w2, x.reshape(shape[0], shape[1], -1)) + b.view(1, -1, 1)
-    y = y.view(shape[0], w2.shape[0], *shape[2:])
+    # The same ATen operators the reference's modules call (nn.Conv1d / nn.Conv2d forward):
+    # whole-step GRADIENTS are sensitive to rounding-level changes of the forward through
+    # max-pool arg-max flips (DESIGN.md "gradient parity"), so the restatement keeps the op
+    # choice and is bit-identical to the reference on the pinned platform.
+    y = F.conv2d(x, w, b) if x.dim() == 4 else F.conv1d(x, w, b)
     if prefix + ".norm.weight" in P:
         rm = rv = None
         if bufs is not None:

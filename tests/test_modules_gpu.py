@@ -1,0 +1,171 @@
+"""GPU parity of the nn.Module surface and of the whole detector step against the golden
+vectors captured from the reference and against the oracle.
+
+Float bar: 1e-5 relative (conftest.assert_close).  Index tensors: bit-exact.
+Whole-step GRADIENTS are compared with a flip-tolerant bound, for the reason DESIGN.md
+("gradient parity") documents with numbers: the step's max-pools route each gradient to ONE
+arg-max position, so a rounding-level change anywhere in the forward (any GEMM that does not
+sum in ATen-CPU's exact order) can flip a near-tie and move a few gradient entries by ~1e-2
+-- the reference's own fp32 run sits 2e-4 from its fp64 run for the same reason.  Sharp (1e-5)
+gradient parity is asserted per operator on fixed inputs instead (layers / losses fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.requires_grad_(True) if grad else t
+
+
+def _load_filled(module):
+    from usip_amd import synth
+    sd = module.state_dict()
+    filled = synth.fill_parameters({k: tuple(v.shape) for k, v in sd.items()})
+    module.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(sd[k].shape) for k, v in filled.items()})
+    return module.to(DEV)
+
+
+def test_myconv2d_matches_reference_fwd_bwd_and_buffers():
+    from usip_amd import layers
+    g = load_golden("layers_cases.npz")
+    conv = _load_filled(layers.MyConv2d(7, 12, kernel_size=(1, 1), stride=1, padding=0, bias=True,
+                                        activation="relu", normalization="batch", momentum=0.1))
+    conv.train()
+    x = _t(g["conv2d_x"], True)
+    y = conv(x)
+    y.backward(_t(g["conv2d_gy"]))
+    assert_close(y.detach().cpu(), g["conv2d_y"], name="y")
+    assert_close(x.grad.cpu(), g["conv2d_gx"], name="gx")
+    assert_close(conv.conv.weight.grad.cpu(), g["conv2d_gw"], name="gw")
+    assert_close(conv.norm.weight.grad.cpu(), g["conv2d_ggamma"], name="ggamma")
+    assert_close(conv.norm.bias.grad.cpu(), g["conv2d_gbeta"], name="gbeta")
+    assert_close(conv.norm.running_mean.cpu(), g["conv2d_running_mean"], name="running_mean")
+    assert_close(conv.norm.running_var.cpu(), g["conv2d_running_var"], name="running_var")
+    conv.eval()
+    assert_close(conv(x.detach()).detach().cpu(), g["conv2d_y_eval"], name="y_eval")
+
+
+def test_equivariant_layer_matches_reference():
+    from usip_amd import layers
+    g = load_golden("layers_cases.npz")
+    eq = _load_filled(layers.EquivariantLayer(6, 9, activation="relu", normalization="batch", momentum=0.1))
+    eq.train()
+    x = _t(g["eq_x"], True)
+    y = eq(x)
+    y.backward(_t(g["eq_gy"]))
+    assert_close(y.detach().cpu(), g["eq_y"], name="y")
+    assert_close(x.grad.cpu(), g["eq_gx"], name="gx")
+    assert_close(eq.conv.weight.grad.cpu(), g["eq_gw"], name="gw")
+
+
+def test_knn_fusion_module_matches_reference():
+    from usip_amd import layers
+    g = load_golden("layers_cases.npz")
+    knn = _load_filled(layers.GeneralKNNFusionModule(3 + 8, (16, 16), (24, 24), activation="relu",
+                                                     normalization="batch", momentum=0.1))
+    knn.train()
+    q = _t(g["knn_q"])
+    f = _t(g["knn_f"], True)
+    y = knn(query=q, database=q, x=f, K=5)
+    y.backward(_t(g["knn_gy"]))
+    assert_close(y.detach().cpu(), g["knn_y"], name="y")
+    assert_close(f.grad.cpu(), g["knn_gf"], rel=5e-5, name="gf")
+    assert_close(knn.layers_before[0].conv.weight.grad.cpu(), g["knn_gw0"], rel=5e-5, name="gw0")
+    assert_close(knn.layers_after[0].conv.weight.grad.cpu(), g["knn_gw_after0"], rel=5e-5, name="gw_after0")
+
+
+def test_losses_match_reference():
+    from usip_amd import losses
+    from usip_amd.networks import DetectorOptions
+    g = load_golden("losses_cases.npz")
+    opt = DetectorOptions()
+    src, dst = _t(g["pc_src"], True), _t(g["pc_dst"], True)
+    ss, sd = _t(g["pc_ss"], True), _t(g["pc_sd"], True)
+    loss, pure, weighted = losses.ChamferLoss_Brute(opt)(src, dst, ss, sd)
+    loss.backward()
+    assert_close(loss.detach().cpu(), g["pc_loss"], name="loss")
+    assert_close(pure.detach().cpu(), g["pc_pure"], name="pure")
+    assert_close(weighted.detach().cpu(), g["pc_weighted"], name="weighted")
+    for got, key in ((src.grad, "pc_gsrc"), (dst.grad, "pc_gdst"), (ss.grad, "pc_gss"), (sd.grad, "pc_gsd")):
+        assert_close(got.cpu(), g[key], name=key)
+    kp = _t(g["ss_kp"], True)
+    d = losses.KeypointOnPCLoss(opt)(kp, _t(g["ss_pc"]), None)
+    d.backward(_t(g["ss_gd"]))
+    assert np.array_equal(d.detach().cpu().numpy(), g["ss_d"])           # same arithmetic order: bit-exact
+    assert_close(kp.grad.cpu(), g["ss_gkp"], name="ss_gkp")
+
+
+def test_som_front_end_matches_reference():
+    from usip_amd import ops, som
+    from oracle import detector as od
+    g = load_golden("som_cases.npz")
+    x, node = _t(g["x"]), _t(g["node"])
+    mask, mask_row_max, min_idx = som.query_topk(node, x, node.shape[2], k=1)
+    assert np.array_equal(min_idx.cpu().numpy(), g["min_idx"])
+    assert np.array_equal(mask_row_max.cpu().numpy(), g["mask_row_max"])
+    assert np.array_equal(mask.sum(1).cpu().numpy(), g["count"])
+    mean, count, dec = ops.som_cluster(x, min_idx.int(), node.shape[2])
+    assert np.array_equal(count.cpu().numpy(), g["count"])
+    om, _, odec = od.som_cluster(torch.from_numpy(g["x"]), torch.from_numpy(g["min_idx"]).long(),
+                                 torch.from_numpy(g["count"]).long())
+    assert_close(mean.cpu(), om, name="cluster_mean")
+    assert_close(dec.cpu(), odec, name="x_decentered")
+
+
+def _run_step(fix):
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    from usip_amd import synth
+    g = load_golden(fix)
+    model = str(g["cfg_model"])
+    cs = g["in/src_sn"].shape[1]
+    opt = DetectorOptions(surface_normal_len=cs, node_knn_k_1=int(g["cfg_knn"]),
+                          loss_sigma_lower_bound=float(g["cfg_sigma_lb"]),
+                          keypoint_on_pc_alpha=float(g["cfg_alpha"]))
+    st = DetectorStep(model, opt, DEV)
+    sd = st.detector.state_dict()
+    st.load_numpy_state(synth.fill_parameters({k: tuple(v.shape) for k, v in sd.items()}))
+    batch = batch_to_device({k[3:]: v for k, v in g.items() if k.startswith("in/")}, DEV)
+    st.step(batch)
+    torch.cuda.synchronize()
+    return g, st
+
+
+@pytest.mark.parametrize("fix", ["detector_som_cfg1.npz", "detector_ball_micro.npz", "detector_som_micro.npz"])
+def test_detector_step_matches_reference(fix):
+    g, st = _run_step(fix)
+    idx = st.detector.last_indices
+    if "idx/min_idx" in g:
+        assert np.array_equal(idx["min_idx"].cpu().numpy(), g["idx/min_idx"])
+        assert np.array_equal(idx["first_idx"].cpu().numpy(), g["idx/index_max_0"])
+        assert np.array_equal(idx["second_idx"].cpu().numpy(), g["idx/index_max_1"])
+    if "idx/ball_idx" in g:
+        assert np.array_equal(idx["ball_idx"].cpu().numpy(), g["idx/ball_idx"])
+    assert np.array_equal(idx["knn_I"].cpu().numpy(), g["idx/knn_I"])
+    for k in ("node", "keypoints", "sigmas", "loss", "loss_chamfer", "chamfer_pure", "chamfer_weighted",
+              "loss_on_pc_src", "loss_on_pc_dst"):
+        assert_close(st.last[k].detach().cpu().numpy(), g[k], name=k)
+    for k, v in st.detector.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(v.cpu().numpy(), g["buf/" + k], name=k)
+    # gradients: flip-tolerant whole-step bound (see module docstring)
+    num = den = 0.0
+    biggest = max(float(v) for k, v in g.items() if k.startswith("grad_norm/"))
+    for k, p in st.detector.named_parameters():
+        if float(g["grad_norm/" + k]) < 1e-5 * biggest:
+            continue      # analytically zero gradient (a bias whose effect a later BatchNorm removes):
+            #               the reference's value is rounding noise, not a number to match
+        gr = p.grad.detach().cpu().numpy().ravel().astype(np.float64)
+        ref_head = g["grad_head/" + k].astype(np.float64)
+        scale = max(np.abs(gr).max(), 1e-30)
+        assert np.abs(gr[:48] - ref_head).max() / scale <= 5e-2, k
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["grad_norm/" + k])) <= 5e-3 * float(g["grad_norm/" + k]), k
+        num += ((gr[:48] - ref_head) ** 2).sum()
+        den += (ref_head ** 2).sum()
+    assert np.sqrt(num / den) <= 5e-3

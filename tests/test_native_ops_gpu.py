@@ -112,7 +112,7 @@ def test_fused_coords_equals_dist_then_query(kind, N, M):
     rng = np.random.default_rng(11)
     B, K = 3, 64
     x = np.stack([synth.make_cloud(rng, N, kind) for _ in range(B)])
-    node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+    node = np.ascontiguousarray(np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)]))
     r = 2.0 if kind != "sphere" else 0.3
     tx, tn = torch.from_numpy(x).to(DEV), torch.from_numpy(node).to(DEV)
     dist = _ops().pairwise_dist(tn, tx)
@@ -131,7 +131,7 @@ def test_ball_query_full_size_properties():
     B, M, N, K, r = 16, 512, 16384, 64, 2.0
     rng = np.random.default_rng(3)
     x = np.stack([synth.make_cloud(rng, N, "slab") for _ in range(B)])
-    node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+    node = np.ascontiguousarray(np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)]))
     tx, tn = torch.from_numpy(x).to(DEV), torch.from_numpy(node).to(DEV)
     dist = _ops().pairwise_dist(tn, tx)
     out = _ops().ball_query(dist, r, K).long()

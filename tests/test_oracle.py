@@ -127,12 +127,13 @@ def test_detector_step_oracle_matches_reference(fix):
     for k in ("node", "keypoints", "sigmas", "loss", "loss_chamfer", "chamfer_pure", "chamfer_weighted",
               "loss_on_pc_src", "loss_on_pc_dst"):
         assert_close(res[k].detach().numpy(), g[k], name=k)
+    biggest = max(float(v) for k, v in g.items() if k.startswith("grad_norm/"))
     for k, p in P.items():
         gr = p.grad.numpy().ravel().astype(np.float64)
         gn = float(g["grad_norm/" + k])
-        if k.endswith("conv.bias") and (k.rsplit(".", 2)[0] + ".norm.weight") in P:
-            # a conv bias in front of BatchNorm has an analytically zero gradient; what autograd
-            # returns is rounding noise relative to the upstream gradient, not a value to match
+        if gn < 1e-5 * biggest:
+            # analytically zero gradient (a conv bias whose effect a later BatchNorm removes): what
+            # autograd returns is rounding noise, not a value to match
             continue
         assert_close(np.sqrt((gr ** 2).sum()), gn, rel=2e-5, name="grad_norm/" + k)
         scale = max(np.abs(gr).max(), 1e-30)

@@ -22,6 +22,9 @@ SIGNATURES = {
     "usip_index_max_f32_cpu": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _int], _int),
     "usip_ball_query_f32": ([_f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),
     "usip_pairwise_dist_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_som_assign_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
+    "usip_som_cluster_f32": ([_f32p, _i32p, _f32p, _i32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_nearest_f32": ([_f32p, _f32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_ball_query_coords_f32": ([_f32p, _f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),
 }
 
@@ -33,10 +36,22 @@ def lib():
             raise RuntimeError(
                 "usip_amd: %s is missing. Build it with `python -m usip_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64.so (same SONAME as /opt/rocm's).  The tensors we
+        # are handed live in THAT runtime, so it must be the one already loaded when our library's
+        # dependency is resolved: import torch first, then check that exactly one HIP runtime is mapped.
+        import torch  # noqa: F401
         try:
             l = ctypes.CDLL(LIB_PATH)
         except OSError as e:
             raise RuntimeError("usip_amd: cannot load %s: %s" % (LIB_PATH, e)) from e
+        try:
+            with open("/proc/self/maps") as f:
+                runtimes = sorted({ln.split()[-1] for ln in f if "libamdhip64" in ln})
+        except OSError:
+            runtimes = []
+        if len(runtimes) > 1:
+            raise RuntimeError("usip_amd: two HIP runtimes are loaded (%s); import torch before anything "
+                               "that links libamdhip64" % ", ".join(runtimes))
         for name, (args, res) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args

@@ -140,9 +140,9 @@ int launch(const float* dist, int32_t* out, float radius, int K, long long rows,
     const size_t lds = (size_t)(SPLIT * K + SPLIT) * sizeof(int);
     dim3 grid((unsigned)rows), block(SPLIT * 64);
     if (vec)
-        hipLaunchKernelGGL((ball_query_kernel<SPLIT, true>), grid, block, lds, st, dist, out, radius, K, N);
+        USIP_LAUNCH((ball_query_kernel<SPLIT, true>), grid, block, lds, st, dist, out, radius, K, N);
     else
-        hipLaunchKernelGGL((ball_query_kernel<SPLIT, false>), grid, block, lds, st, dist, out, radius, K, N);
+        USIP_LAUNCH((ball_query_kernel<SPLIT, false>), grid, block, lds, st, dist, out, radius, K, N);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -147,9 +147,9 @@ extern "C" int usip_ball_query_coords_f32(const float* node, const float* x, int
     dim3 grid(usip_ceil_div(M, 4 * R), B), block(256);
     const size_t lds = (size_t)4 * R * K * sizeof(int);
     if (vec)
-        hipLaunchKernelGGL((ball_query_coords_kernel<true>), grid, block, lds, st, node, x, out_idx, T, K, M, N);
+        USIP_LAUNCH((ball_query_coords_kernel<true>), grid, block, lds, st, node, x, out_idx, T, K, M, N);
     else
-        hipLaunchKernelGGL((ball_query_coords_kernel<false>), grid, block, lds, st, node, x, out_idx, T, K, M, N);
+        USIP_LAUNCH((ball_query_coords_kernel<false>), grid, block, lds, st, node, x, out_idx, T, K, M, N);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -6,6 +6,14 @@
 
 #define USIP_WAVE 64
 
+// hipGetLastError() is sticky per thread: clear whatever an unrelated earlier runtime call left
+// behind, launch, then USIP_LAUNCH_CHECK() reports this launch only.
+#define USIP_LAUNCH(...)                                      \
+    do {                                                      \
+        (void)hipGetLastError();                              \
+        hipLaunchKernelGGL(__VA_ARGS__);                      \
+    } while (0)
+
 #define USIP_LAUNCH_CHECK()                                   \
     do {                                                      \
         hipError_t e__ = hipGetLastError();                   \

@@ -88,9 +88,9 @@ int launch(const float* data, const int32_t* index, int32_t* out, int B, int C, 
     const size_t lds = (size_t)CH * K * sizeof(unsigned long long);
     dim3 grid((unsigned)(B * (C / CH))), block(256);
     if (vec)
-        hipLaunchKernelGGL((index_max_kernel<CH, true>), grid, block, lds, st, data, index, out, C, N, K);
+        USIP_LAUNCH((index_max_kernel<CH, true>), grid, block, lds, st, data, index, out, C, N, K);
     else
-        hipLaunchKernelGGL((index_max_kernel<CH, false>), grid, block, lds, st, data, index, out, C, N, K);
+        USIP_LAUNCH((index_max_kernel<CH, false>), grid, block, lds, st, data, index, out, C, N, K);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -66,10 +66,10 @@ extern "C" int usip_pairwise_dist_f32(const float* a, const float* x, float* dis
     dim3 block(256);
     if (vec) {
         dim3 grid(usip_ceil_div(N, 1024), usip_ceil_div(M, TM), B);
-        hipLaunchKernelGGL((pairwise_dist_kernel<true>), grid, block, 0, st, a, x, dist, M, N);
+        USIP_LAUNCH((pairwise_dist_kernel<true>), grid, block, 0, st, a, x, dist, M, N);
     } else {
         dim3 grid(usip_ceil_div(N, 256), usip_ceil_div(M, TM), B);
-        hipLaunchKernelGGL((pairwise_dist_kernel<false>), grid, block, 0, st, a, x, dist, M, N);
+        USIP_LAUNCH((pairwise_dist_kernel<false>), grid, block, 0, st, a, x, dist, M, N);
     }
     USIP_LAUNCH_CHECK();
     return USIP_OK;

@@ -1,0 +1,189 @@
+"""nn.Module surface of the shared-MLP path: same class names, constructor signatures and
+state_dict keys as the reference's models/layers.py, for the classes its detectors instantiate
+(SURVEY 8 a-5, a-6, a-7, a-13), so released checkpoints load and models/networks.py builds on
+them unchanged.  The arithmetic lives in usip_amd.functional / the HIP library.
+
+Only what the detector path uses is provided: 1x1 kernels, 'batch' or no normalisation,
+'relu' or no activation.  Anything else raises NotImplementedError instead of silently
+taking another code path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import functional as Fh
+
+
+class _EpochDecayBatchNorm(_BatchNorm):
+    """BatchNorm whose momentum decays with the epoch (models/layers.py:49-71, :100-121):
+    momentum = max(0.01, momentum0 * decay ** (epoch // step)) once epoch >= 1 and step > 0."""
+
+    _dims = ()
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True,
+                 momentum_decay_step=None, momentum_decay=1):
+        super().__init__(num_features, eps, momentum, affine)
+        self.momentum_decay_step = momentum_decay_step
+        self.momentum_decay = momentum_decay
+        self.momentum_original = self.momentum
+
+    def _check_input_dim(self, input):
+        if input.dim() not in self._dims:
+            raise ValueError("expected %s input (got %dD input)" %
+                             (" or ".join("%dD" % d for d in self._dims), input.dim()))
+
+    def decay_momentum(self, epoch):
+        if epoch is not None and epoch >= 1 and self.momentum_decay_step is not None \
+                and self.momentum_decay_step > 0:
+            self.momentum = max(0.01, self.momentum_original *
+                                self.momentum_decay ** (epoch // self.momentum_decay_step))
+
+    def forward(self, input, epoch=None):
+        self._check_input_dim(input)
+        self.decay_momentum(epoch)
+        return torch.nn.functional.batch_norm(input, self.running_mean, self.running_var, self.weight,
+                                              self.bias, self.training, self.momentum, self.eps)
+
+
+class MyBatchNorm1d(_EpochDecayBatchNorm):
+    _dims = (2, 3)
+
+
+class MyBatchNorm2d(_EpochDecayBatchNorm):
+    _dims = (4,)
+
+
+def _check_supported(activation, normalization):
+    if activation not in (None, "relu"):
+        raise NotImplementedError("usip_amd: activation %r is outside the detector path (relu only)" % activation)
+    if normalization not in (None, "batch"):
+        raise NotImplementedError("usip_amd: normalization %r is outside the detector path (batch only)"
+                                  % normalization)
+
+
+def _init_conv(conv, fan_in):
+    conv.weight.data.normal_(0, math.sqrt(2.0 / fan_in))        # layers.py:196-205, :278-287
+    if conv.bias is not None:
+        conv.bias.data.zero_()
+
+
+class MyConv2d(nn.Module):
+    """1x1 Conv2d + BatchNorm2d + ReLU over grouped neighbourhoods B x C x M x K
+    (models/layers.py:172-216)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True,
+                 activation=None, normalization=None, momentum=0.1, bn_momentum_decay_step=None,
+                 bn_momentum_decay=1):
+        super().__init__()
+        _check_supported(activation, normalization)
+        ks = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size, kernel_size)
+        if tuple(ks) != (1, 1) or stride not in (1, (1, 1)) or padding not in (0, (0, 0)):
+            raise NotImplementedError("usip_amd: the shared MLP is a 1x1 convolution (stride 1, no padding)")
+        self.activation = activation
+        self.normalization = normalization
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
+        if normalization == "batch":
+            self.norm = MyBatchNorm2d(out_channels, momentum=momentum, affine=True,
+                                      momentum_decay_step=bn_momentum_decay_step,
+                                      momentum_decay=bn_momentum_decay)
+        if activation == "relu":
+            self.act = nn.ReLU()
+        _init_conv(self.conv, in_channels)
+
+    def forward(self, x, epoch=None):
+        bn = getattr(self, "norm", None)
+        if bn is not None:
+            bn.decay_momentum(epoch)
+        return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu")
+
+
+class EquivariantLayer(nn.Module):
+    """Conv1d(k=1) + BatchNorm1d + ReLU over points B x C x N (models/layers.py:248-303)."""
+
+    def __init__(self, num_in_channels, num_out_channels, activation="relu", normalization=None,
+                 momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        _check_supported(activation, normalization)
+        self.num_in_channels = num_in_channels
+        self.num_out_channels = num_out_channels
+        self.activation = activation
+        self.normalization = normalization
+        self.conv = nn.Conv1d(num_in_channels, num_out_channels, kernel_size=1, stride=1, padding=0)
+        if normalization == "batch":
+            self.norm = MyBatchNorm1d(num_out_channels, momentum=momentum, affine=True,
+                                      momentum_decay_step=bn_momentum_decay_step,
+                                      momentum_decay=bn_momentum_decay)
+        if activation == "relu":
+            self.act = nn.ReLU()
+        _init_conv(self.conv, num_in_channels)
+
+    def forward(self, x, epoch=None):
+        bn = getattr(self, "norm", None)
+        if bn is not None:
+            bn.decay_momentum(epoch)
+        return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu")
+
+
+class PointNet(nn.Module):
+    """Stack of EquivariantLayers; the last one has neither normalisation nor activation
+    (models/layers.py:524-544)."""
+
+    def __init__(self, in_channels, out_channels_list, activation, normalization, momentum=0.1,
+                 bn_momentum_decay_step=None, bn_momentum_decay=1, output_init_radius=None):
+        super().__init__()
+        self.layers = nn.ModuleList()
+        prev = in_channels
+        last = len(out_channels_list) - 1
+        for i, c_out in enumerate(out_channels_list):
+            if i != last:
+                self.layers.append(EquivariantLayer(prev, c_out, activation, normalization, momentum,
+                                                    bn_momentum_decay_step, bn_momentum_decay))
+            else:
+                self.layers.append(EquivariantLayer(prev, c_out, None, None))
+            prev = c_out
+        if output_init_radius is not None:
+            self.layers[last].conv.bias.data.uniform_(-output_init_radius, output_init_radius)
+
+    def forward(self, x, epoch=None):
+        for layer in self.layers:
+            x = layer(x, epoch)
+        return x
+
+
+class GeneralKNNFusionModule(nn.Module):
+    """query -> database KNN, gather, shared MLP, max over K, concat, shared MLP, max over K
+    (models/layers.py:375-440)."""
+
+    def __init__(self, in_channels, out_channels_list_before, out_channels_list_after, activation,
+                 normalization, momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=1):
+        super().__init__()
+        kw = dict(kernel_size=1, stride=1, padding=0, bias=True, activation=activation,
+                  normalization=normalization, momentum=momentum,
+                  bn_momentum_decay_step=bn_momentum_decay_step, bn_momentum_decay=bn_momentum_decay)
+        self.layers_before = nn.ModuleList()
+        prev = in_channels
+        for c_out in out_channels_list_before:
+            self.layers_before.append(MyConv2d(prev, c_out, **kw))
+            prev = c_out
+        self.layers_after = nn.ModuleList()
+        prev = 2 * prev
+        for c_out in out_channels_list_after:
+            self.layers_after.append(MyConv2d(prev, c_out, **kw))
+            prev = c_out
+
+    def forward(self, query, database, x, K, epoch=None):
+        """query Bx3xM, database Bx3xN, x BxCxN -> BxC'xM.  Coordinates carry no gradient."""
+        knn_I = Fh.knn_indices(query, database, K)                       # layers.py:417-421
+        self.last_knn_I = knn_I
+        coord = Fh.gather_neighbours(database.detach(), knn_I) - query.detach().unsqueeze(3)
+        feat = Fh.gather_neighbours(x, knn_I)
+        h = torch.cat((coord, feat), dim=1)
+        for layer in self.layers_before:
+            h = layer(h, epoch)
+        pooled = torch.max(h, dim=3, keepdim=True)[0]
+        y = torch.cat((pooled.expand_as(h), h), dim=1)
+        for layer in self.layers_after:
+            y = layer(y, epoch)
+        return torch.max(y, dim=3, keepdim=False)[0]

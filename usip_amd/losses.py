@@ -1,0 +1,61 @@
+"""Detector losses with the reference's class names and call signatures (models/losses.py),
+built on the fused nearest-neighbour kernel instead of materialised B x M x N matrices
+(SURVEY 8 a-9, a-10)."""
+import torch
+import torch.nn as nn
+
+from . import functional as Fh
+
+
+class ChamferLoss_Brute(nn.Module):
+    """Probabilistic (sigma-weighted) chamfer loss (models/losses.py:44-99).
+    forward(src Bx3xM, dst Bx3xN, sigma_src BxM, sigma_dst BxN) -> (loss, chamfer_pure, chamfer_weighted)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.dimension = 3
+
+    def forward(self, pc_src_input, pc_dst_input, sigma_src=None, sigma_dst=None):
+        a, J = Fh.nearest_distance(pc_src_input, pc_dst_input)          # row minima  (:81)
+        c, I = Fh.nearest_distance(pc_dst_input, pc_src_input)          # column minima (:86)
+        self.last_indices = (J, I)
+        if sigma_src is None or sigma_dst is None:                       # losses.py:68-78
+            return a + c, a + c, a + c
+        s_fwd = (sigma_src + torch.gather(sigma_dst, 1, J)) / 2
+        forward_loss = (torch.log(s_fwd) + a / s_fwd).mean()
+        s_bwd = (sigma_dst + torch.gather(sigma_src, 1, I)) / 2
+        backward_loss = (torch.log(s_bwd) + c / s_bwd).mean()
+        chamfer_pure = (a.mean() + c.mean()).detach()
+        w_fwd = (1.0 / s_fwd) / torch.mean(1.0 / s_fwd)
+        w_bwd = (1.0 / s_bwd) / torch.mean(1.0 / s_bwd)
+        chamfer_weighted = ((w_fwd * a).mean() + (w_bwd * c).mean()).detach()
+        return forward_loss + backward_loss, chamfer_pure, chamfer_weighted
+
+
+class SingleSideChamferLoss_Brute(nn.Module):
+    """min_n |src[b,:,m] - dst[b,:,n]| -> BxM (models/losses.py:119-143)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.dimension = 3
+
+    def forward(self, pc_src_input, pc_dst_input):
+        return Fh.nearest_distance(pc_src_input, pc_dst_input.detach()
+                                   if not pc_dst_input.requires_grad else pc_dst_input)[0]
+
+
+class KeypointOnPCLoss(nn.Module):
+    """Keypoint-to-cloud distance (models/losses.py:102-116).  The point-to-plane variant
+    (sn given) is not a default anywhere and is outside the path."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.single_side_chamfer = SingleSideChamferLoss_Brute(opt)
+
+    def forward(self, keypoint, pc, sn=None):
+        if sn is not None:
+            raise NotImplementedError("usip_amd: point_to_plane keypoint-on-pc loss is outside the path")
+        return self.single_side_chamfer(keypoint, pc)

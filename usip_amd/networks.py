@@ -1,0 +1,159 @@
+"""The two detectors of the path, with the reference's class names, constructor, forward
+signature and state_dict keys (models/networks.py:20-162 RPN_Detector, :611-738
+RPN_Detector_Ball), written on the fused HIP operators: no B x N x M temporaries, no dense
+one-hot masks, distances in the kernels.
+
+forward(x Bx3xN, sn BxCsxN, node Bx3xM, is_train=False, epoch=None)
+    -> (nodes Bx3xM, keypoints Bx3xM, sigmas BxM, None)
+`is_train` is accepted and ignored as in the reference; train/eval is module state.
+"""
+import torch
+import torch.nn as nn
+
+from . import functional as Fh
+from . import ops
+from .layers import EquivariantLayer, GeneralKNNFusionModule, MyConv2d, PointNet
+
+
+def _bn_kw(opt):
+    return dict(momentum=opt.bn_momentum, bn_momentum_decay_step=opt.bn_momentum_decay_step,
+                bn_momentum_decay=opt.bn_momentum_decay)
+
+
+class _DetectorTail(nn.Module):
+    """knnlayer_1 + mlp1..3 + softplus, shared by every detector (networks.py:41-72, :135-154)."""
+
+    def _build_tail(self, opt):
+        assert opt.node_knn_k_1 >= 2
+        self.C2 = 512
+        self.knnlayer_1 = GeneralKNNFusionModule(3 + self.C1, (self.C2 // 2, self.C2 // 2, self.C2 // 2),
+                                                 (self.C2, self.C2), activation=opt.activation,
+                                                 normalization=opt.normalization, **_bn_kw(opt))
+        self.mlp1 = EquivariantLayer(self.C1 + self.C2, 512, activation=opt.activation,
+                                     normalization=opt.normalization, **_bn_kw(opt))
+        self.mlp2 = EquivariantLayer(512, 256, activation=opt.activation,
+                                     normalization=opt.normalization, **_bn_kw(opt))
+        self.mlp3 = EquivariantLayer(256, 4, activation=None, normalization=None)
+        self.mlp3.conv.weight.data.normal_(0, 1e-4)                      # networks.py:70-71
+        self.mlp3.conv.bias.data.zero_()
+        self.softplus = torch.nn.Softplus()
+
+    def _tail(self, centre, node_feature, epoch):
+        knn_feature = self.knnlayer_1(query=centre, database=centre, x=node_feature,
+                                      K=self.opt.node_knn_k_1, epoch=epoch)
+        agg = torch.cat((node_feature, knn_feature), dim=1)
+        y = self.mlp2(self.mlp1(agg))                                    # no epoch: networks.py:147-148
+        ks = self.mlp3(y)
+        keypoints = ks[:, 0:3, :] + centre
+        sigmas = self.softplus(ks[:, 3, :]) + self.opt.loss_sigma_lower_bound
+        return keypoints, sigmas
+
+
+class RPN_Detector(_DetectorTail):
+    """SOM variant: nearest-node assignment -> PointNet -> index_max -> PointNet -> index_max
+    -> node KNN fusion -> head (models/networks.py:20-162)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        if opt.k != 1:
+            raise NotImplementedError("usip_amd: RPN_Detector is implemented for opt.k == 1")
+        self.C1 = 128
+        h = self.C1 // 2
+        self.first_pointnet = PointNet(3 + opt.surface_normal_len, [h, h, h], activation=opt.activation,
+                                       normalization=opt.normalization, **_bn_kw(opt))
+        self.second_pointnet = PointNet(self.C1, [self.C1, self.C1], activation=opt.activation,
+                                        normalization=opt.normalization, **_bn_kw(opt))
+        self._build_tail(opt)
+
+    def forward(self, x, sn, node, is_train=False, epoch=None):
+        Fh.require_device(x, "RPN_Detector")
+        B, _, N = x.shape
+        M = node.shape[2]
+        x = x.contiguous()
+        min_idx32 = ops.som_assign(x, node.contiguous())                  # som.py:31-39
+        cluster_mean, count, x_dec = ops.som_cluster(x, min_idx32, M)     # networks.py:87-107
+        has_pts = (count > 0).to(x.dtype).unsqueeze(1)                    # mask_row_max
+        min_idx = min_idx32.long()
+        self.last_indices = dict(min_idx=min_idx32)
+        feat_in = torch.cat((x_dec, sn), dim=1) if self.opt.surface_normal_len >= 1 else x_dec
+        first = self.first_pointnet(feat_in, epoch)
+        first_idx = ops.index_max(first.detach().contiguous(), min_idx32, M).long()   # networks.py:117-118
+        first_max = first.gather(2, first_idx) * has_pts
+        scattered = torch.gather(first_max, 2, min_idx.unsqueeze(1).expand(B, first.shape[1], N))
+        second = self.second_pointnet(torch.cat((first, scattered), dim=1), epoch)
+        second_idx = ops.index_max(second.detach().contiguous(), min_idx32, M).long()  # networks.py:130-131
+        second_max = second.gather(2, second_idx) * has_pts
+        self.last_indices.update(first_idx=first_idx, second_idx=second_idx)
+        keypoints, sigmas = self._tail(cluster_mean, second_max, epoch)
+        self.last_indices["knn_I"] = self.knnlayer_1.last_knn_I
+        return cluster_mean, keypoints, sigmas, None
+
+
+class RPN_Detector_Ball(_DetectorTail):
+    """Ball-query variant (radius 2, 64 samples, both hard-coded in the reference:
+    models/networks.py:691-692): ball grouping -> grouped shared MLP -> max -> concat -> MLP ->
+    max -> node KNN fusion -> head (networks.py:611-738)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.C1 = 128
+        h = self.C1 // 2
+        kw = dict(kernel_size=(1, 1), stride=1, padding=0, bias=True, activation=opt.activation,
+                  normalization=opt.normalization, **_bn_kw(opt))
+        self.conv1 = MyConv2d(3 + opt.surface_normal_len, h, **kw)
+        self.conv2 = MyConv2d(h, h, **kw)
+        self.conv3 = MyConv2d(h, h, **kw)
+        self.conv4 = MyConv2d(self.C1, self.C1, **kw)
+        self.conv5 = MyConv2d(self.C1, self.C1, **kw)
+        self._build_tail(opt)
+        self.ball_radius = 2
+        self.ball_k = 64
+
+    def forward(self, x, sn, node, is_train=False, epoch=None):
+        Fh.require_device(x, "RPN_Detector_Ball")
+        x = x.contiguous()
+        node = node.contiguous()
+        x_aug = torch.cat((x, sn), dim=1)
+        ball_idx = ops.ball_query_coords(node, x, self.ball_radius, self.ball_k).long()   # :694-698 fused
+        g = Fh.gather_neighbours(x_aug, ball_idx)
+        g = torch.cat((g[:, 0:3] - node.unsqueeze(3), g[:, 3:]), dim=1)   # networks.py:703
+        h = self.conv3(self.conv2(self.conv1(g)))                         # no epoch: networks.py:705
+        pooled = torch.max(h, dim=3, keepdim=True)[0]
+        h = self.conv5(self.conv4(torch.cat((h, pooled.expand_as(h)), dim=1)))
+        second_max = torch.max(h, dim=3, keepdim=False)[0]
+        keypoints, sigmas = self._tail(node, second_max, epoch)
+        self.last_indices = dict(ball_idx=ball_idx, knn_I=self.knnlayer_1.last_knn_I)
+        return node, keypoints, sigmas, None
+
+
+class DetectorOptions:
+    """The fields of the reference's argparse namespace that the detector path reads
+    (kitti/options_detector.py:14-60), with the KITTI defaults."""
+
+    def __init__(self, **kw):
+        self.surface_normal_len = 4
+        self.activation = "relu"
+        self.normalization = "batch"
+        self.bn_momentum = 0.1
+        self.bn_momentum_decay_step = None
+        self.bn_momentum_decay = 0.6
+        self.k = 1
+        self.node_knn_k_1 = 16
+        self.loss_sigma_lower_bound = 0.001
+        self.keypoint_on_pc_alpha = 0.01
+        self.keypoint_on_pc_type = "point_to_point"
+        self.lr = 0.001
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def build_detector(model: str, opt) -> nn.Module:
+    return {"som": RPN_Detector, "ball": RPN_Detector_Ball}[model](opt)
+
+
+def detector_param_shapes(model: str, surface_normal_len: int):
+    """{state_dict key: shape} of a detector, parameters and BN buffers."""
+    net = build_detector(model, DetectorOptions(surface_normal_len=surface_normal_len))
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}

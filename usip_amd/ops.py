@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, prof
 
 
 def _stream(t: torch.Tensor):
@@ -35,13 +35,14 @@ def _ptr(t: torch.Tensor):
 
 def index_max(data: torch.Tensor, index: torch.Tensor, K: int) -> torch.Tensor:
     """a-1: data f32 [B,C,N], index i32 [B,N] -> i32 [B,C,K] (index_max_cuda.cu:83-98)."""
+    K = int(K)
     _need(data, "data", torch.float32)
     _need(index, "index", torch.int32)
     if data.dim() != 3 or index.dim() != 2 or index.shape[0] != data.shape[0] or index.shape[1] != data.shape[2]:
         raise RuntimeError("index_max: expected data [B,C,N] and index [B,N]")
     B, C, N = data.shape
     out = torch.empty((B, C, int(K)), dtype=torch.int32, device=data.device)
-    with torch.cuda.device(data.device):
+    with torch.cuda.device(data.device), prof.kernel("index_max", 4.0 * (B * C * N + B * N + B * C * K)):
         _lib.check(_lib.lib().usip_index_max_f32(_ptr(data), _ptr(index), _ptr(out), B, C, N, int(K),
                                                  _stream(data)), "usip_index_max_f32")
     return out
@@ -49,12 +50,13 @@ def index_max(data: torch.Tensor, index: torch.Tensor, K: int) -> torch.Tensor:
 
 def ball_query(dist: torch.Tensor, radius: float, K: int) -> torch.Tensor:
     """a-2: dist f32 [B,M,N] -> i32 [B,M,K] (ball_query_cuda.cu:53-70)."""
+    K = int(K)
     _need(dist, "node_to_point_dist", torch.float32)
     if dist.dim() != 3:
         raise RuntimeError("ball_query: expected dist [B,M,N]")
     B, M, N = dist.shape
     out = torch.empty((B, M, int(K)), dtype=torch.int32, device=dist.device)
-    with torch.cuda.device(dist.device):
+    with torch.cuda.device(dist.device), prof.kernel("ball_query", 4.0 * (B * M * N + B * M * K)):
         _lib.check(_lib.lib().usip_ball_query_f32(_ptr(dist), _ptr(out), float(radius), int(K), B, M, N,
                                                   _stream(dist)), "usip_ball_query_f32")
     return out
@@ -69,7 +71,7 @@ def pairwise_dist(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     B, _, M = a.shape
     N = x.shape[2]
     out = torch.empty((B, M, N), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with torch.cuda.device(a.device), prof.kernel("pairwise_dist", 4.0 * (B * M * N + 3 * B * (M + N))):
         _lib.check(_lib.lib().usip_pairwise_dist_f32(_ptr(a), _ptr(x), _ptr(out), B, M, N, _stream(a)),
                    "usip_pairwise_dist_f32")
     return out
@@ -77,6 +79,7 @@ def pairwise_dist(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 def ball_query_coords(node: torch.Tensor, x: torch.Tensor, radius: float, K: int) -> torch.Tensor:
     """f-2: fused pairwise_dist + ball_query; node [B,3,M], x [B,3,N] -> i32 [B,M,K]."""
+    K = int(K)
     _need(node, "node", torch.float32)
     _need(x, "x", torch.float32)
     if node.dim() != 3 or x.dim() != 3 or node.shape[1] != 3 or x.shape[1] != 3 or node.shape[0] != x.shape[0]:
@@ -84,10 +87,59 @@ def ball_query_coords(node: torch.Tensor, x: torch.Tensor, radius: float, K: int
     B, _, M = node.shape
     N = x.shape[2]
     out = torch.empty((B, M, int(K)), dtype=torch.int32, device=node.device)
-    with torch.cuda.device(node.device):
+    with torch.cuda.device(node.device), prof.kernel("ball_query_coords", 4.0 * (3 * B * (M + N) + B * M * K),
+                                                    8.0 * B * M * N):
         _lib.check(_lib.lib().usip_ball_query_coords_f32(_ptr(node), _ptr(x), _ptr(out), float(radius), int(K),
                                                          B, M, N, _stream(node)), "usip_ball_query_coords_f32")
     return out
+
+
+def _need_pts(t, name):
+    _need(t, name, torch.float32)
+    if t.dim() != 3 or t.shape[1] != 3:
+        raise RuntimeError("%s must be [B,3,N]" % name)
+
+
+def som_assign(x: torch.Tensor, node: torch.Tensor) -> torch.Tensor:
+    """a-3: nearest SOM node of every point. x [B,3,N], node [B,3,M] -> min_idx i32 [B,N]."""
+    _need_pts(x, "x")
+    _need_pts(node, "node")
+    B, _, N = x.shape
+    M = node.shape[2]
+    out = torch.empty((B, N), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device), prof.kernel("som_assign", 4.0 * (3 * B * (M + N) + B * N), 9.0 * B * M * N):
+        _lib.check(_lib.lib().usip_som_assign_f32(_ptr(x), _ptr(node), _ptr(out), B, N, M, _stream(x)),
+                   "usip_som_assign_f32")
+    return out
+
+
+def som_cluster(x: torch.Tensor, min_idx: torch.Tensor, M: int, decenter: bool = True):
+    """a-4: (cluster_mean f32 [B,3,M], count i32 [B,M], x_decentered f32 [B,3,N] or None)."""
+    _need_pts(x, "x")
+    _need(min_idx, "min_idx", torch.int32)
+    B, _, N = x.shape
+    mean = torch.empty((B, 3, int(M)), dtype=torch.float32, device=x.device)
+    count = torch.empty((B, int(M)), dtype=torch.int32, device=x.device)
+    dec = torch.empty_like(x) if decenter else None
+    with torch.cuda.device(x.device), prof.kernel("som_cluster", 4.0 * (7 * B * N + 4 * B * M)):
+        _lib.check(_lib.lib().usip_som_cluster_f32(_ptr(x), _ptr(min_idx), _ptr(mean), _ptr(count),
+                                                   _ptr(dec) if decenter else None, B, N, int(M), _stream(x)),
+                   "usip_som_cluster_f32")
+    return mean, count, dec
+
+
+def nearest(a: torch.Tensor, b: torch.Tensor):
+    """a-9/a-10 core: (min_j |a_i - b_j| f32 [B,Ma], first arg-min i32 [B,Ma])."""
+    _need_pts(a, "a")
+    _need_pts(b, "b")
+    B, _, Ma = a.shape
+    Nb = b.shape[2]
+    d = torch.empty((B, Ma), dtype=torch.float32, device=a.device)
+    arg = torch.empty((B, Ma), dtype=torch.int32, device=a.device)
+    with torch.cuda.device(a.device), prof.kernel("nearest", 4.0 * (3 * B * (Ma + Nb) + 2 * B * Ma), 8.0 * B * Ma * Nb):
+        _lib.check(_lib.lib().usip_nearest_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg), B, Ma, Nb, _stream(a)),
+                   "usip_nearest_f32")
+    return d, arg
 
 
 def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:

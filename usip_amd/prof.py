@@ -1,0 +1,53 @@
+"""Per-kernel HIP-event timing on the launch stream.
+
+Disabled by default (one boolean test per operator call).  bench.py enables it over the timed
+region: every operator wrapper brackets its kernel launch with two events recorded on torch's
+current stream -- the stream the kernel is launched on -- and tags the launch with its
+ALGORITHMIC work (bytes and/or flops), so that achieved GB/s or TFLOP/s per kernel come from
+live measurements of the same run that produces the throughput number.
+"""
+from collections import defaultdict
+from contextlib import contextmanager
+
+import torch
+
+enabled = False
+_records = defaultdict(list)        # name -> [(start_event, end_event, bytes, flops)]
+
+
+def enable(flag: bool = True):
+    global enabled
+    enabled = flag
+
+
+def reset():
+    _records.clear()
+
+
+@contextmanager
+def kernel(name: str, nbytes: float = 0.0, flops: float = 0.0):
+    if not enabled:
+        yield
+        return
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()                      # current stream == launch stream of the wrapped kernel
+    yield
+    e.record()
+    _records[name].append((s, e, nbytes, flops))
+
+
+def summary():
+    """{name: dict(calls, total_ms, avg_us, bytes_per_call, flops_per_call, GBps, TFLOPs)} (synchronises)."""
+    torch.cuda.synchronize()
+    out = {}
+    for name, recs in _records.items():
+        ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+        tot = sum(ms)
+        nb = sum(r[2] for r in recs) / len(recs)
+        fl = sum(r[3] for r in recs) / len(recs)
+        avg_s = tot / len(recs) * 1e-3
+        out[name] = dict(calls=len(recs), total_ms=tot, avg_us=avg_s * 1e6, bytes_per_call=nb,
+                         flops_per_call=fl, GBps=(nb / avg_s / 1e9) if avg_s > 0 else 0.0,
+                         TFLOPs=(fl / avg_s / 1e12) if avg_s > 0 else 0.0)
+    return out

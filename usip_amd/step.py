@@ -1,0 +1,106 @@
+"""One detector training step = ModelDetector.optimize of the reference
+(models/keypoint_detector.py:158-207), as a data-parallel unit:
+
+    siamese forward on cat(src, dst)  ->  R*kp*s + t  ->  probabilistic chamfer
+    + alpha * mean(keypoint-on-pc src) + alpha * mean(keypoint-on-pc dst)  ->  backward
+    [-> one RCCL all-reduce of the flat gradient bucket]  [-> Adam]
+
+Sharding: every (src, dst) pair is independent in forward, losses and backward;
+BatchNorm statistics are per replica in the reference (nn.DataParallel, no SyncBN) and stay
+per rank here.  Rank r owns pairs [r*B/W, (r+1)*B/W); the only exchange is the gradient sum.
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .losses import ChamferLoss_Brute, KeypointOnPCLoss
+from .networks import build_detector
+
+
+class FlatGradBucket:
+    """All parameter gradients of a module as views into ONE contiguous fp32 buffer, so the
+    data-parallel exchange is a single all-reduce (4.79 MB for the detector) instead of 46."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        """sum over ranks then / world: gradients of the mean-of-means loss (equal shards)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+class DetectorStep:
+    """Owns detector + criteria (+ optimizer) on one device and runs optimize()-equivalent steps."""
+
+    def __init__(self, model: str, opt, device, with_optimizer: bool = False):
+        self.opt = opt
+        self.device = torch.device(device)
+        self.detector = build_detector(model, opt).to(self.device)
+        self.chamfer_criteria = ChamferLoss_Brute(opt)
+        self.keypoint_on_pc_criteria = KeypointOnPCLoss(opt)
+        self.bucket = FlatGradBucket(self.detector)
+        self.optimizer = None
+        if with_optimizer:                                    # keypoint_detector.py:42-45
+            self.optimizer = torch.optim.Adam(self.detector.parameters(), lr=opt.lr, betas=(0.9, 0.999))
+        self.last: Dict[str, torch.Tensor] = {}
+
+    def load_numpy_state(self, state: Dict):
+        sd = self.detector.state_dict()
+        self.detector.load_state_dict({k: torch.as_tensor(v).reshape(sd[k].shape) for k, v in state.items()})
+        # load_state_dict copies in place, gradients keep pointing into the flat bucket
+
+    def forward_losses(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None):
+        B = batch["src_pc"].shape[0]
+        self.detector.train()                                 # keypoint_detector.py:171
+        nodes, kp, sg, _ = self.detector(torch.cat((batch["src_pc"], batch["dst_pc"]), 0),
+                                         torch.cat((batch["src_sn"], batch["dst_sn"]), 0),
+                                         torch.cat((batch["src_node"], batch["dst_node"]), 0),
+                                         True, epoch)         # forward_siamese :141-156
+        kp_src, kp_dst = kp[:B], kp[B:]
+        kp_t = torch.matmul(batch["R"], kp_src)               # :182
+        kp_t = kp_t * batch["scale"].unsqueeze(1).unsqueeze(2)   # :183
+        kp_t = kp_t + batch["shift"]                          # :184
+        loss_chamfer, pure, weighted = self.chamfer_criteria(kp_t, kp_dst, sg[:B], sg[B:])
+        alpha = self.opt.keypoint_on_pc_alpha
+        on_src = torch.mean(self.keypoint_on_pc_criteria(kp_src, batch["src_pc"], None)) * alpha
+        on_dst = torch.mean(self.keypoint_on_pc_criteria(kp_dst, batch["dst_pc"], None)) * alpha
+        loss = loss_chamfer + on_src + on_dst                 # :204
+        self.last = dict(node=nodes, keypoints=kp, sigmas=sg, loss=loss, loss_chamfer=loss_chamfer,
+                         chamfer_pure=pure, chamfer_weighted=weighted, loss_on_pc_src=on_src,
+                         loss_on_pc_dst=on_dst)
+        return loss
+
+    def step(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None, group=None):
+        """forward + losses + backward (+ gradient all-reduce) (+ Adam when constructed with it)."""
+        self.bucket.zero()                                    # detector.zero_grad() :186
+        loss = self.forward_losses(batch, epoch)
+        loss.backward()                                       # :205
+        self.bucket.all_reduce_mean(group)
+        if self.optimizer is not None:
+            self.optimizer.step()                             # :207
+        return loss
+
+
+def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
+    return {k: torch.as_tensor(v).to(device) for k, v in batch_np.items()}
+
+
+def shard_pairs(batch_np: Dict, rank: int, world: int) -> Dict:
+    """Rank r's contiguous slice of pairs."""
+    B = batch_np["src_pc"].shape[0]
+    assert B % world == 0, "pairs must divide evenly over ranks"
+    per = B // world
+    return {k: v[rank * per:(rank + 1) * per] for k, v in batch_np.items()}

@@ -69,7 +69,7 @@ def make_pair_batch(seed: int, pairs: int, n: int, m: int, cs: int, kind: str = 
         out["R"].append(R)
         out["scale"].append(np.float32(1.0))
         out["shift"].append(shift)
-    return {k: np.stack(v).astype(np.float32) for k, v in out.items()}
+    return {k: np.ascontiguousarray(np.stack(v), dtype=np.float32) for k, v in out.items()}
 
 
 def fill_parameters(named_shapes: Dict[str, tuple], head_std: float = 0.05
