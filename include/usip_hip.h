@@ -92,6 +92,54 @@ int usip_som_cluster_f32(const float* x, const int32_t* min_idx, float* cluster_
 int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
                      int B, int Ma, int Nb, void* stream);
 
+/* ------------------------------------------------------------------ a-5 / a-6 / a-7 / a-8  shared MLP
+ * Replaces, per layer, nn.Conv1d/Conv2d(k=1) + MyBatchNorm + ReLU and their autograd backward
+ * (models/layers.py:208-216 MyConv2d.forward, :293-303 EquivariantLayer.forward, :61-71/:112-121
+ * MyBatchNorm*.forward).  Activations are [nb][C][P] exactly as the reference stores them
+ * (B x C x M x K or B x C x N flattened over positions); fp32 MFMA, fp32 accumulate.
+ *
+ * usip_mlp_gemm_f32:  Y[b][m][p] = sum_k At[k][m] * pro(X[b][k][p]) + bias[m]
+ *   At is the matrix operand K-major ([K][M], row stride lda): W^T for the forward product,
+ *   W itself ([Cout][Cin]) for the data gradient dX = W^T . dY.
+ *   pro: 0 identity | 1 relu(x*coef[0][k] + coef[1][k]) | 2 BatchNorm+ReLU backward of X = dZ,
+ *        X2 = pre-BN output, coef = the [4][K] array written by usip_bn_backward_reduce_f32.
+ *   stats (may be NULL): [2][tiles][M] per-tile (sum, sum of squares) of Y over valid positions,
+ *   tiles = usip_mlp_gemm_tiles(M, P, nb); summed in fixed order by usip_bn_finalize_f32. */
+int usip_mlp_gemm_tiles(int M, int P, int nb);
+int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2, const float* coef,
+                      int pro, const float* bias, float* Y, float* stats,
+                      int M, int K, int P, int nb, void* stream);
+
+/* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
+ * coefficients coef[2][C] = (gamma*invstd, beta - mean*gamma*invstd), and the running-statistics
+ * update running = (1-momentum)*running + momentum*batch (unbiased variance), as F.batch_norm does
+ * in training mode.  running_mean/var may both be NULL.  count = nb*P. */
+int usip_bn_finalize_f32(const float* stats, int tiles, int C, long long count,
+                         const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, float* mean, float* invstd,
+                         float* coef, void* stream);
+
+/* Z = Y*coef[0][c] + coef[1][c], followed by ReLU when relu != 0.  Y, Z: [nb][C][P]. */
+int usip_bn_apply_f32(const float* Y, const float* coef, float* Z, int relu,
+                      int nb, int C, int P, void* stream);
+
+/* Backward reductions of BatchNorm(+ReLU): dbeta[c] = sum dYhat, dgamma[c] = sum dYhat*yhat with
+ * dYhat = dZ*[fma(y,coef_fwd[0],coef_fwd[1]) > 0] (dZ if !relu), and coef4[4][C] such that
+ * dY = coef4[0]*dYhat + coef4[2]*y + coef4[3] (coef4[0..1] repeat coef_fwd for the mask).
+ * Y == NULL selects the plain mode: dbeta[c] = sum dZ (bias gradient of a layer without BN).
+ * partial: workspace of 2*nb*C floats. */
+int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* coef_fwd,
+                                const float* mean, const float* invstd, const float* gamma, int relu,
+                                float* partial, float* dgamma, float* dbeta, float* coef4,
+                                int nb, int C, int P, void* stream);
+
+/* dW[m][n] = sum_{b,p} pro(G)[b][m][p] * X[b][n][p]   (pro 0: G = dY given; pro 2: G = dZ, G2 = Y,
+ * coef = coef4 as above).  workspace: usip_mlp_wgrad_workspace(M, N, P, nb) floats of partial tiles,
+ * reduced in fixed order (deterministic). */
+long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb);
+int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro, const float* X,
+                       float* workspace, float* dW, int M, int N, int P, int nb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,107 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the data-parallel host logic of
+usip_amd.step (pair sharding, flat gradient bucket, all-reduce-mean) -- the only exchange the
+path has.  The HIP forward/backward itself needs a GPU and is covered by -m gpu tests;
+here the 'backward' is a stand-in that writes rank-dependent gradients through the same bucket
+views autograd accumulates into."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions, build_detector
+    from usip_amd.step import FlatGradBucket, shard_pairs
+
+    torch.manual_seed(0)                                   # identical replicas, as bench.py does
+    net = build_detector("som", DetectorOptions(surface_normal_len=3))
+    bucket = FlatGradBucket(net)
+    n_params = sum(p.numel() for p in net.parameters())
+    assert bucket.flat.numel() == n_params == 1198660       # Cs=3 detector
+    # gradients are views into the one flat buffer (a single all-reduce moves all 46 tensors)
+    for p in net.parameters():
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr()
+        assert p.grad.data_ptr() < bucket.flat.data_ptr() + 4 * n_params
+    # stand-in backward: rank-dependent gradient, accumulated in place like autograd does
+    bucket.zero()
+    for i, p in enumerate(net.parameters()):
+        p.grad.add_(torch.full_like(p, float(rank + 1) * (i + 1)))
+    bucket.all_reduce_mean()
+    want = [(1 + 2) / 2.0 * (i + 1) for i in range(len(list(net.parameters())))]
+    ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(net.parameters(), want))
+    # pair sharding: contiguous, disjoint, complete
+    batch = synth.make_pair_batch(7, 4, 64, 8, 3, "sphere")
+    mine = shard_pairs(batch, rank, world)
+    assert mine["src_pc"].shape[0] == 2
+    ok = ok and np.array_equal(mine["src_pc"], batch["src_pc"][rank * 2:(rank + 1) * 2])
+    # parameters stay identical across ranks after an identical update of identical gradients
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    opt.step()
+    flat_p = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    gathered = [torch.empty_like(flat_p) for _ in range(world)]
+    dist.all_gather(gathered, flat_p)
+    ok = ok and torch.equal(gathered[0], gathered[1])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_allreduce_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_detector_state_dict_keys_match_reference_checkpoints():
+    """46 parameter tensors, reference key names, 1,198,724 parameters at Cs=4."""
+    from usip_amd.networks import DetectorOptions, build_detector
+    net = build_detector("som", DetectorOptions(surface_normal_len=4))
+    keys = dict(net.named_parameters())
+    assert len(keys) == 46 and sum(p.numel() for p in keys.values()) == 1198724
+    assert tuple(keys["first_pointnet.layers.0.conv.weight"].shape) == (64, 7, 1)
+    assert tuple(keys["knnlayer_1.layers_before.0.conv.weight"].shape) == (256, 131, 1, 1)
+    assert tuple(keys["knnlayer_1.layers_after.1.conv.weight"].shape) == (512, 512, 1, 1)
+    assert tuple(keys["mlp1.conv.weight"].shape) == (512, 640, 1)
+    assert tuple(keys["mlp3.conv.weight"].shape) == (4, 256, 1)
+    sd = net.state_dict()
+    assert "first_pointnet.layers.0.norm.running_mean" in sd
+    assert "mlp1.norm.num_batches_tracked" in sd
+    assert "first_pointnet.layers.2.norm.weight" not in sd        # last PointNet layer: no BN
+    ball = build_detector("ball", DetectorOptions(surface_normal_len=4))
+    bk = dict(ball.named_parameters())
+    assert tuple(bk["conv1.conv.weight"].shape) == (64, 7, 1, 1)
+    assert tuple(bk["conv5.conv.weight"].shape) == (128, 128, 1, 1)
+    assert len(bk) == 50 and sum(p.numel() for p in bk.values()) == 1199108   # conv3/conv5 keep their BN
+
+
+def test_product_forward_refuses_host_tensors():
+    """No CPU fallback in the product path."""
+    import pytest
+    from usip_amd.networks import DetectorOptions, build_detector
+    net = build_detector("ball", DetectorOptions())
+    x = torch.randn(1, 3, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(x, torch.randn(1, 4, 64), x[:, :, :8].contiguous())

@@ -1,0 +1,723 @@
+// usip_amd/csrc/shared_mlp.hip -- the shared-MLP (1x1 convolution + BatchNorm + ReLU) of the
+// USIP detector as hand-written fp32-MFMA kernels for gfx950.
+//
+// Reference: models/layers.py:208-216 (MyConv2d.forward), :293-303 (EquivariantLayer.forward):
+// cuDNN/MIOpen convolution + native batch-norm + clamp as three kernels per layer forward and
+// ~six per layer backward, every one a full round trip over B x C x M x K activations.
+//
+// Layout.  Activations stay in the reference's channel-major layout [cloud][C][P] (P = M*K
+// grouped positions, or N points): for  Y[b] = W . X[b]  the positions are the GEMM's N
+// dimension and are contiguous, so the MFMA B operand (v_mfma_f32_32x32x2_f32: lane l holds
+// B[k = l>>5][n = l&31]) and the C/D rows are read and written as 128-B coalesced segments
+// with no transposes anywhere.  The matrix operand is handed over K-major ("At" = [K][M]).
+//
+// Kernels
+//   gemm_kernel     Y = At^T . pro(X) + bias, epilogue: per-channel (sum, sum^2) partials of Y for
+//                   the BatchNorm that follows (deterministic: one partial per position tile).
+//                   pro = identity | relu(x*s+t) | BatchNorm-backward of (dZ, Y) -> dY.
+//                   The same kernel is the forward GEMM (At = W^T) and the data-gradient GEMM
+//                   (At = W, X = dZ/Y of the layer's output).
+//   wgrad_kernel    dW[co][ci] = sum_p pro(G)[co][p] * X[ci][p]: split over position ranges,
+//                   partial tiles to a workspace, summed in fixed order by wgrad_reduce_kernel.
+//   bn_* kernels    statistics finalisation (+ running stats), BN+ReLU apply, backward reductions.
+//
+// fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf
+// chain, so parity with the fp32 reference is a matter of summation order only (<= 1e-6).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2 };
+
+struct GemmArgs {
+    const float* At; int lda;          // [K][M], row stride lda
+    const float* X;                    // [nb][K][P]
+    const float* X2;                   // [nb][K][P]  (PRO_BN_BWD: the layer's pre-BN output Y)
+    const float* coef;                 // [4][K] prologue coefficients per input channel
+    const float* bias;                 // [M] or null
+    float* Y;                          // [nb][M][P]
+    float* stats;                      // [2][ntn][M] or null
+    int M, K, P, nb;
+};
+
+// prologue on one element of the streamed operand, channel coefficients c0..c3
+template <int PRO>
+__device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1, float c2, float c3)
+{
+    if (PRO == PRO_AFFINE_RELU) return fmaxf(__builtin_fmaf(x, c0, c1), 0.0f);
+    if (PRO == PRO_BN_BWD) {
+        // x = dZ, x2 = Y (pre-BN).  a1 = gamma*invstd, a0 = beta - mean*a1 reproduce the forward's
+        // z = relu(fma(y, a1, a0)) decision exactly; dY = a1*dYhat + q1*y + q0 (see bn_bwd_finalize).
+        const float dyh = (__builtin_fmaf(x2, c0, c1) > 0.0f) ? x : 0.0f;
+        return __builtin_fmaf(c0, dyh, __builtin_fmaf(c2, x2, c3));
+    }
+    return x;
+}
+
+template <int WM, int WN, int PRO, bool STATS, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
+{
+    constexpr int BM = WM * 64, BN = WN * 64, BK = 16;
+    constexpr int NA = BM / 16;                 // A elements per thread per stage
+    constexpr int NB4 = BK * BN / 4 / 256;      // X float4 per thread per stage (VEC)
+    constexpr int NBS = BK * BN / 256;          // X scalars per thread per stage (!VEC)
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // logical tile id: co-tiles of one position tile are consecutive; XCD-aware remap so that
+    // they also land on ONE XCD (shared L2 for the X tile) -- speed only, never correctness.
+    const int tpc = (a.P + BN - 1) / BN, nmt = (a.M + BM - 1) / BM;
+    const int total = a.nb * tpc * nmt;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+    const int mt = L % nmt, tn = L / nmt;
+    const int b = tn / tpc, pt = tn % tpc;
+    const int m0 = mt * BM, p0 = pt * BN;
+    const float* Xb = a.X + (long long)b * a.K * a.P;
+    const float* X2b = (PRO == PRO_BN_BWD) ? a.X2 + (long long)b * a.K * a.P : nullptr;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float ra[NA];
+    float4 rx[VEC ? NB4 : 1];
+    float rxs[VEC ? 1 : NBS];
+
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + i * 256, k = e / BM, m = e % BM;
+            ra[i] = (k0 + k < a.K && m0 + m < a.M) ? a.At[(long long)(k0 + k) * a.lda + m0 + m] : 0.0f;
+        }
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NB4; ++i) {
+                const int f = tid + i * 256, k = f / (BN / 4), col = (f % (BN / 4)) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + k < a.K && p0 + col < a.P) {
+                    const long long off = (long long)(k0 + k) * a.P + p0 + col;
+                    v = *reinterpret_cast<const float4*>(Xb + off);
+                    if (PRO != PRO_NONE) {
+                        const float c0 = a.coef[k0 + k], c1 = a.coef[a.K + k0 + k];
+                        float c2 = 0.f, c3 = 0.f;
+                        float4 w = v;
+                        if (PRO == PRO_BN_BWD) {
+                            c2 = a.coef[2 * a.K + k0 + k]; c3 = a.coef[3 * a.K + k0 + k];
+                            w = *reinterpret_cast<const float4*>(X2b + off);
+                        }
+                        v.x = pro_apply<PRO>(v.x, w.x, c0, c1, c2, c3);
+                        v.y = pro_apply<PRO>(v.y, w.y, c0, c1, c2, c3);
+                        v.z = pro_apply<PRO>(v.z, w.z, c0, c1, c2, c3);
+                        v.w = pro_apply<PRO>(v.w, w.w, c0, c1, c2, c3);
+                    }
+                }
+                rx[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBS; ++i) {
+                const int e = tid + i * 256, k = e / BN, col = e % BN;
+                float v = 0.f;
+                if (k0 + k < a.K && p0 + col < a.P) {
+                    const long long off = (long long)(k0 + k) * a.P + p0 + col;
+                    v = Xb[off];
+                    if (PRO != PRO_NONE) {
+                        const float c0 = a.coef[k0 + k], c1 = a.coef[a.K + k0 + k];
+                        float c2 = 0.f, c3 = 0.f, w = v;
+                        if (PRO == PRO_BN_BWD) {
+                            c2 = a.coef[2 * a.K + k0 + k]; c3 = a.coef[3 * a.K + k0 + k];
+                            w = X2b[off];
+                        }
+                        v = pro_apply<PRO>(v, w, c0, c1, c2, c3);
+                    }
+                }
+                rxs[i] = v;
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + i * 256;
+            As[buf][e / BM][e % BM] = ra[i];
+        }
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NB4; ++i) {
+                const int f = tid + i * 256;
+                *reinterpret_cast<float4*>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = rx[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBS; ++i) {
+                const int e = tid + i * 256;
+                Bs[buf][e / BN][e % BN] = rxs[i];
+            }
+        }
+    };
+
+    const int nk = (a.K + BK - 1) / BK;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int cur = 0;
+    const int kr = lane >> 5, c = lane & 31;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) load_stage((kt + 1) * BK);          // in flight under the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[cur][kk + kr][wm * 64 + c];
+            const float a1 = As[cur][kk + kr][wm * 64 + 32 + c];
+            const float b0 = Bs[cur][kk + kr][wn * 64 + c];
+            const float b1 = Bs[cur][kk + kr][wn * 64 + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: + bias, store, BatchNorm partial statistics ------------------------------
+    float* Yb = a.Y + (long long)b * a.M * a.P;
+    float* red = &As[0][0][0];                               // [2][WN][BM] scratch (LDS is free now)
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int row = m0 + row_l;
+            const float bv = (a.bias && row < a.M) ? a.bias[row] : 0.0f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = p0 + wn * 64 + j * 32 + c;
+                const float v = acc[i][j][r] + bv;
+                if (row < a.M && col < a.P) {
+                    Yb[(long long)row * a.P + col] = v;
+                    if (STATS) { s += v; q = __builtin_fmaf(v, v, q); }
+                }
+            }
+            if (STATS) {
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) {
+                    s += __shfl_xor(s, off);
+                    q += __shfl_xor(q, off);
+                }
+                if (c == 0) {
+                    red[wn * BM + row_l] = s;
+                    red[WN * BM + wn * BM + row_l] = q;
+                }
+            }
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { s += red[w * BM + tid]; q += red[WN * BM + w * BM + tid]; }
+            const long long ntn = (long long)a.nb * tpc;
+            a.stats[(long long)tn * a.M + m0 + tid] = s;
+            a.stats[ntn * a.M + (long long)tn * a.M + m0 + tid] = q;
+        }
+    }
+}
+
+template <int WM, int WN>
+int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
+{
+    constexpr int BM = WM * 64, BN = WN * 64;
+    const int tpc = (a.P + BN - 1) / BN, nmt = (a.M + BM - 1) / BM;
+    const long long total = (long long)a.nb * tpc * nmt;
+    if (total > 0x7fffffffLL) return USIP_EINVAL;
+    const bool vec = (a.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15u) == 0) &&
+                     (pro != PRO_BN_BWD || (reinterpret_cast<uintptr_t>(a.X2) & 15u) == 0);
+    const bool stats = a.stats != nullptr;
+    dim3 grid((unsigned)total), block(256);
+#define USIP_GEMM_CASE(P_, S_, V_)                                                              \
+    if (pro == P_ && stats == S_ && vec == V_) {                                                \
+        USIP_LAUNCH((gemm_kernel<WM, WN, P_, S_, V_>), grid, block, 0, st, a);                  \
+        USIP_LAUNCH_CHECK();                                                                    \
+        return USIP_OK;                                                                         \
+    }
+    USIP_GEMM_CASE(PRO_NONE, true, true)
+    USIP_GEMM_CASE(PRO_NONE, true, false)
+    USIP_GEMM_CASE(PRO_NONE, false, true)
+    USIP_GEMM_CASE(PRO_NONE, false, false)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, true, true)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, true, false)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, false, true)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, false, false)
+    USIP_GEMM_CASE(PRO_BN_BWD, false, true)
+    USIP_GEMM_CASE(PRO_BN_BWD, false, false)
+#undef USIP_GEMM_CASE
+    return USIP_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[m=co][n=ci] = sum over positions of pro(G)[co][p] * X[ci][p]
+struct WgradArgs {
+    const float* G;  const float* G2; const float* coef;   // [nb][M][P] (+ Y and [4][M] for PRO_BN_BWD)
+    const float* X;                                         // [nb][N][P]
+    float* part;                                            // [slices][M][N]
+    int M, N, P, nb, seglen, segs;                          // segs position segments per cloud
+};
+
+// One stage of a [rows][32 positions] operand tile of the weight gradient: thread -> (row, 4
+// consecutive positions), 8 lanes cover one 128-B row segment.  PRO_BN_BWD turns (dZ, Y) into dY.
+template <int N4, int PRO, bool VEC>
+__device__ __forceinline__ void wgrad_load_rows(const float* __restrict__ base, const float* __restrict__ base2,
+                                                const float* __restrict__ coef, int rows, int P, int r0,
+                                                int p, int pend, int tid, float4 (&dst)[N4])
+{
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+        if (r0 + row < rows) {
+            const long long off = (long long)(r0 + row) * P + p + kq;
+            if (VEC && p + kq + 3 < pend) {
+                const float4 t = *reinterpret_cast<const float4*>(base + off);
+                v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
+                if (PRO == PRO_BN_BWD) {
+                    const float4 u = *reinterpret_cast<const float4*>(base2 + off);
+                    w0 = u.x; w1 = u.y; w2 = u.z; w3 = u.w;
+                }
+            } else {
+                if (p + kq + 0 < pend) { v0 = base[off + 0]; if (PRO == PRO_BN_BWD) w0 = base2[off + 0]; }
+                if (p + kq + 1 < pend) { v1 = base[off + 1]; if (PRO == PRO_BN_BWD) w1 = base2[off + 1]; }
+                if (p + kq + 2 < pend) { v2 = base[off + 2]; if (PRO == PRO_BN_BWD) w2 = base2[off + 2]; }
+                if (p + kq + 3 < pend) { v3 = base[off + 3]; if (PRO == PRO_BN_BWD) w3 = base2[off + 3]; }
+            }
+            if (PRO == PRO_BN_BWD) {
+                const int ch = r0 + row;
+                const float c0 = coef[ch], c1 = coef[rows + ch], c2 = coef[2 * rows + ch], c3 = coef[3 * rows + ch];
+                v0 = (p + kq + 0 < pend) ? pro_apply<PRO_BN_BWD>(v0, w0, c0, c1, c2, c3) : 0.f;
+                v1 = (p + kq + 1 < pend) ? pro_apply<PRO_BN_BWD>(v1, w1, c0, c1, c2, c3) : 0.f;
+                v2 = (p + kq + 2 < pend) ? pro_apply<PRO_BN_BWD>(v2, w2, c0, c1, c2, c3) : 0.f;
+                v3 = (p + kq + 3 < pend) ? pro_apply<PRO_BN_BWD>(v3, w3, c0, c1, c2, c3) : 0.f;
+            }
+        }
+        dst[i] = make_float4(v0, v1, v2, v3);
+    }
+}
+
+template <int TM, int TN, int PRO, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
+{
+    // 2 x 2 waves, each TM x TN MFMA tiles of 32 x 32: block tile 128 x 128 (TM = TN = 2) or 64 x 64
+    constexpr int WN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32, BKP = 32;
+    constexpr int LDM = BM + 2, LDN = BN + 2;
+    __shared__ float Gs[2][BKP][LDM];
+    __shared__ float Xs[2][BKP][LDN];
+    constexpr int NG4 = BM * BKP / 4 / 256, NX4 = BN * BKP / 4 / 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nmt = (a.M + BM - 1) / BM, nnt = (a.N + BN - 1) / BN;
+    const int tile = blockIdx.x % (nmt * nnt), slice = blockIdx.x / (nmt * nnt);
+    const int m0 = (tile / nnt) * BM, n0 = (tile % nnt) * BN;
+    const int b = slice / a.segs, seg = slice % a.segs;
+    const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
+    const float* Gb = a.G + (long long)b * a.M * a.P;
+    const float* G2b = (PRO == PRO_BN_BWD) ? a.G2 + (long long)b * a.M * a.P : nullptr;
+    const float* Xb = a.X + (long long)b * a.N * a.P;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 rg[NG4], rx[NX4];
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NG4; ++i) {
+            const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
+            Gs[buf][kq][row] = rg[i].x; Gs[buf][kq + 1][row] = rg[i].y;
+            Gs[buf][kq + 2][row] = rg[i].z; Gs[buf][kq + 3][row] = rg[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < NX4; ++i) {
+            const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
+            Xs[buf][kq][row] = rx[i].x; Xs[buf][kq + 1][row] = rx[i].y;
+            Xs[buf][kq + 2][row] = rx[i].z; Xs[buf][kq + 3][row] = rx[i].w;
+        }
+    };
+
+    const int nst = (pend - pbeg + BKP - 1) / BKP;
+    if (nst > 0) {
+        wgrad_load_rows<NG4, PRO, VEC>(Gb, G2b, a.coef, a.M, a.P, m0, pbeg, pend, tid, rg);
+        wgrad_load_rows<NX4, PRO_NONE, VEC>(Xb, nullptr, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx);
+        store_stage(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    const int kr = lane >> 5, c = lane & 31;
+    for (int s = 0; s < nst; ++s) {
+        if (s + 1 < nst) {
+            wgrad_load_rows<NG4, PRO, VEC>(Gb, G2b, a.coef, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg);
+            wgrad_load_rows<NX4, PRO_NONE, VEC>(Xb, nullptr, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BKP; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = Gs[cur][kk + kr][(wm * TM + i) * 32 + c];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Xs[cur][kk + kr][(wn * TN + j) * 32 + c];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nst) store_stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float* out = a.part + (long long)slice * a.M * a.N;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = n0 + (wn * TN + j) * 32 + c;
+                if (row < a.M && col < a.N) out[(long long)row * a.N + col] = acc[i][j][r];
+            }
+}
+
+// dW[e] = sum over slices, in a fixed order: 64 elements x 4 slice lanes per block, every lane sums
+// its quarter of the slices (4 independent chains), the quarters are combined through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                           float* __restrict__ dW, long long elems, int slices)
+{
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < elems) {
+        const int per = (slices + 3) / 4, k0 = q * per, k1 = min(slices, k0 + per);
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            s0 += part[(long long)k * elems + i];
+            s1 += part[(long long)(k + 1) * elems + i];
+            s2 += part[(long long)(k + 2) * elems + i];
+            s3 += part[(long long)(k + 3) * elems + i];
+        }
+        for (; k < k1; ++k) s0 += part[(long long)k * elems + i];
+    }
+    red[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < elems) dW[i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm helpers.  One wave per channel; partials are summed in double in a fixed order.
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(
+    const float* __restrict__ stats, int ntn, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+    float* __restrict__ coef)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int t = lane; t < ntn; t += 64) {
+        s += (double)stats[(long long)t * C + ch];
+        q += (double)stats[(long long)ntn * C + (long long)t * C + ch];
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if (lane == 0) {
+        const double mean = s / count;
+        double var = q / count - mean * mean;                 // biased, as F.batch_norm normalises
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[ch] : 1.0f, bt = beta ? beta[ch] : 0.0f;
+        const float sc = g * invstd;
+        mean_out[ch] = (float)mean;
+        invstd_out[ch] = invstd;
+        coef[ch] = sc;                                        // z = relu(fma(y, sc, sh))
+        coef[C + ch] = bt - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mean;
+            running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)unbiased;
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Y, const float* __restrict__ coef,
+                                                       float* __restrict__ Z, int relu, int C, int P)
+{
+    const long long rowid = blockIdx.y;                       // b*C + c
+    const int ch = (int)(rowid % C);
+    const float sc = coef[ch], sh = coef[C + ch];
+    const float* y = Y + rowid * P;
+    float* z = Z + rowid * P;
+    if (VEC) {
+        const int p = (blockIdx.x * 256 + threadIdx.x) * 4;
+        if (p >= P) return;
+        float4 v = *reinterpret_cast<const float4*>(y + p);
+        v.x = __builtin_fmaf(v.x, sc, sh); v.y = __builtin_fmaf(v.y, sc, sh);
+        v.z = __builtin_fmaf(v.z, sc, sh); v.w = __builtin_fmaf(v.w, sc, sh);
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4*>(z + p) = v;
+    } else {
+        const int p = blockIdx.x * 256 + threadIdx.x;
+        if (p >= P) return;
+        float v = __builtin_fmaf(y[p], sc, sh);
+        z[p] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// Per (cloud, channel) row: s1 = sum dYhat, s2 = sum dYhat * yhat with
+// dYhat = dZ * [fma(y, sc, sh) > 0] (or dZ when !relu), yhat = (y - mean) * invstd.
+// mode 1 (no BN): s1 = sum dZ only (bias gradient of a layer without normalisation).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dZ, const float* __restrict__ Y, const float* __restrict__ coef,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
+    int relu, int plain, int C, int P, int nrows)
+{
+    __shared__ float red[2][4];
+    const long long rowid = blockIdx.x;
+    const int ch = (int)(rowid % C);
+    const float* dz = dZ + rowid * P;
+    float s1 = 0.f, s2 = 0.f;
+    if (plain) {
+        for (int p = threadIdx.x; p < P; p += 256) s1 += dz[p];
+    } else {
+        const float* y = Y + rowid * P;
+        const float sc = coef[ch], sh = coef[C + ch], mu = mean[ch], is = invstd[ch];
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const float yv = y[p];
+            const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dz[p] : 0.f;
+            s1 += d;
+            s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[rowid] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[nrows + rowid] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// dgamma = sum2, dbeta = sum1, and the PRO_BN_BWD coefficients
+//   dY = gamma*invstd * (dYhat - mean(dYhat) - yhat * mean(dYhat*yhat)) = a1*dYhat + q1*y + q0
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, int nb, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ coef_fwd, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef4)
+{
+    const int ch = blockIdx.x * 64 + threadIdx.x;
+    if (ch >= C) return;
+    const long long nrows = (long long)nb * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        s1 += (double)partial[(long long)b * C + ch];
+        s2 += (double)partial[nrows + (long long)b * C + ch];
+    }
+    if (dbeta) dbeta[ch] = (float)s1;
+    if (dgamma) dgamma[ch] = (float)s2;
+    if (coef4) {
+        const float a1 = coef_fwd[ch], a0 = coef_fwd[C + ch];
+        const float is = invstd[ch], mu = mean[ch];
+        const float c1m = (float)(s1 / count), c2m = (float)(s2 / count);
+        coef4[ch] = a1;
+        coef4[C + ch] = a0;
+        coef4[2 * C + ch] = -a1 * c2m * is;
+        coef4[3 * C + ch] = a1 * (c2m * is * mu - c1m);
+    }
+    (void)gamma;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
+{
+    const int BN = (M <= 64) ? 256 : 128;
+    return nb * ((P + BN - 1) / BN);
+}
+
+extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
+                                 const float* coef, int pro, const float* bias, float* Y, float* stats,
+                                 int M, int K, int P, int nb, void* stream)
+{
+    if (M < 1 || K < 1 || P < 0 || nb < 0 || lda < M) return USIP_EINVAL;
+    if ((long long)P * nb == 0) return USIP_OK;
+    if (!At || !X || !Y || pro < 0 || pro > 2) return USIP_EINVAL;
+    if (pro != PRO_NONE && !coef) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD && (!X2 || stats)) return USIP_EINVAL;
+    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb};
+    hipStream_t st = (hipStream_t)stream;
+    return (M <= 64) ? launch_gemm<1, 4>(a, pro, st) : launch_gemm<2, 2>(a, pro, st);
+}
+
+// Workspace (floats) the weight-gradient needs, and the slicing it will use.
+static void wgrad_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* small, int* tiles)
+{
+    *small = (M <= 64 && N <= 64) ? 1 : 0;
+    const int BM = *small ? 64 : 128, BN = *small ? 64 : 128;
+    *tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // aim at ~1024 workgroups (4 per CU); a position segment is a multiple of 32 and >= 512 so that
+    // the partial tile a workgroup writes stays small next to what it streams
+    long long want = 1024 / (*tiles);
+    if (want < 1) want = 1;
+    long long per_cloud = (want + nb - 1) / nb;
+    if (per_cloud < 1) per_cloud = 1;
+    long long sl = (P + per_cloud - 1) / per_cloud;
+    sl = ((sl + 31) / 32) * 32;
+    if (sl < 512) sl = 512;
+    *seglen = (int)sl;
+    *segs = (int)((P + sl - 1) / sl);
+}
+
+extern "C" long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb)
+{
+    int seglen, segs, small, tiles;
+    wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
+    return (long long)nb * segs * M * N;
+}
+
+extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro,
+                                  const float* X, float* workspace, float* dW,
+                                  int M, int N, int P, int nb, void* stream)
+{
+    if (M < 1 || N < 1 || P < 0 || nb < 0) return USIP_EINVAL;
+    if (!dW) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long long)P * nb == 0) {
+        (void)hipGetLastError();
+        hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * N, st);
+        return e == hipSuccess ? USIP_OK : (int)e;
+    }
+    if (!G || !X || !workspace || (pro != PRO_NONE && pro != PRO_BN_BWD)) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD && (!G2 || !coef)) return USIP_EINVAL;
+    int seglen, segs, small, tiles;
+    wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
+    WgradArgs a{G, G2, coef, X, workspace, M, N, P, nb, seglen, segs};
+    const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
+                     (pro != PRO_BN_BWD || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
+    const long long blocks = (long long)tiles * nb * segs;
+    if (blocks > 0x7fffffffLL) return USIP_EINVAL;
+    dim3 grid((unsigned)blocks), block(256);
+#define USIP_WGRAD_CASE(T_, P_, V_)                                                            \
+    if (small == (T_ == 1) && pro == P_ && vec == V_) {                                        \
+        USIP_LAUNCH((wgrad_kernel<T_, T_, P_, V_>), grid, block, 0, st, a);                    \
+        USIP_LAUNCH_CHECK();                                                                   \
+    }
+    USIP_WGRAD_CASE(1, PRO_NONE, true)
+    USIP_WGRAD_CASE(1, PRO_NONE, false)
+    USIP_WGRAD_CASE(1, PRO_BN_BWD, true)
+    USIP_WGRAD_CASE(1, PRO_BN_BWD, false)
+    USIP_WGRAD_CASE(2, PRO_NONE, true)
+    USIP_WGRAD_CASE(2, PRO_NONE, false)
+    USIP_WGRAD_CASE(2, PRO_BN_BWD, true)
+    USIP_WGRAD_CASE(2, PRO_BN_BWD, false)
+#undef USIP_WGRAD_CASE
+    const long long elems = (long long)M * N;
+    USIP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st,
+                workspace, dW, elems, nb * segs);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_bn_finalize_f32(const float* stats, int ntiles, int C, long long count,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* mean, float* invstd,
+                                    float* coef, void* stream)
+{
+    if (!stats || ntiles < 1 || C < 1 || count < 1 || !mean || !invstd || !coef) return USIP_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return USIP_EINVAL;
+    USIP_LAUNCH(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, ntiles, C, (double)count,
+                gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, coef);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_bn_apply_f32(const float* Y, const float* coef, float* Z, int relu,
+                                 int nb, int C, int P, void* stream)
+{
+    if (nb < 0 || C < 1 || P < 0) return USIP_EINVAL;
+    if ((long long)nb * P == 0) return USIP_OK;
+    if (!Y || !coef || !Z || (long long)nb * C > 65535LL * 65535LL) return USIP_EINVAL;
+    const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(Z) & 15u) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    // grid.y <= 65535: fold rows if needed
+    const long long rows = (long long)nb * C;
+    if (rows > 65535) {
+        // process in slabs of <= 65535 rows (C divides the slab start only if slab % C == 0)
+        const long long slab = (65535 / C) * (long long)C;
+        if (slab == 0) return USIP_EINVAL;
+        for (long long r0 = 0; r0 < rows; r0 += slab) {
+            const long long n = (rows - r0 < slab) ? rows - r0 : slab;
+            if (vec) USIP_LAUNCH((bn_apply_kernel<true>), dim3(usip_ceil_div(P, 1024), (unsigned)n), dim3(256), 0, st,
+                                 Y + r0 * P, coef, Z + r0 * P, relu, C, P);
+            else USIP_LAUNCH((bn_apply_kernel<false>), dim3(usip_ceil_div(P, 256), (unsigned)n), dim3(256), 0, st,
+                             Y + r0 * P, coef, Z + r0 * P, relu, C, P);
+            USIP_LAUNCH_CHECK();
+        }
+        return USIP_OK;
+    }
+    if (vec) USIP_LAUNCH((bn_apply_kernel<true>), dim3(usip_ceil_div(P, 1024), (unsigned)rows), dim3(256), 0, st,
+                         Y, coef, Z, relu, C, P);
+    else USIP_LAUNCH((bn_apply_kernel<false>), dim3(usip_ceil_div(P, 256), (unsigned)rows), dim3(256), 0, st,
+                     Y, coef, Z, relu, C, P);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* coef_fwd,
+                                           const float* mean, const float* invstd, const float* gamma,
+                                           int relu, float* partial, float* dgamma, float* dbeta,
+                                           float* coef4, int nb, int C, int P, void* stream)
+{
+    if (nb < 1 || C < 1 || P < 1 || !dZ || !partial) return USIP_EINVAL;
+    const int plain = (Y == nullptr);
+    if (!plain && (!coef_fwd || !mean || !invstd)) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)nb * C;
+    if (rows > 0x7fffffffLL) return USIP_EINVAL;
+    USIP_LAUNCH(bn_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean, invstd,
+                partial, relu, plain, C, P, (int)rows);
+    USIP_LAUNCH_CHECK();
+    USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
+                (double)nb * (double)P, gamma, coef_fwd, mean, invstd, dgamma, dbeta, plain ? nullptr : coef4);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}

@@ -70,22 +70,82 @@ def gather_neighbours(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- shared MLP layer
+class _SharedMLPLayer(torch.autograd.Function):
+    """1x1 convolution (+bias) -> BatchNorm (batch statistics) -> ReLU as ONE autograd node on the
+    HIP kernels of csrc/shared_mlp.hip (models/layers.py:208-216, :293-303 + autograd's backward).
+
+      forward : GEMM (+bias, + per-channel sum/sum^2 partials in its epilogue) -> statistics
+                finalise (+ running stats) -> BN+ReLU apply
+      backward: one reduction pass (dgamma, dbeta) -> data-gradient GEMM and weight-gradient GEMM
+                that both rebuild dY = BN'(ReLU'(dZ)) from (dZ, Y) in their prologue; dY is never
+                written to memory.
+    The conv bias in front of a training-mode BatchNorm has an analytically zero gradient (the
+    reference's autograd returns rounding noise there); zeros are returned.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        x = x.contiguous()
+        wt = w2.detach().t().contiguous()                      # K-major matrix operand [Cin][Cout]
+        nb, _, P = x.shape
+        ctx.has_bn = gamma is not None
+        ctx.relu = bool(relu)
+        ctx.train_stats = bool(training)
+        if not ctx.has_bn:
+            if relu:
+                raise NotImplementedError("usip_amd: ReLU without BatchNorm is outside the detector path")
+            y, _ = ops.mlp_gemm(wt, x, bias)
+            ctx.save_for_backward(x, w2)
+            return y
+        if training:
+            y, stats = ops.mlp_gemm(wt, x, bias, want_stats=True)
+            mean, invstd, coef = ops.bn_finalize(stats, nb * P, gamma, beta, eps, momentum,
+                                                 running_mean, running_var)
+        else:
+            y, _ = ops.mlp_gemm(wt, x, bias)
+            invstd = torch.rsqrt(running_var + eps)
+            mean = running_mean
+            scale = gamma * invstd
+            coef = torch.stack((scale, beta - running_mean * scale)).contiguous()
+        z = ops.bn_apply(y, coef, relu)
+        ctx.save_for_backward(x, w2, y, coef, mean, invstd, gamma)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        dz = dz.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if not ctx.has_bn:
+            x, w2 = ctx.saved_tensors
+            dx = ops.mlp_gemm(w2.contiguous(), dz, tag="dgrad")[0] if need_x else None
+            dw = ops.mlp_wgrad(dz, x) if need_w else None
+            db = ops.bn_backward_reduce(dz, None, None, None, None, None, False)[1] if ctx.needs_input_grad[2] else None
+            return dx, dw, db, None, None, None, None, None, None, None, None
+        if not ctx.train_stats:
+            raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
+        x, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
+        dgamma, dbeta, coef4 = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu)
+        dx = ops.mlp_gemm(w2.contiguous(), dz, pro=2, X2=y, coef=coef4, tag="dgrad")[0] if need_x else None
+        dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4) if need_w else None
+        db = torch.zeros_like(gamma) if ctx.needs_input_grad[2] else None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+
+
 def conv1x1_bn_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                    bn: Optional[torch.nn.modules.batchnorm._BatchNorm], relu: bool) -> torch.Tensor:
     """One shared-MLP layer: 1x1 convolution (+bias) -> BatchNorm (batch statistics when the
     module is in training mode) -> ReLU  (models/layers.py:208-216, :293-303).
     x [B,Cin,*positions], weight [Cout,Cin,1(,1)] -> [B,Cout,*positions]."""
+    require_device(x, "the shared MLP")
     shape = x.shape
     w2 = weight.reshape(weight.shape[0], weight.shape[1])
-    xf = x.reshape(shape[0], shape[1], -1)
-    with prof.kernel("shared_mlp_gemm_fwd %dx%d" % (w2.shape[0], w2.shape[1]),
-                     flops=2.0 * w2.shape[0] * w2.shape[1] * xf.shape[0] * xf.shape[2]):
-        y = torch.matmul(w2, xf)
-    if bias is not None:
-        y = y + bias.view(1, -1, 1)
-    if bn is not None:
-        y = F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                         bn.training or bn.running_mean is None, bn.momentum, bn.eps)
-    if relu:
-        y = torch.relu(y)
+    x3 = x.reshape(shape[0], shape[1], -1)
+    if bn is None:
+        y = _SharedMLPLayer.apply(x3, w2, bias, None, None, None, None, False, 0.0, 0.0, relu)
+    else:
+        training = bn.training or bn.running_mean is None
+        if bn.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        y = _SharedMLPLayer.apply(x3, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  training, bn.momentum, bn.eps, relu)
     return y.view(shape[0], w2.shape[0], *shape[2:])

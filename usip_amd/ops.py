@@ -142,6 +142,92 @@ def nearest(a: torch.Tensor, b: torch.Tensor):
     return d, arg
 
 
+# --------------------------------------------------------------------------- shared MLP
+def _opt(t):
+    return _ptr(t) if t is not None else None
+
+
+def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
+             X2=None, coef=None, tag: str = "fwd"):
+    """Y[b] = At^T . pro(X[b]) + bias.  At [K,M] (K-major matrix operand), X [nb,K,P] -> Y [nb,M,P]
+    (+ stats [2,tiles,M] when want_stats)."""
+    _need(At, "At", torch.float32)
+    _need(X, "X", torch.float32)
+    K, M = At.shape
+    nb, Kx, P = X.shape
+    if Kx != K:
+        raise RuntimeError("mlp_gemm: At is [%d,%d] but X has %d channels" % (K, M, Kx))
+    Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
+    stats = None
+    if want_stats:
+        tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
+        stats = torch.empty((2, tiles, M), dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
+                                                  4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
+                                                  2.0 * M * K * nb * P):
+        _lib.check(_lib.lib().usip_mlp_gemm_f32(_ptr(At), M, _ptr(X), _opt(X2), _opt(coef), int(pro), _opt(bias),
+                                                _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), "usip_mlp_gemm_f32")
+    return Y, stats
+
+
+def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
+    """-> (mean [C], invstd [C], coef [2,C]); updates running_mean/var in place when given."""
+    _, tiles, C = stats.shape
+    dev = stats.device
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    coef = torch.empty((2, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("bn_finalize", 4.0 * 2 * tiles * C):
+        _lib.check(_lib.lib().usip_bn_finalize_f32(_ptr(stats), tiles, C, int(count), _opt(gamma), _opt(beta),
+                                                   float(eps), float(momentum), _opt(running_mean),
+                                                   _opt(running_var), _ptr(mean), _ptr(invstd), _ptr(coef),
+                                                   _stream(stats)), "usip_bn_finalize_f32")
+    return mean, invstd, coef
+
+
+def bn_apply(Y, coef, relu: bool):
+    """Z = relu?(Y * coef[0] + coef[1]); Y [nb,C,P]."""
+    nb, C, P = Y.shape
+    Z = torch.empty_like(Y)
+    with torch.cuda.device(Y.device), prof.kernel("bn_apply", 8.0 * nb * C * P):
+        _lib.check(_lib.lib().usip_bn_apply_f32(_ptr(Y), _ptr(coef), _ptr(Z), int(bool(relu)), nb, C, P,
+                                                _stream(Y)), "usip_bn_apply_f32")
+    return Z
+
+
+def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool):
+    """-> (dgamma [C], dbeta [C], coef4 [4,C]).  Y None: plain mode, returns (None, sum dZ, None)."""
+    nb, C, P = dZ.shape
+    dev = dZ.device
+    partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dgamma = coef4 = None
+    if Y is not None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("bn_backward_reduce", 4.0 * nb * C * P * (1 if Y is None else 2)):
+        _lib.check(_lib.lib().usip_bn_backward_reduce_f32(_ptr(dZ), _opt(Y), _opt(coef_fwd), _opt(mean), _opt(invstd),
+                                                          _opt(gamma), int(bool(relu)), _ptr(partial), _opt(dgamma),
+                                                          _ptr(dbeta), _opt(coef4), nb, C, P, _stream(dZ)),
+                   "usip_bn_backward_reduce_f32")
+    return dgamma, dbeta, coef4
+
+
+def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None):
+    """dW [M,N] = sum_{b,p} pro(G)[b,m,p] * X[b,n,p]; G [nb,M,P], X [nb,N,P]."""
+    nb, M, P = G.shape
+    N = X.shape[1]
+    dev = G.device
+    ws_n = _lib.lib().usip_mlp_wgrad_workspace(M, N, P, nb)
+    ws = torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev)
+    dW = torch.empty((M, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
+                                             4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P):
+        _lib.check(_lib.lib().usip_mlp_wgrad_f32(_ptr(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _ptr(ws), _ptr(dW),
+                                                 M, N, P, nb, _stream(G)), "usip_mlp_wgrad_f32")
+    return dW
+
+
 def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:
     """index_max.forward_cpu / forward_multi_thread_cpu (index_max.cpp:33-112): HOST tensors."""
     for t, name, dt in ((data, "data", torch.float32), (index, "index", torch.int32)):
