@@ -103,11 +103,15 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
  *   W itself ([Cout][Cin]) for the data gradient dX = W^T . dY.
  *   pro: 0 identity | 1 relu(x*coef[0][k] + coef[1][k]) | 2 BatchNorm+ReLU backward of X = dZ,
  *        X2 = pre-BN output, coef = the [4][K] array written by usip_bn_backward_reduce_f32.
+ *   rowbias (may be NULL): [nb][M][P/rb_group], added as Y[b][m][p] += rowbias[b][m][p / rb_group]:
+ *   the contribution of input channels that are constant inside a neighbourhood of rb_group
+ *   positions (the max-pooled feature the reference expands and concatenates, networks.py:706-709,
+ *   layers.py:433-435) -- computed once per neighbourhood instead of once per neighbour.
  *   stats (may be NULL): [2][tiles][M] per-tile (sum, sum of squares) of Y over valid positions,
  *   tiles = usip_mlp_gemm_tiles(M, P, nb); summed in fixed order by usip_bn_finalize_f32. */
 int usip_mlp_gemm_tiles(int M, int P, int nb);
 int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2, const float* coef,
-                      int pro, const float* bias, float* Y, float* stats,
+                      int pro, const float* bias, const float* rowbias, int rb_group, float* Y, float* stats,
                       int M, int K, int P, int nb, void* stream);
 
 /* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
@@ -127,18 +131,39 @@ int usip_bn_apply_f32(const float* Y, const float* coef, float* Z, int relu,
  * dYhat = dZ*[fma(y,coef_fwd[0],coef_fwd[1]) > 0] (dZ if !relu), and coef4[4][C] such that
  * dY = coef4[0]*dYhat + coef4[2]*y + coef4[3] (coef4[0..1] repeat coef_fwd for the mask).
  * Y == NULL selects the plain mode: dbeta[c] = sum dZ (bias gradient of a layer without BN).
- * partial: workspace of 2*nb*C floats. */
+ * partial: workspace of 2*nb*C floats.
+ * gsum (may be NULL): [2][nb][C][P/group] per-neighbourhood sums of dYhat and of y, from which
+ * sum_k dY = coef4[0]*gsum[0] + coef4[2]*gsum[1] + group*coef4[3] follows without a second pass
+ * (group % 4 == 0 and group/4 a power of two <= 64). */
 int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* coef_fwd,
                                 const float* mean, const float* invstd, const float* gamma, int relu,
                                 float* partial, float* dgamma, float* dbeta, float* coef4,
-                                int nb, int C, int P, void* stream);
+                                float* gsum, int group, int nb, int C, int P, void* stream);
 
 /* dW[m][n] = sum_{b,p} pro(G)[b][m][p] * X[b][n][p]   (pro 0: G = dY given; pro 2: G = dZ, G2 = Y,
  * coef = coef4 as above).  workspace: usip_mlp_wgrad_workspace(M, N, P, nb) floats of partial tiles,
- * reduced in fixed order (deterministic). */
+ * reduced in fixed order (deterministic).  dW is written as dW[m*ldw + coloff + n], so a column
+ * block of a wider weight matrix can be filled in place. */
 long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb);
 int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro, const float* X,
-                       float* workspace, float* dW, int M, int N, int P, int nb, void* stream);
+                       float* workspace, float* dW, int ldw, int coloff,
+                       int M, int N, int P, int nb, void* stream);
+
+/* ------------------------------------------------------------------ a-6 / a-7 / a-12  grouping, pooling
+ * out[b][coff+c][m][k] = x[b][c][idx[b][m][k]] - (c < nsub ? sub[b][c][m] : 0), written into the
+ * channel slice [coff, coff+C) of an output with Ctot channels.  Replaces index expansion +
+ * torch.gather + decentering + torch.cat (models/operations.py:271-287, networks.py:699-703,
+ * layers.py:422-430).  x [B][C][N], idx i32 [B][M][K], sub [B][nsub][M], out [B][Ctot][M][K]. */
+int usip_group_gather_f32(const float* x, const int32_t* idx, const float* sub, float* out,
+                          int B, int C, int N, int M, int K, int nsub, int Ctot, int coff, void* stream);
+/* Its backward w.r.t. x (scatter-add; dx [B][C][N] is zeroed first). */
+int usip_group_gather_backward_f32(const float* dout, const int32_t* idx, float* dx,
+                                   int B, int C, int N, int M, int K, int Ctot, int coff, void* stream);
+/* pooled[row] = max_k z[row][k], arg[row] = first k attaining it (torch.max over the K axis,
+ * networks.py:706,710, layers.py:433,438); rows = B*C*M.  Backward: dz[row][k] = (k==arg)*dpooled. */
+int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, long long rows, int K, void* stream);
+int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float* dz,
+                                long long rows, int K, void* stream);
 
 #ifdef __cplusplus
 }

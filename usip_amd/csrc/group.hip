@@ -1,0 +1,250 @@
+// usip_amd/csrc/group.hip -- neighbourhood grouping and pooling on gfx950.
+//
+// Replaces the index-expansion + torch.gather + in-place decentering + torch.cat + torch.max chains
+// of the reference (models/networks.py:699-710, models/layers.py:422-438, models/operations.py:
+// 271-287): there the int64 index tensor is expanded to B x C x (M*K) (8 B per gathered float),
+// gathered, decentered in a second pass, concatenated in a third, and max-pooled with a fourth
+// pass that also materialises int64 arg-max indices.
+//
+//   group_gather      out[b, coff+c, m, k] = x[b, c, idx[b,m,k]] - (c < nsub ? sub[b,c,m] : 0)
+//                     written straight into a channel slice of the (pre-concatenated) output.
+//   group_gather_bwd  dx[b,c,n] += sum_{(m,k): idx = n} dout[b, coff+c, m, k]   (float atomics, as
+//                     ATen's scatter_add; the only non-deterministic summation order on the path)
+//   group_max         pooled[b,c,m] = max_k z[b,c,m,k], arg = first k attaining it
+//   group_max_bwd     dz[b,c,m,k] = (k == arg[b,c,m]) ? dpooled[b,c,m] : 0
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void group_gather_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ idx, const float* __restrict__ sub,
+    float* __restrict__ out, int C, int N, int M, int K, int nsub, int Ctot, int coff)
+{
+    const int b = blockIdx.y;
+    const int P = M * K;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int n = idx[(long long)b * P + p];
+    const int m = p / K;
+    const float* xb = x + (long long)b * C * N;
+    float* ob = out + ((long long)b * Ctot + coff) * P;
+    for (int c = 0; c < C; ++c) {
+        float v = xb[(long long)c * N + n];
+        if (c < nsub) v -= sub[((long long)b * nsub + c) * M + m];
+        ob[(long long)c * P + p] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void group_gather_bwd_kernel(
+    const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dx,
+    int C, int N, int P, int Ctot, int coff)
+{
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int n = idx[(long long)b * P + p];
+    const float* gb = dout + ((long long)b * Ctot + coff) * P;
+    float* xb = dx + (long long)b * C * N;
+    for (int c = 0; c < C; ++c) atomicAdd(&xb[(long long)c * N + n], gb[(long long)c * P + p]);
+}
+
+// L lanes (a power of two, <= 64) cooperate on one row of K values; rows = B*C*M.
+template <int L>
+__global__ __launch_bounds__(256) void group_max_kernel(
+    const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows, int K)
+{
+    constexpr int RPB = 256 / L;                    // rows per block
+    const int sub = threadIdx.x % L;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / L;
+    float best = -__builtin_inff();
+    int bk = 0x7fffffff;
+    if (row < rows) {
+        const float* zr = z + row * K;
+        for (int k = sub; k < K; k += L) {
+            const float v = zr[k];
+            if (bk == 0x7fffffff || v > best) { best = v; bk = k; }   // first k wins this lane's ties
+        }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int ok = __shfl_xor(bk, off);
+        if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+    }
+    if (sub == 0 && row < rows) { pooled[row] = best; arg[row] = bk; }
+}
+
+// K % 4 == 0 and L = K/4 a power of two <= 64: every lane owns 4 consecutive neighbours (one 16-B load).
+template <int L>
+__global__ __launch_bounds__(256) void group_max4_kernel(
+    const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows)
+{
+    constexpr int RPB = 256 / L;
+    const int sub = threadIdx.x % L;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / L;
+    float best = -__builtin_inff();
+    int bk = 0x7fffffff;
+    if (row < rows) {
+        const float4 v = *reinterpret_cast<const float4*>(z + (row * L + sub) * 4);
+        best = v.x; bk = sub * 4;
+        if (v.y > best) { best = v.y; bk = sub * 4 + 1; }
+        if (v.z > best) { best = v.z; bk = sub * 4 + 2; }
+        if (v.w > best) { best = v.w; bk = sub * 4 + 3; }
+    }
+#pragma unroll
+    for (int off = L / 2; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off);
+        const int ok = __shfl_xor(bk, off);
+        if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+    }
+    if (sub == 0 && row < rows) { pooled[row] = best; arg[row] = bk; }
+}
+
+__global__ __launch_bounds__(256) void group_max_bwd4_kernel(
+    const float* __restrict__ dpooled, const int32_t* __restrict__ arg, float* __restrict__ dz,
+    long long total4, int K4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const long long row = i / K4;
+    const int k = (int)(i - row * K4) * 4;
+    const int a = arg[row] - k;
+    const float g = dpooled[row];
+    *reinterpret_cast<float4*>(dz + i * 4) =
+        make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f, a == 3 ? g : 0.f);
+}
+
+// Scatter-add through LDS: a workgroup owns CPB channels of one cloud, accumulates them in an
+// LDS table [CPB][N] with ds_add_f32 (neighbours of one neighbourhood are distinct points, so a wave
+// rarely hits one address twice) and writes the table out once.  N*CPB*4 B <= 64 KiB.
+template <int CPB>
+__global__ __launch_bounds__(256) void group_gather_bwd_lds_kernel(
+    const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dx,
+    int C, int N, int P, int Ctot, int coff)
+{
+    extern __shared__ __attribute__((aligned(16))) float table[];       // [CPB][N]
+    const int b = blockIdx.y, c0 = blockIdx.x * CPB;
+    for (int i = threadIdx.x; i < CPB * N; i += 256) table[i] = 0.f;
+    __syncthreads();
+    const int32_t* ib = idx + (long long)b * P;
+    const float* gb = dout + ((long long)b * Ctot + coff + c0) * P;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const int n = ib[p];
+#pragma unroll
+        for (int c = 0; c < CPB; ++c)
+            if (c0 + c < C) atomicAdd(&table[c * N + n], gb[(long long)c * P + p]);
+    }
+    __syncthreads();
+    float* xb = dx + ((long long)b * C + c0) * N;
+    for (int i = threadIdx.x; i < CPB * N; i += 256)
+        if (c0 + i / N < C) xb[i] = table[i];
+}
+
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(
+    const float* __restrict__ dpooled, const int32_t* __restrict__ arg, float* __restrict__ dz,
+    long long total, int K)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long row = i / K;
+    const int k = (int)(i - row * K);
+    dz[i] = (arg[row] == k) ? dpooled[row] : 0.0f;
+}
+
+}  // namespace
+
+extern "C" int usip_group_gather_f32(const float* x, const int32_t* idx, const float* sub, float* out,
+                                     int B, int C, int N, int M, int K, int nsub, int Ctot, int coff,
+                                     void* stream)
+{
+    if (B < 0 || C < 1 || N < 1 || M < 0 || K < 0 || nsub < 0 || nsub > C || coff < 0 || coff + C > Ctot)
+        return USIP_EINVAL;
+    if ((long long)B * M * K == 0) return USIP_OK;
+    if (!x || !idx || !out || (nsub > 0 && !sub) || B > 65535) return USIP_EINVAL;
+    USIP_LAUNCH(group_gather_kernel, dim3(usip_ceil_div((long long)M * K, 256), B), dim3(256), 0,
+                (hipStream_t)stream, x, idx, sub, out, C, N, M, K, nsub, Ctot, coff);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_group_gather_backward_f32(const float* dout, const int32_t* idx, float* dx,
+                                              int B, int C, int N, int M, int K, int Ctot, int coff,
+                                              void* stream)
+{
+    if (B < 0 || C < 1 || N < 1 || M < 0 || K < 0 || coff < 0 || coff + C > Ctot) return USIP_EINVAL;
+    if (!dx) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if ((long long)B * M * K > 0 && dout && idx && B <= 65535 && (long long)N * 8 * 4 <= 65536) {
+        // LDS path: 8 channels per workgroup, every dx element written exactly once (no memset)
+        USIP_LAUNCH((group_gather_bwd_lds_kernel<8>), dim3(usip_ceil_div(C, 8), B), dim3(256),
+                    (size_t)8 * N * sizeof(float), st, dout, idx, dx, C, N, M * K, Ctot, coff);
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
+    }
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * C * N, st);
+    if (e != hipSuccess) return (int)e;
+    if ((long long)B * M * K == 0) return USIP_OK;
+    if (!dout || !idx || B > 65535) return USIP_EINVAL;
+    USIP_LAUNCH(group_gather_bwd_kernel, dim3(usip_ceil_div((long long)M * K, 256), B), dim3(256), 0, st,
+                dout, idx, dx, C, N, M * K, Ctot, coff);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, long long rows, int K,
+                                  void* stream)
+{
+    if (rows < 0 || K < 1) return USIP_EINVAL;
+    if (rows == 0) return USIP_OK;
+    if (!z || !pooled || !arg) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int L4 = K / 4;
+    if (K % 4 == 0 && (L4 & (L4 - 1)) == 0 && L4 <= 64 && (reinterpret_cast<uintptr_t>(z) & 15u) == 0) {
+#define USIP_GM4(L_)                                                                             \
+        if (L4 == L_) {                                                                          \
+            const long long blocks = (rows + (256 / L_) - 1) / (256 / L_);                       \
+            if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                       \
+            USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows); \
+        }
+        USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
+#undef USIP_GM4
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
+    }
+    int L = 1;
+    while (L < K && L < 64) L <<= 1;
+#define USIP_GM(L_)                                                                              \
+    if (L == L_) {                                                                               \
+        const long long blocks = (rows + (256 / L_) - 1) / (256 / L_);                           \
+        if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                           \
+        USIP_LAUNCH((group_max_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows, K); \
+    }
+    USIP_GM(1) USIP_GM(2) USIP_GM(4) USIP_GM(8) USIP_GM(16) USIP_GM(32) USIP_GM(64)
+#undef USIP_GM
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float* dz,
+                                           long long rows, int K, void* stream)
+{
+    if (rows < 0 || K < 1) return USIP_EINVAL;
+    if (rows == 0) return USIP_OK;
+    if (!dpooled || !arg || !dz) return USIP_EINVAL;
+    const long long total = rows * K;
+    if (K % 4 == 0 && (reinterpret_cast<uintptr_t>(dz) & 15u) == 0) {
+        const long long total4 = total / 4, blocks4 = (total4 + 255) / 256;
+        if (blocks4 > 0x7fffffffLL) return USIP_EINVAL;
+        USIP_LAUNCH(group_max_bwd4_kernel, dim3((unsigned)blocks4), dim3(256), 0, (hipStream_t)stream,
+                    dpooled, arg, dz, total4, K / 4);
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
+    }
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return USIP_EINVAL;
+    USIP_LAUNCH(group_max_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                dpooled, arg, dz, total, K);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}

@@ -24,6 +24,7 @@
 // fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf
 // chain, so parity with the fp32 reference is a matter of summation order only (<= 1e-6).
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -40,6 +41,7 @@ struct GemmArgs {
     float* Y;                          // [nb][M][P]
     float* stats;                      // [2][ntn][M] or null
     int M, K, P, nb;
+    const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
 };
 
 // prologue on one element of the streamed operand, channel coefficients c0..c3
@@ -56,13 +58,14 @@ __device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1
     return x;
 }
 
-template <int WM, int WN, int PRO, bool STATS, bool VEC>
+template <int WM, int WN, int BK, int PRO, bool STATS, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
 {
-    constexpr int BM = WM * 64, BN = WN * 64, BK = 16;
-    constexpr int NA = BM / 16;                 // A elements per thread per stage
+    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int NA = BM * BK / 256;           // A elements per thread per stage
     constexpr int NB4 = BK * BN / 4 / 256;      // X float4 per thread per stage (VEC)
     constexpr int NBS = BK * BN / 256;          // X scalars per thread per stage (!VEC)
+    constexpr bool TWO = (PRO == PRO_BN_BWD);   // second streamed tensor (the layer's pre-BN output)
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
     const int b = tn / tpc, pt = tn % tpc;
     const int m0 = mt * BM, p0 = pt * BN;
     const float* Xb = a.X + (long long)b * a.K * a.P;
-    const float* X2b = (PRO == PRO_BN_BWD) ? a.X2 + (long long)b * a.K * a.P : nullptr;
+    const float* X2b = TWO ? a.X2 + (long long)b * a.K * a.P : nullptr;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -90,103 +93,118 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // Raw register staging: the loads of stage t+1 are issued before the MFMAs of stage t and are
+    // first touched (prologue math + ds_write) after them, so their latency hides under the MFMAs.
     float ra[NA];
-    float4 rx[VEC ? NB4 : 1];
-    float rxs[VEC ? 1 : NBS];
+    float4 rx[VEC ? NB4 : 1], ry[(VEC && TWO) ? NB4 : 1];
+    float rxs[VEC ? 1 : NBS], rys[(!VEC && TWO) ? NBS : 1];
 
     auto load_stage = [&](int k0) {
+        // branch-free: out-of-range elements load from a clamped (valid) address and are zeroed when
+        // the registers are written to LDS (store_stage), so the loads issue back to back and nothing
+        // touches their results until after the MFMAs
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = tid + i * 256, k = e / BM, m = e % BM;
-            ra[i] = (k0 + k < a.K && m0 + m < a.M) ? a.At[(long long)(k0 + k) * a.lda + m0 + m] : 0.0f;
+            ra[i] = a.At[(long long)min(k0 + k, a.K - 1) * a.lda + min(m0 + m, a.M - 1)];
         }
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < NB4; ++i) {
                 const int f = tid + i * 256, k = f / (BN / 4), col = (f % (BN / 4)) * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k0 + k < a.K && p0 + col < a.P) {
-                    const long long off = (long long)(k0 + k) * a.P + p0 + col;
-                    v = *reinterpret_cast<const float4*>(Xb + off);
-                    if (PRO != PRO_NONE) {
-                        const float c0 = a.coef[k0 + k], c1 = a.coef[a.K + k0 + k];
-                        float c2 = 0.f, c3 = 0.f;
-                        float4 w = v;
-                        if (PRO == PRO_BN_BWD) {
-                            c2 = a.coef[2 * a.K + k0 + k]; c3 = a.coef[3 * a.K + k0 + k];
-                            w = *reinterpret_cast<const float4*>(X2b + off);
-                        }
-                        v.x = pro_apply<PRO>(v.x, w.x, c0, c1, c2, c3);
-                        v.y = pro_apply<PRO>(v.y, w.y, c0, c1, c2, c3);
-                        v.z = pro_apply<PRO>(v.z, w.z, c0, c1, c2, c3);
-                        v.w = pro_apply<PRO>(v.w, w.w, c0, c1, c2, c3);
-                    }
-                }
-                rx[i] = v;
+                const long long off = (long long)min(k0 + k, a.K - 1) * a.P + min(p0 + col, a.P - 4);
+                rx[i] = *reinterpret_cast<const float4*>(Xb + off);
+                if (TWO) ry[i] = *reinterpret_cast<const float4*>(X2b + off);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NBS; ++i) {
                 const int e = tid + i * 256, k = e / BN, col = e % BN;
-                float v = 0.f;
+                float v = 0.f, w = 0.f;
                 if (k0 + k < a.K && p0 + col < a.P) {
                     const long long off = (long long)(k0 + k) * a.P + p0 + col;
                     v = Xb[off];
-                    if (PRO != PRO_NONE) {
-                        const float c0 = a.coef[k0 + k], c1 = a.coef[a.K + k0 + k];
-                        float c2 = 0.f, c3 = 0.f, w = v;
-                        if (PRO == PRO_BN_BWD) {
-                            c2 = a.coef[2 * a.K + k0 + k]; c3 = a.coef[3 * a.K + k0 + k];
-                            w = X2b[off];
-                        }
-                        v = pro_apply<PRO>(v, w, c0, c1, c2, c3);
-                    }
+                    if (TWO) w = X2b[off];
                 }
                 rxs[i] = v;
+                if (TWO) rys[i] = w;
             }
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int e = tid + i * 256;
-            As[buf][e / BM][e % BM] = ra[i];
+            const int e = tid + i * 256, k = e / BM, m = e % BM;
+            As[buf][k][m] = (k0 + k < a.K && m0 + m < a.M) ? ra[i] : 0.0f;
         }
         if (VEC) {
 #pragma unroll
             for (int i = 0; i < NB4; ++i) {
-                const int f = tid + i * 256;
-                *reinterpret_cast<float4*>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = rx[i];
+                const int f = tid + i * 256, k = f / (BN / 4), col = (f % (BN / 4)) * 4;
+                float4 v = rx[i];
+                const bool ok = (k0 + k < a.K && p0 + col < a.P);
+                if (PRO == PRO_NONE) {
+                    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    const int kc = min(k0 + k, a.K - 1);
+                    const float c0 = a.coef[kc], c1 = a.coef[a.K + kc];
+                    float c2 = 0.f, c3 = 0.f;
+                    float4 w = v;
+                    if (TWO) { c2 = a.coef[2 * a.K + kc]; c3 = a.coef[3 * a.K + kc]; w = ry[i]; }
+                    v.x = ok ? pro_apply<PRO>(v.x, w.x, c0, c1, c2, c3) : 0.f;
+                    v.y = ok ? pro_apply<PRO>(v.y, w.y, c0, c1, c2, c3) : 0.f;
+                    v.z = ok ? pro_apply<PRO>(v.z, w.z, c0, c1, c2, c3) : 0.f;
+                    v.w = ok ? pro_apply<PRO>(v.w, w.w, c0, c1, c2, c3) : 0.f;
+                }
+                *reinterpret_cast<float4*>(&Bs[buf][k][col]) = v;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NBS; ++i) {
-                const int e = tid + i * 256;
-                Bs[buf][e / BN][e % BN] = rxs[i];
+                const int e = tid + i * 256, k = e / BN, col = e % BN;
+                float v = rxs[i];
+                if (PRO != PRO_NONE) {
+                    const bool ok = (k0 + k < a.K && p0 + col < a.P);
+                    const int kc = min(k0 + k, a.K - 1);
+                    const float c0 = a.coef[kc], c1 = a.coef[a.K + kc];
+                    float c2 = 0.f, c3 = 0.f, w = v;
+                    if (TWO) { c2 = a.coef[2 * a.K + kc]; c3 = a.coef[3 * a.K + kc]; w = rys[i]; }
+                    v = ok ? pro_apply<PRO>(v, w, c0, c1, c2, c3) : 0.f;
+                }
+                Bs[buf][k][col] = v;
             }
         }
     };
 
     const int nk = (a.K + BK - 1) / BK;
     load_stage(0);
-    store_stage(0);
+    store_stage(0, 0);
     __syncthreads();
     int cur = 0;
     const int kr = lane >> 5, c = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_stage((kt + 1) * BK);          // in flight under the MFMAs below
+        // fragments of step kk+2 are read from LDS while the four MFMAs of step kk run
+        float fa0 = As[cur][kr][wm * 64 + c], fa1 = As[cur][kr][wm * 64 + 32 + c];
+        float fb0 = Bs[cur][kr][wn * 64 + c], fb1 = Bs[cur][kr][wn * 64 + 32 + c];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[cur][kk + kr][wm * 64 + c];
-            const float a1 = As[cur][kk + kr][wm * 64 + 32 + c];
-            const float b0 = Bs[cur][kk + kr][wn * 64 + c];
-            const float b1 = Bs[cur][kk + kr][wn * 64 + 32 + c];
+            const float a0 = fa0, a1 = fa1, b0 = fb0, b1 = fb1;
+            if (kk + 2 < BK) {
+                fa0 = As[cur][kk + 2 + kr][wm * 64 + c];
+                fa1 = As[cur][kk + 2 + kr][wm * 64 + 32 + c];
+                fb0 = Bs[cur][kk + 2 + kr][wn * 64 + c];
+                fb1 = Bs[cur][kk + 2 + kr][wn * 64 + 32 + c];
+            }
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            // pin the order: next step's LDS reads first, then this step's four MFMAs cover them
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        if (kt + 1 < nk) store_stage(cur ^ 1);
+        if (kt + 1 < nk) store_stage(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
         cur ^= 1;
     }
@@ -206,8 +224,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = p0 + wn * 64 + j * 32 + c;
-                const float v = acc[i][j][r] + bv;
+                float v = acc[i][j][r] + bv;
                 if (row < a.M && col < a.P) {
+                    if (a.rowbias)
+                        v += a.rowbias[((long long)b * a.M + row) * (a.P / a.rb_group) + col / a.rb_group];
                     Yb[(long long)row * a.P + col] = v;
                     if (STATS) { s += v; q = __builtin_fmaf(v, v, q); }
                 }
@@ -238,7 +258,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int BK>
 int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
 {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -251,7 +271,7 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     dim3 grid((unsigned)total), block(256);
 #define USIP_GEMM_CASE(P_, S_, V_)                                                              \
     if (pro == P_ && stats == S_ && vec == V_) {                                                \
-        USIP_LAUNCH((gemm_kernel<WM, WN, P_, S_, V_>), grid, block, 0, st, a);                  \
+        USIP_LAUNCH((gemm_kernel<WM, WN, BK, P_, S_, V_>), grid, block, 0, st, a);                  \
         USIP_LAUNCH_CHECK();                                                                    \
         return USIP_OK;                                                                         \
     }
@@ -279,41 +299,32 @@ struct WgradArgs {
 };
 
 // One stage of a [rows][32 positions] operand tile of the weight gradient: thread -> (row, 4
-// consecutive positions), 8 lanes cover one 128-B row segment.  PRO_BN_BWD turns (dZ, Y) into dY.
-template <int N4, int PRO, bool VEC>
+// consecutive positions), 8 lanes cover one 128-B row segment.  Raw loads only; the BatchNorm-backward
+// prologue runs when the registers are written to LDS (after the MFMAs the loads overlap with).
+template <int N4, bool TWO, bool VEC>
 __device__ __forceinline__ void wgrad_load_rows(const float* __restrict__ base, const float* __restrict__ base2,
-                                                const float* __restrict__ coef, int rows, int P, int r0,
-                                                int p, int pend, int tid, float4 (&dst)[N4])
+                                                int rows, int P, int r0, int p, int pend, int tid,
+                                                float4 (&dst)[N4], float4 (&dst2)[TWO ? N4 : 1])
 {
 #pragma unroll
     for (int i = 0; i < N4; ++i) {
         const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-        if (r0 + row < rows) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+        if (VEC) {
+            // P % 4 == 0 and segments start at multiples of 32: a float4 is entirely inside or outside.
+            // Branch-free: clamped (valid) address, zeroed afterwards.
+            const long long off = (long long)min(r0 + row, rows - 1) * P + min(p + kq, P - 4);
+            v = *reinterpret_cast<const float4*>(base + off);           // masked at LDS-store time
+            if (TWO) w = *reinterpret_cast<const float4*>(base2 + off);
+        } else if (r0 + row < rows) {
             const long long off = (long long)(r0 + row) * P + p + kq;
-            if (VEC && p + kq + 3 < pend) {
-                const float4 t = *reinterpret_cast<const float4*>(base + off);
-                v0 = t.x; v1 = t.y; v2 = t.z; v3 = t.w;
-                if (PRO == PRO_BN_BWD) {
-                    const float4 u = *reinterpret_cast<const float4*>(base2 + off);
-                    w0 = u.x; w1 = u.y; w2 = u.z; w3 = u.w;
-                }
-            } else {
-                if (p + kq + 0 < pend) { v0 = base[off + 0]; if (PRO == PRO_BN_BWD) w0 = base2[off + 0]; }
-                if (p + kq + 1 < pend) { v1 = base[off + 1]; if (PRO == PRO_BN_BWD) w1 = base2[off + 1]; }
-                if (p + kq + 2 < pend) { v2 = base[off + 2]; if (PRO == PRO_BN_BWD) w2 = base2[off + 2]; }
-                if (p + kq + 3 < pend) { v3 = base[off + 3]; if (PRO == PRO_BN_BWD) w3 = base2[off + 3]; }
-            }
-            if (PRO == PRO_BN_BWD) {
-                const int ch = r0 + row;
-                const float c0 = coef[ch], c1 = coef[rows + ch], c2 = coef[2 * rows + ch], c3 = coef[3 * rows + ch];
-                v0 = (p + kq + 0 < pend) ? pro_apply<PRO_BN_BWD>(v0, w0, c0, c1, c2, c3) : 0.f;
-                v1 = (p + kq + 1 < pend) ? pro_apply<PRO_BN_BWD>(v1, w1, c0, c1, c2, c3) : 0.f;
-                v2 = (p + kq + 2 < pend) ? pro_apply<PRO_BN_BWD>(v2, w2, c0, c1, c2, c3) : 0.f;
-                v3 = (p + kq + 3 < pend) ? pro_apply<PRO_BN_BWD>(v3, w3, c0, c1, c2, c3) : 0.f;
-            }
+            if (p + kq + 0 < pend) { v.x = base[off + 0]; if (TWO) w.x = base2[off + 0]; }
+            if (p + kq + 1 < pend) { v.y = base[off + 1]; if (TWO) w.y = base2[off + 1]; }
+            if (p + kq + 2 < pend) { v.z = base[off + 2]; if (TWO) w.z = base2[off + 2]; }
+            if (p + kq + 3 < pend) { v.w = base[off + 3]; if (TWO) w.w = base2[off + 3]; }
         }
-        dst[i] = make_float4(v0, v1, v2, v3);
+        dst[i] = v;
+        if (TWO) dst2[i] = w;
     }
 }
 
@@ -331,7 +342,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int nmt = (a.M + BM - 1) / BM, nnt = (a.N + BN - 1) / BN;
-    const int tile = blockIdx.x % (nmt * nnt), slice = blockIdx.x / (nmt * nnt);
+    // All output tiles of one position slice stream the SAME rows of G and X in lockstep: put them on
+    // ONE XCD (workgroup id mod 8 selects the XCD) so that the re-reads are L2 hits instead of
+    // 8 separate fetches.  Speed only; any placement gives the same result.
+    const int total = gridDim.x;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+    const int tile = L % (nmt * nnt), slice = L / (nmt * nnt);
     const int m0 = (tile / nnt) * BM, n0 = (tile % nnt) * BN;
     const int b = slice / a.segs, seg = slice % a.segs;
     const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
@@ -347,50 +364,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    float4 rg[NG4], rx[NX4];
-    auto store_stage = [&](int buf) {
+    constexpr bool TWO = (PRO == PRO_BN_BWD);
+    float4 rg[NG4], rg2[TWO ? NG4 : 1], rx[NX4], rdummy[1];
+    auto store_stage = [&](int buf, int p) {
 #pragma unroll
         for (int i = 0; i < NG4; ++i) {
             const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
-            Gs[buf][kq][row] = rg[i].x; Gs[buf][kq + 1][row] = rg[i].y;
-            Gs[buf][kq + 2][row] = rg[i].z; Gs[buf][kq + 3][row] = rg[i].w;
+            float4 v = rg[i];
+            if (!TWO && VEC && !(m0 + row < a.M && p + kq < pend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (TWO) {
+                const int ch = min(m0 + row, a.M - 1);
+                const bool rok = m0 + row < a.M;
+                const float c0 = a.coef[ch], c1 = a.coef[a.M + ch], c2 = a.coef[2 * a.M + ch],
+                            c3 = a.coef[3 * a.M + ch];
+                const float4 w = rg2[i];
+                v.x = (rok && p + kq + 0 < pend) ? pro_apply<PRO_BN_BWD>(v.x, w.x, c0, c1, c2, c3) : 0.f;
+                v.y = (rok && p + kq + 1 < pend) ? pro_apply<PRO_BN_BWD>(v.y, w.y, c0, c1, c2, c3) : 0.f;
+                v.z = (rok && p + kq + 2 < pend) ? pro_apply<PRO_BN_BWD>(v.z, w.z, c0, c1, c2, c3) : 0.f;
+                v.w = (rok && p + kq + 3 < pend) ? pro_apply<PRO_BN_BWD>(v.w, w.w, c0, c1, c2, c3) : 0.f;
+            }
+            Gs[buf][kq][row] = v.x; Gs[buf][kq + 1][row] = v.y;
+            Gs[buf][kq + 2][row] = v.z; Gs[buf][kq + 3][row] = v.w;
         }
 #pragma unroll
         for (int i = 0; i < NX4; ++i) {
             const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
-            Xs[buf][kq][row] = rx[i].x; Xs[buf][kq + 1][row] = rx[i].y;
-            Xs[buf][kq + 2][row] = rx[i].z; Xs[buf][kq + 3][row] = rx[i].w;
+            float4 v = rx[i];
+            if (VEC && !(n0 + row < a.N && p + kq < pend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            Xs[buf][kq][row] = v.x; Xs[buf][kq + 1][row] = v.y;
+            Xs[buf][kq + 2][row] = v.z; Xs[buf][kq + 3][row] = v.w;
         }
     };
 
     const int nst = (pend - pbeg + BKP - 1) / BKP;
     if (nst > 0) {
-        wgrad_load_rows<NG4, PRO, VEC>(Gb, G2b, a.coef, a.M, a.P, m0, pbeg, pend, tid, rg);
-        wgrad_load_rows<NX4, PRO_NONE, VEC>(Xb, nullptr, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx);
-        store_stage(0);
+        wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
+        wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx, rdummy);
+        store_stage(0, pbeg);
     }
     __syncthreads();
     int cur = 0;
     const int kr = lane >> 5, c = lane & 31;
     for (int s = 0; s < nst; ++s) {
         if (s + 1 < nst) {
-            wgrad_load_rows<NG4, PRO, VEC>(Gb, G2b, a.coef, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg);
-            wgrad_load_rows<NX4, PRO_NONE, VEC>(Xb, nullptr, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx);
+            wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
+            wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx, rdummy);
         }
+        float fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = Gs[cur][kr][(wm * TM + i) * 32 + c];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = Xs[cur][kr][(wn * TN + j) * 32 + c];
 #pragma unroll
         for (int kk = 0; kk < BKP; kk += 2) {
             float av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = Gs[cur][kk + kr][(wm * TM + i) * 32 + c];
+            for (int i = 0; i < TM; ++i) av[i] = fa[i];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Xs[cur][kk + kr][(wn * TN + j) * 32 + c];
+            for (int j = 0; j < TN; ++j) bv[j] = fb[j];
+            if (kk + 2 < BKP) {                       // next step's fragments, under this step's MFMAs
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = Gs[cur][kk + 2 + kr][(wm * TM + i) * 32 + c];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = Xs[cur][kk + 2 + kr][(wn * TN + j) * 32 + c];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (s + 1 < nst) store_stage(cur ^ 1);
+        if (s + 1 < nst) store_stage(cur ^ 1, pbeg + (s + 1) * BKP);
         __syncthreads();
         cur ^= 1;
     }
@@ -411,7 +457,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 // dW[e] = sum over slices, in a fixed order: 64 elements x 4 slice lanes per block, every lane sums
 // its quarter of the slices (4 independent chains), the quarters are combined through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
-                                                           float* __restrict__ dW, long long elems, int slices)
+                                                           float* __restrict__ dW, long long elems, int slices,
+                                                           int N, int ldw, int coloff)
 {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -430,7 +477,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     red[q][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (q == 0 && i < elems) dW[i] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (q == 0 && i < elems)
+        dW[(i / N) * ldw + coloff + (i % N)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,11 +549,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 // Per (cloud, channel) row: s1 = sum dYhat, s2 = sum dYhat * yhat with
 // dYhat = dZ * [fma(y, sc, sh) > 0] (or dZ when !relu), yhat = (y - mean) * invstd.
-// mode 1 (no BN): s1 = sum dZ only (bias gradient of a layer without normalisation).
+// plain (no BN): s1 = sum dZ only (bias gradient of a layer without normalisation).
+// GROUP (K consecutive positions form one neighbourhood, K % 4 == 0, K/4 a power of two <= 64):
+// also gsum[0][row][m] = sum_k dYhat, gsum[1][row][m] = sum_k y -- what the pooled-concat layer
+// needs to push the gradient through its broadcast input without a second pass.
+template <bool GROUP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dZ, const float* __restrict__ Y, const float* __restrict__ coef,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
-    int relu, int plain, int C, int P, int nrows)
+    float* __restrict__ gsum, int relu, int plain, int C, int P, int nrows, int K)
 {
     __shared__ float red[2][4];
     const long long rowid = blockIdx.x;
@@ -514,14 +566,61 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     float s1 = 0.f, s2 = 0.f;
     if (plain) {
         for (int p = threadIdx.x; p < P; p += 256) s1 += dz[p];
+    } else if (GROUP) {
+        const float* y = Y + rowid * P;
+        const float sc = coef[ch], sh = coef[C + ch], mu = mean[ch], is = invstd[ch];
+        const int lpg = K / 4;                                   // lanes per group
+        const int G = P / K;
+        float* g0 = gsum + rowid * G;
+        float* g1 = gsum + ((long long)nrows + rowid) * G;
+        for (int p = threadIdx.x * 4; p < ((P + 1023) / 1024) * 1024; p += 1024) {
+            float gd = 0.f, gy = 0.f;
+            if (p < P) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + p);
+                const float4 dv = *reinterpret_cast<const float4*>(dz + p);
+                const float d0 = (!relu || __builtin_fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f;
+                const float d1 = (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
+                const float d2 = (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f;
+                const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
+                gd = (d0 + d1) + (d2 + d3);
+                gy = (yv.x + yv.y) + (yv.z + yv.w);
+                s1 += gd;
+                s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
+                s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
+                s2 = __builtin_fmaf(d2, (yv.z - mu) * is, s2);
+                s2 = __builtin_fmaf(d3, (yv.w - mu) * is, s2);
+            }
+            for (int off = lpg / 2; off > 0; off >>= 1) {        // lpg lanes = one neighbourhood
+                gd += __shfl_xor(gd, off);
+                gy += __shfl_xor(gy, off);
+            }
+            if (p < P && (threadIdx.x % lpg) == 0) { g0[p / K] = gd; g1[p / K] = gy; }
+        }
     } else {
         const float* y = Y + rowid * P;
         const float sc = coef[ch], sh = coef[C + ch], mu = mean[ch], is = invstd[ch];
-        for (int p = threadIdx.x; p < P; p += 256) {
-            const float yv = y[p];
-            const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dz[p] : 0.f;
-            s1 += d;
-            s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
+        const bool vec = (P % 4 == 0) && (((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y)) & 15u) == 0);
+        if (vec) {
+            for (int p = threadIdx.x * 4; p < P; p += 1024) {
+                const float4 yv = *reinterpret_cast<const float4*>(y + p);
+                const float4 dv = *reinterpret_cast<const float4*>(dz + p);
+                const float d0 = (!relu || __builtin_fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f;
+                const float d1 = (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
+                const float d2 = (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f;
+                const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
+                s1 += (d0 + d1) + (d2 + d3);
+                s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
+                s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
+                s2 = __builtin_fmaf(d2, (yv.z - mu) * is, s2);
+                s2 = __builtin_fmaf(d3, (yv.w - mu) * is, s2);
+            }
+        } else {
+            for (int p = threadIdx.x; p < P; p += 256) {
+                const float yv = y[p];
+                const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dz[p] : 0.f;
+                s1 += d;
+                s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
+            }
         }
     }
 #pragma unroll
@@ -566,6 +665,17 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
 }  // namespace
 
 // ================================================================================================
+// K-step of the GEMM pipeline: 16 by default (measured faster: 2x the workgroups per CU), USIP_GEMM_BK=32 selects the deeper stage.
+static int usip_gemm_bk()
+{
+    static int bk = 0;
+    if (!bk) {
+        const char* e = getenv("USIP_GEMM_BK");
+        bk = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    return bk;
+}
+
 extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 {
     const int BN = (M <= 64) ? 256 : 128;
@@ -573,7 +683,8 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 }
 
 extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
-                                 const float* coef, int pro, const float* bias, float* Y, float* stats,
+                                 const float* coef, int pro, const float* bias, const float* rowbias,
+                                 int rb_group, float* Y, float* stats,
                                  int M, int K, int P, int nb, void* stream)
 {
     if (M < 1 || K < 1 || P < 0 || nb < 0 || lda < M) return USIP_EINVAL;
@@ -581,9 +692,12 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
     if (!At || !X || !Y || pro < 0 || pro > 2) return USIP_EINVAL;
     if (pro != PRO_NONE && !coef) return USIP_EINVAL;
     if (pro == PRO_BN_BWD && (!X2 || stats)) return USIP_EINVAL;
-    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb};
+    if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
+    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group};
     hipStream_t st = (hipStream_t)stream;
-    return (M <= 64) ? launch_gemm<1, 4>(a, pro, st) : launch_gemm<2, 2>(a, pro, st);
+    const int bk = usip_gemm_bk();
+    if (M <= 64) return bk == 32 ? launch_gemm<1, 4, 32>(a, pro, st) : launch_gemm<1, 4, 16>(a, pro, st);
+    return bk == 32 ? launch_gemm<2, 2, 32>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
 }
 
 // Workspace (floats) the weight-gradient needs, and the slicing it will use.
@@ -613,17 +727,12 @@ extern "C" long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb)
 }
 
 extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro,
-                                  const float* X, float* workspace, float* dW,
+                                  const float* X, float* workspace, float* dW, int ldw, int coloff,
                                   int M, int N, int P, int nb, void* stream)
 {
-    if (M < 1 || N < 1 || P < 0 || nb < 0) return USIP_EINVAL;
+    if (M < 1 || N < 1 || P < 1 || nb < 1 || ldw < N + coloff || coloff < 0) return USIP_EINVAL;
     if (!dW) return USIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if ((long long)P * nb == 0) {
-        (void)hipGetLastError();
-        hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)M * N, st);
-        return e == hipSuccess ? USIP_OK : (int)e;
-    }
     if (!G || !X || !workspace || (pro != PRO_NONE && pro != PRO_BN_BWD)) return USIP_EINVAL;
     if (pro == PRO_BN_BWD && (!G2 || !coef)) return USIP_EINVAL;
     int seglen, segs, small, tiles;
@@ -651,7 +760,7 @@ extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* 
 #undef USIP_WGRAD_CASE
     const long long elems = (long long)M * N;
     USIP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st,
-                workspace, dW, elems, nb * segs);
+                workspace, dW, elems, nb * segs, N, ldw, coloff);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
@@ -705,16 +814,28 @@ extern "C" int usip_bn_apply_f32(const float* Y, const float* coef, float* Z, in
 extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* coef_fwd,
                                            const float* mean, const float* invstd, const float* gamma,
                                            int relu, float* partial, float* dgamma, float* dbeta,
-                                           float* coef4, int nb, int C, int P, void* stream)
+                                           float* coef4, float* gsum, int group,
+                                           int nb, int C, int P, void* stream)
 {
     if (nb < 1 || C < 1 || P < 1 || !dZ || !partial) return USIP_EINVAL;
     const int plain = (Y == nullptr);
+    if (gsum) {
+        // vector path only: K % 4 == 0, K/4 a power of two <= 64, 16-B aligned rows
+        const int lpg = group / 4;
+        if (plain || group < 4 || group % 4 != 0 || (lpg & (lpg - 1)) != 0 || lpg > 64 || P % group != 0 ||
+            (reinterpret_cast<uintptr_t>(dZ) & 15u) || (reinterpret_cast<uintptr_t>(Y) & 15u))
+            return USIP_EINVAL;
+    }
     if (!plain && (!coef_fwd || !mean || !invstd)) return USIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)nb * C;
     if (rows > 0x7fffffffLL) return USIP_EINVAL;
-    USIP_LAUNCH(bn_bwd_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean, invstd,
-                partial, relu, plain, C, P, (int)rows);
+    if (gsum)
+        USIP_LAUNCH((bn_bwd_reduce_kernel<true>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean,
+                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group);
+    else
+        USIP_LAUNCH((bn_bwd_reduce_kernel<false>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean,
+                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group);
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
                 (double)nb * (double)P, gamma, coef_fwd, mean, invstd, dgamma, dbeta, plain ? nullptr : coef4);

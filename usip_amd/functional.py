@@ -124,11 +124,141 @@ class _SharedMLPLayer(torch.autograd.Function):
         if not ctx.train_stats:
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
         x, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
-        dgamma, dbeta, coef4 = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu)
+        dgamma, dbeta, coef4, _ = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu)
         dx = ops.mlp_gemm(w2.contiguous(), dz, pro=2, X2=y, coef=coef4, tag="dgrad")[0] if need_x else None
         dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4) if need_w else None
         db = torch.zeros_like(gamma) if ctx.needs_input_grad[2] else None
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+
+
+def _group_sums_supported(K: int) -> bool:
+    lpg = K // 4
+    return K >= 4 and K % 4 == 0 and (lpg & (lpg - 1)) == 0 and lpg <= 64
+
+
+class _SharedMLPLayerPooled(torch.autograd.Function):
+    """The shared-MLP layer whose input is cat(h, expand(pooled)) over channels -- the reference
+    expands the max-pooled neighbourhood feature over K and concatenates it (networks.py:706-709,
+    layers.py:433-435) -- WITHOUT building that tensor:
+
+        W . [h ; pooled] = W_h . h  +  (W_p . pooled)[m]          (constant inside a neighbourhood)
+
+    The second term is a GEMM over M positions instead of M*K and enters the big GEMM's epilogue as
+    a per-neighbourhood row bias.  Backward: sum_k dY follows from per-neighbourhood sums the BN
+    reduction pass already produces, so d(pooled) and dW_p are M-sized GEMMs as well.  Same math as
+    the reference up to fp32 summation order; half the multiply-adds of that layer."""
+
+    @staticmethod
+    def forward(ctx, h, pooled, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
+                relu, pooled_first):
+        B, Ch, M, K = h.shape
+        Cp = pooled.shape[1]
+        Cout = w2.shape[0]
+        poff, hoff = (0, Cp) if pooled_first else (Ch, 0)
+        h3 = h.contiguous().view(B, Ch, M * K)
+        pooled = pooled.contiguous()
+        wt = w2.detach().t().contiguous()                                   # [Ctot][Cout]
+        r, _ = ops.mlp_gemm(wt[poff:poff + Cp], pooled, tag="fwd_pooled")   # [B,Cout,M]
+        y, stats = ops.mlp_gemm(wt[hoff:hoff + Ch], h3, bias, want_stats=True, rowbias=r, rb_group=K)
+        mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum,
+                                             running_mean, running_var)
+        z = ops.bn_apply(y, coef, relu)
+        ctx.save_for_backward(h3, pooled, w2, y, coef, mean, invstd, gamma)
+        ctx.dims = (B, Ch, Cp, Cout, M, K, poff, hoff)
+        ctx.relu = bool(relu)
+        return z.view(B, Cout, M, K)
+
+    @staticmethod
+    def backward(ctx, dz):
+        h3, pooled, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
+        B, Ch, Cp, Cout, M, K, poff, hoff = ctx.dims
+        dz = dz.contiguous().view(B, Cout, M * K)
+        dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu, group=K)
+        # sum over the K neighbours of dY = a1*dYhat + q1*y + q0
+        sdy = (coef4[0].view(1, -1, 1) * gsum[0] + coef4[2].view(1, -1, 1) * gsum[1]
+               + float(K) * coef4[3].view(1, -1, 1)).contiguous()
+        w2c = w2.contiguous()
+        dpooled = dh = dw = None
+        if ctx.needs_input_grad[1]:
+            dpooled = ops.mlp_gemm(w2c, sdy, tag="dgrad_pooled", M=Cp, a_offset=poff)[0]
+        if ctx.needs_input_grad[0]:
+            dh = ops.mlp_gemm(w2c, dz, pro=2, X2=y, coef=coef4, tag="dgrad", M=Ch, a_offset=hoff)[0]
+            dh = dh.view(B, Ch, M, K)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(w2c)
+            ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff)
+            ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
+        db = torch.zeros_like(gamma) if ctx.needs_input_grad[3] else None
+        return dh, dpooled, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def conv1x1_bn_act_pooled(h: torch.Tensor, pooled: torch.Tensor, weight: torch.Tensor,
+                          bias: Optional[torch.Tensor], bn, relu: bool, pooled_first: bool) -> torch.Tensor:
+    """conv1x1_bn_act(cat((expand(pooled), h) if pooled_first else (h, expand(pooled)), dim=1)) without the
+    concatenated tensor.  h [B,Ch,M,K], pooled [B,Cp,M]."""
+    require_device(h, "the shared MLP")
+    K = h.shape[3]
+    fused = (bn is not None and bn.training and bias is not None and _group_sums_supported(K)
+             and torch.is_grad_enabled())
+    if not fused:
+        e = pooled.unsqueeze(3).expand(-1, -1, -1, K)
+        return conv1x1_bn_act(torch.cat((e, h) if pooled_first else (h, e), dim=1), weight, bias, bn, relu)
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _SharedMLPLayerPooled.apply(h, pooled, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       True, bn.momentum, bn.eps, relu, pooled_first)
+
+
+# --------------------------------------------------------------------------- grouping / pooling
+class _GroupMax(torch.autograd.Function):
+    """max over the K neighbours (torch.max(dim=3), networks.py:706,710, layers.py:433,438); the
+    gradient goes to the first arg-max."""
+
+    @staticmethod
+    def forward(ctx, z):
+        pooled, arg = ops.group_max(z.contiguous())
+        ctx.save_for_backward(arg)
+        ctx.K = z.shape[3]
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        (arg,) = ctx.saved_tensors
+        return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K)
+
+
+def group_max(z: torch.Tensor) -> torch.Tensor:
+    """z [B,C,M,K] -> [B,C,M]."""
+    require_device(z, "group_max")
+    return _GroupMax.apply(z)
+
+
+class _KnnGroup(torch.autograd.Function):
+    """cat(gather(database, I) - query, gather(feat, I)) as one tensor [B, 3+C, M, K]
+    (models/layers.py:422-430); only the features carry a gradient (coordinates are detached there)."""
+
+    @staticmethod
+    def forward(ctx, feat, database, query, idx32):
+        B, C, N = feat.shape
+        _, M, K = idx32.shape
+        out = torch.empty((B, 3 + C, M, K), dtype=torch.float32, device=feat.device)
+        ops.group_gather(database.contiguous(), idx32, sub=query.contiguous(), out=out, coff=0)
+        ops.group_gather(feat.contiguous(), idx32, out=out, coff=3)
+        ctx.save_for_backward(idx32)
+        ctx.dims = (C, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx32,) = ctx.saved_tensors
+        C, N = ctx.dims
+        return ops.group_gather_backward(dout.contiguous(), idx32, C, N, coff=3), None, None, None
+
+
+def knn_group(feat, database, query, idx32):
+    require_device(feat, "knn_group")
+    return _KnnGroup.apply(feat, database, query, idx32)
 
 
 def conv1x1_bn_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],

@@ -177,13 +177,16 @@ class GeneralKNNFusionModule(nn.Module):
         """query Bx3xM, database Bx3xN, x BxCxN -> BxC'xM.  Coordinates carry no gradient."""
         knn_I = Fh.knn_indices(query, database, K)                       # layers.py:417-421
         self.last_knn_I = knn_I
-        coord = Fh.gather_neighbours(database.detach(), knn_I) - query.detach().unsqueeze(3)
-        feat = Fh.gather_neighbours(x, knn_I)
-        h = torch.cat((coord, feat), dim=1)
+        h = Fh.knn_group(x, database.detach(), query.detach(), knn_I.int().contiguous())   # :422-430
         for layer in self.layers_before:
             h = layer(h, epoch)
-        pooled = torch.max(h, dim=3, keepdim=True)[0]
-        y = torch.cat((pooled.expand_as(h), h), dim=1)
-        for layer in self.layers_after:
+        pooled = Fh.group_max(h)                                         # :433
+        first, rest = self.layers_after[0], list(self.layers_after)[1:]
+        bn = getattr(first, "norm", None)
+        if bn is not None:
+            bn.decay_momentum(epoch)
+        y = Fh.conv1x1_bn_act_pooled(h, pooled, first.conv.weight, first.conv.bias, bn,
+                                     first.activation == "relu", pooled_first=True)   # :435
+        for layer in rest:
             y = layer(y, epoch)
-        return torch.max(y, dim=3, keepdim=False)[0]
+        return Fh.group_max(y)                                           # :438

@@ -116,13 +116,16 @@ class RPN_Detector_Ball(_DetectorTail):
         x = x.contiguous()
         node = node.contiguous()
         x_aug = torch.cat((x, sn), dim=1)
-        ball_idx = ops.ball_query_coords(node, x, self.ball_radius, self.ball_k).long()   # :694-698 fused
-        g = Fh.gather_neighbours(x_aug, ball_idx)
-        g = torch.cat((g[:, 0:3] - node.unsqueeze(3), g[:, 3:]), dim=1)   # networks.py:703
+        ball_idx32 = ops.ball_query_coords(node, x, self.ball_radius, self.ball_k)        # :694-698 fused
+        g = ops.group_gather(x_aug, ball_idx32, sub=node)                 # gather + decenter :699-703
         h = self.conv3(self.conv2(self.conv1(g)))                         # no epoch: networks.py:705
-        pooled = torch.max(h, dim=3, keepdim=True)[0]
-        h = self.conv5(self.conv4(torch.cat((h, pooled.expand_as(h)), dim=1)))
-        second_max = torch.max(h, dim=3, keepdim=False)[0]
+        pooled = Fh.group_max(h)                                          # :706
+        h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
+                                     getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
+                                     pooled_first=False)                  # cat(h, expand(max)) :708-709
+        h = self.conv5(h)
+        second_max = Fh.group_max(h)                                      # :710
+        ball_idx = ball_idx32.long()
         keypoints, sigmas = self._tail(node, second_max, epoch)
         self.last_indices = dict(ball_idx=ball_idx, knn_I=self.knnlayer_1.last_knn_I)
         return node, keypoints, sigmas, None

@@ -5,6 +5,7 @@ memory + stream plumbing only), enqueues the HIP kernels on torch's CURRENT stre
 returns without synchronising.  Host tensors raise RuntimeError: there is no CPU path here.
 """
 import ctypes
+from typing import Optional
 
 import torch
 
@@ -148,25 +149,31 @@ def _opt(t):
 
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
-             X2=None, coef=None, tag: str = "fwd"):
-    """Y[b] = At^T . pro(X[b]) + bias.  At [K,M] (K-major matrix operand), X [nb,K,P] -> Y [nb,M,P]
-    (+ stats [2,tiles,M] when want_stats)."""
+             X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
+             M: Optional[int] = None, a_offset: int = 0):
+    """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
+    At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
+    (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,tiles,M] when want_stats)."""
     _need(At, "At", torch.float32)
     _need(X, "X", torch.float32)
-    K, M = At.shape
+    K, lda = At.shape
+    M = lda if M is None else int(M)
     nb, Kx, P = X.shape
-    if Kx != K:
-        raise RuntimeError("mlp_gemm: At is [%d,%d] but X has %d channels" % (K, M, Kx))
+    if Kx != K or a_offset < 0 or a_offset + M > lda:
+        raise RuntimeError("mlp_gemm: operand shapes do not match (At %s, X %s, M %d, offset %d)"
+                           % (tuple(At.shape), tuple(X.shape), M, a_offset))
     Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
     stats = None
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, tiles, M), dtype=torch.float32, device=X.device)
+    a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P):
-        _lib.check(_lib.lib().usip_mlp_gemm_f32(_ptr(At), M, _ptr(X), _opt(X2), _opt(coef), int(pro), _opt(bias),
-                                                _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), "usip_mlp_gemm_f32")
+        _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, lda, _ptr(X), _opt(X2), _opt(coef), int(pro), _opt(bias),
+                                                _opt(rowbias), int(rb_group), _ptr(Y), _opt(stats), M, K, P, nb,
+                                                _stream(X)), "usip_mlp_gemm_f32")
     return Y, stats
 
 
@@ -195,37 +202,94 @@ def bn_apply(Y, coef, relu: bool):
     return Z
 
 
-def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool):
-    """-> (dgamma [C], dbeta [C], coef4 [4,C]).  Y None: plain mode, returns (None, sum dZ, None)."""
+def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: int = 0):
+    """-> (dgamma [C], dbeta [C], coef4 [4,C], gsum).  Y None: plain mode, returns (None, sum dZ, None, None).
+    group > 0 additionally returns gsum [2,nb,C,P/group] (per-neighbourhood sums of dYhat and y)."""
     nb, C, P = dZ.shape
     dev = dZ.device
     partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
     dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-    dgamma = coef4 = None
+    dgamma = coef4 = gsum = None
     if Y is not None:
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+        if group:
+            gsum = torch.empty((2, nb, C, P // group), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("bn_backward_reduce", 4.0 * nb * C * P * (1 if Y is None else 2)):
         _lib.check(_lib.lib().usip_bn_backward_reduce_f32(_ptr(dZ), _opt(Y), _opt(coef_fwd), _opt(mean), _opt(invstd),
                                                           _opt(gamma), int(bool(relu)), _ptr(partial), _opt(dgamma),
-                                                          _ptr(dbeta), _opt(coef4), nb, C, P, _stream(dZ)),
+                                                          _ptr(dbeta), _opt(coef4), _opt(gsum), int(group),
+                                                          nb, C, P, _stream(dZ)),
                    "usip_bn_backward_reduce_f32")
-    return dgamma, dbeta, coef4
+    return dgamma, dbeta, coef4, gsum
 
 
-def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None):
-    """dW [M,N] = sum_{b,p} pro(G)[b,m,p] * X[b,n,p]; G [nb,M,P], X [nb,N,P]."""
+def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0):
+    """dW [M,N] = sum_{b,p} pro(G)[b,m,p] * X[b,n,p]; G [nb,M,P], X [nb,N,P].
+    With `out` ([M, ldw] contiguous) the result is written into columns [coloff, coloff+N) of it."""
     nb, M, P = G.shape
     N = X.shape[1]
     dev = G.device
     ws_n = _lib.lib().usip_mlp_wgrad_workspace(M, N, P, nb)
     ws = torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev)
-    dW = torch.empty((M, N), dtype=torch.float32, device=dev)
+    dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+    ldw = dW.shape[1]
     with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
                                              4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P):
         _lib.check(_lib.lib().usip_mlp_wgrad_f32(_ptr(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _ptr(ws), _ptr(dW),
-                                                 M, N, P, nb, _stream(G)), "usip_mlp_wgrad_f32")
+                                                 int(ldw), int(coloff), M, N, P, nb, _stream(G)), "usip_mlp_wgrad_f32")
     return dW
+
+
+# --------------------------------------------------------------------------- grouping / pooling
+def group_gather(x, idx32, sub=None, out=None, coff: int = 0):
+    """out[b, coff+c, m, k] = x[b, c, idx[b,m,k]] - (c < nsub ? sub[b,c,m] : 0).  x [B,C,N], idx i32 [B,M,K],
+    sub [B,nsub,M] or None.  `out` [B,Ctot,M,K] lets several gathers fill one pre-concatenated tensor."""
+    _need(x, "x", torch.float32)
+    _need(idx32, "idx", torch.int32)
+    B, C, N = x.shape
+    _, M, K = idx32.shape
+    if out is None:
+        out = torch.empty((B, C, M, K), dtype=torch.float32, device=x.device)
+    Ctot = out.shape[1]
+    nsub = 0 if sub is None else sub.shape[1]
+    with torch.cuda.device(x.device), prof.kernel("group_gather", 4.0 * B * M * K * (C + 1)):
+        _lib.check(_lib.lib().usip_group_gather_f32(_ptr(x), _ptr(idx32), _opt(sub), _ptr(out), B, C, N, M, K, nsub,
+                                                    Ctot, int(coff), _stream(x)), "usip_group_gather_f32")
+    return out
+
+
+def group_gather_backward(dout, idx32, C: int, N: int, coff: int = 0):
+    """dx [B,C,N] = scatter-add of dout[:, coff:coff+C] (dout [B,Ctot,M,K] contiguous)."""
+    _need(dout, "dout", torch.float32)
+    B, Ctot, M, K = dout.shape
+    dx = torch.empty((B, C, N), dtype=torch.float32, device=dout.device)
+    with torch.cuda.device(dout.device), prof.kernel("group_gather_bwd", 4.0 * B * M * K * (C + 1)):
+        _lib.check(_lib.lib().usip_group_gather_backward_f32(_ptr(dout), _ptr(idx32), _ptr(dx), B, C, N, M, K, Ctot,
+                                                             int(coff), _stream(dout)), "usip_group_gather_backward_f32")
+    return dx
+
+
+def group_max(z):
+    """z [B,C,M,K] -> (pooled [B,C,M], arg i32 [B,C,M])."""
+    _need(z, "z", torch.float32)
+    B, C, M, K = z.shape
+    pooled = torch.empty((B, C, M), dtype=torch.float32, device=z.device)
+    arg = torch.empty((B, C, M), dtype=torch.int32, device=z.device)
+    with torch.cuda.device(z.device), prof.kernel("group_max", 4.0 * B * C * M * (K + 2)):
+        _lib.check(_lib.lib().usip_group_max_f32(_ptr(z), _ptr(pooled), _ptr(arg), B * C * M, K, _stream(z)),
+                   "usip_group_max_f32")
+    return pooled, arg
+
+
+def group_max_backward(dpooled, arg, K: int):
+    _need(dpooled, "dpooled", torch.float32)
+    B, C, M = dpooled.shape
+    dz = torch.empty((B, C, M, int(K)), dtype=torch.float32, device=dpooled.device)
+    with torch.cuda.device(dpooled.device), prof.kernel("group_max_bwd", 4.0 * B * C * M * (K + 2)):
+        _lib.check(_lib.lib().usip_group_max_backward_f32(_ptr(dpooled), _ptr(arg), _ptr(dz), B * C * M, int(K),
+                                                          _stream(dpooled)), "usip_group_max_backward_f32")
+    return dz
 
 
 def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:
