@@ -145,6 +145,7 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
  * reduced in fixed order (deterministic).  dW is written as dW[m*ldw + coloff + n], so a column
  * block of a wider weight matrix can be filled in place. */
 long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb);
+int usip_mlp_wgrad_blocks(int M, int N, int P, int nb);        /* workgroups launched (profiling aid) */
 int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro, const float* X,
                        float* workspace, float* dW, int ldw, int coloff,
                        int M, int N, int P, int nb, void* stream);
@@ -164,6 +165,13 @@ int usip_group_gather_backward_f32(const float* dout, const int32_t* idx, float*
 int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, long long rows, int K, void* stream);
 int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float* dz,
                                 long long rows, int K, void* stream);
+
+/* ------------------------------------------------------------------ a-7  node KNN
+ * idx[b][m][0..K) = the K database points nearest to query m, ascending distance (lower index first on
+ * exact ties): torch.norm + torch.topk(K, largest=False, sorted=True) of models/layers.py:417-421 without
+ * the B x M x N matrix.  query f32 [B][3][M], database f32 [B][3][N], N <= 1024, K <= N. */
+int usip_knn_f32(const float* query, const float* database, int32_t* idx,
+                 int B, int M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

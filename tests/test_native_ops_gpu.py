@@ -149,3 +149,22 @@ def test_ball_query_full_size_properties():
     rank = torch.cumsum(inside.long(), -1) - 1
     assert torch.equal(torch.gather(rank, 2, out)[genuine], j.expand_as(out)[genuine])
     assert torch.equal(_ops().ball_query_coords(tn, tx, r, K).long(), out)
+
+
+# ------------------------------------------------------------------ node KNN
+@pytest.mark.parametrize("shape", [(3, 64, 64, 32), (2, 512, 512, 16), (2, 100, 777, 5), (1, 7, 1024, 64), (2, 30, 30, 30)])
+def test_knn_matches_oracle_topk(shape):
+    """usip_knn_f32 against torch.norm + torch.topk(sorted=True) on the pinned CPU platform."""
+    from usip_amd import synth
+    B, M, N, K = shape
+    rng = np.random.default_rng(M + N + K)
+    db = np.ascontiguousarray(np.stack([synth.make_cloud(rng, N, "slab:10") for _ in range(B)]))
+    q = db[:, :, :M].copy() if M <= N else np.ascontiguousarray(np.stack([synth.make_cloud(rng, M, "slab:10") for _ in range(B)]))
+    tq, td = torch.from_numpy(q), torch.from_numpy(db)
+    norm = torch.norm(tq.unsqueeze(3) - td.unsqueeze(2), dim=1)
+    want_d, want_i = torch.topk(norm, k=K, dim=2, largest=False, sorted=True)
+    got = _ops().knn(tq.to(DEV), td.to(DEV), K).cpu().long()
+    got_d = torch.gather(norm, 2, got)
+    assert torch.equal(got_d, want_d)                       # same distances in the same order (bit-exact values)
+    distinct = (want_d[..., 1:] != want_d[..., :-1]).all(-1)
+    assert torch.equal(got[distinct], want_i[distinct])     # identical indices wherever there is no exact tie

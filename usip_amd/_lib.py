@@ -34,6 +34,7 @@ SIGNATURES = {
     "usip_bn_backward_reduce_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _f32p,
                                      _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_workspace": ([_int, _int, _int, _int], ctypes.c_longlong),
+    "usip_mlp_wgrad_blocks": ([_int, _int, _int, _int], _int),
     "usip_mlp_wgrad_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
                             _stream], _int),
     "usip_group_gather_f32": ([_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int,
@@ -41,6 +42,7 @@ SIGNATURES = {
     "usip_group_gather_backward_f32": ([_f32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _stream], _int),
     "usip_group_max_f32": ([_f32p, _f32p, _i32p, ctypes.c_longlong, _int, _stream], _int),
     "usip_group_max_backward_f32": ([_f32p, _i32p, _f32p, ctypes.c_longlong, _int, _stream], _int),
+    "usip_knn_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_ball_query_coords_f32": ([_f32p, _f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),
 }
 

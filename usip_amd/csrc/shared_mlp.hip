@@ -726,6 +726,14 @@ extern "C" long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb)
     return (long long)nb * segs * M * N;
 }
 
+// Number of workgroups usip_mlp_wgrad_f32 launches (lets a profiler match launches to layer shapes).
+extern "C" int usip_mlp_wgrad_blocks(int M, int N, int P, int nb)
+{
+    int seglen, segs, small, tiles;
+    wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
+    return tiles * nb * segs;
+}
+
 extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro,
                                   const float* X, float* workspace, float* dW, int ldw, int coloff,
                                   int M, int N, int P, int nb, void* stream)

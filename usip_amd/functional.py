@@ -51,12 +51,15 @@ def nearest_distance(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, to
 
 
 def knn_indices(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
-    """The K nearest database points of every query point, nearest first, int64 [B,M,K]
-    (torch.norm + topk(sorted=True), models/layers.py:417-421).  The distance matrix comes from
-    the HIP kernel in the oracle platform's arithmetic order, so the ordering is the oracle's."""
+    """The K nearest database points of every query point, nearest first, int32 [B,M,K]
+    (torch.norm + topk(sorted=True), models/layers.py:417-421).  Distances use the oracle platform's
+    arithmetic order, so the ordering is the oracle's."""
     require_device(query, "knn_indices")
-    dist = ops.pairwise_dist(query.detach().contiguous(), database.detach().contiguous())
-    return torch.topk(dist, k=K, dim=2, largest=False, sorted=True)[1]
+    q, d = query.detach().contiguous(), database.detach().contiguous()
+    if d.shape[2] <= 1024:
+        return ops.knn(q, d, K)
+    # node counts above 1024 are outside the detector's configurations: distance matrix + ATen top-k
+    return torch.topk(ops.pairwise_dist(q, d), k=K, dim=2, largest=False, sorted=True)[1].int()
 
 
 # --------------------------------------------------------------------------- gathers

@@ -177,7 +177,7 @@ class GeneralKNNFusionModule(nn.Module):
         """query Bx3xM, database Bx3xN, x BxCxN -> BxC'xM.  Coordinates carry no gradient."""
         knn_I = Fh.knn_indices(query, database, K)                       # layers.py:417-421
         self.last_knn_I = knn_I
-        h = Fh.knn_group(x, database.detach(), query.detach(), knn_I.int().contiguous())   # :422-430
+        h = Fh.knn_group(x, database.detach(), query.detach(), knn_I)    # :422-430
         for layer in self.layers_before:
             h = layer(h, epoch)
         pooled = Fh.group_max(h)                                         # :433

@@ -168,9 +168,17 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, tiles, M), dtype=torch.float32, device=X.device)
     a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
+    def _key():
+        wm, wn = (1, 4) if M <= 64 else (2, 2)
+        tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
+        vec = P % 4 == 0
+        return "gemm_kernel<%d, %d, 16, %d, %s, %s> |wg=%d" % (
+            wm, wn, pro, "true" if want_stats else "false", "true" if vec else "false",
+            tiles * ((M + wm * 64 - 1) // (wm * 64)))
+
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
-                                                  2.0 * M * K * nb * P):
+                                                  2.0 * M * K * nb * P, rocprof_key=_key):
         _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, lda, _ptr(X), _opt(X2), _opt(coef), int(pro), _opt(bias),
                                                 _opt(rowbias), int(rb_group), _ptr(Y), _opt(stats), M, K, P, nb,
                                                 _stream(X)), "usip_mlp_gemm_f32")
@@ -234,8 +242,14 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     ws = torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev)
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     ldw = dW.shape[1]
+    def _key():
+        t = 1 if (M <= 64 and N <= 64) else 2
+        return "wgrad_kernel<%d, %d, %d, %s> |wg=%d" % (t, t, pro, "true" if P % 4 == 0 else "false",
+                                                       _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
+
     with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
-                                             4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P):
+                                             4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
+                                             rocprof_key=_key):
         _lib.check(_lib.lib().usip_mlp_wgrad_f32(_ptr(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _ptr(ws), _ptr(dW),
                                                  int(ldw), int(coloff), M, N, P, nb, _stream(G)), "usip_mlp_wgrad_f32")
     return dW
@@ -290,6 +304,19 @@ def group_max_backward(dpooled, arg, K: int):
         _lib.check(_lib.lib().usip_group_max_backward_f32(_ptr(dpooled), _ptr(arg), _ptr(dz), B * C * M, int(K),
                                                           _stream(dpooled)), "usip_group_max_backward_f32")
     return dz
+
+
+def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
+    """a-7: i32 [B,M,K] nearest-first neighbour indices; query [B,3,M], database [B,3,N], N <= 1024."""
+    _need_pts(query, "query")
+    _need_pts(database, "database")
+    B, _, M = query.shape
+    N = database.shape[2]
+    out = torch.empty((B, M, int(K)), dtype=torch.int32, device=query.device)
+    with torch.cuda.device(query.device), prof.kernel("knn", 4.0 * B * (3 * (M + N) + M * K), 8.0 * B * M * N):
+        _lib.check(_lib.lib().usip_knn_f32(_ptr(query), _ptr(database), _ptr(out), B, M, N, int(K), _stream(query)),
+                   "usip_knn_f32")
+    return out
 
 
 def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:

@@ -13,6 +13,7 @@ import torch
 
 enabled = False
 _records = defaultdict(list)        # name -> [(start_event, end_event, bytes, flops)]
+_keys = {}                          # name -> rocprof key
 
 
 def enable(flag: bool = True):
@@ -25,10 +26,14 @@ def reset():
 
 
 @contextmanager
-def kernel(name: str, nbytes: float = 0.0, flops: float = 0.0):
+def kernel(name: str, nbytes: float = 0.0, flops: float = 0.0, rocprof_key=None):
+    """rocprof_key: "<kernel template> |wg=<workgroups>" as tools/pmc_summary.py names launches, so that
+    PMC traffic collected in a separate rocprofv3 pass can be attached to this operator."""
     if not enabled:
         yield
         return
+    if rocprof_key is not None:
+        _keys[name] = rocprof_key() if callable(rocprof_key) else rocprof_key
     s = torch.cuda.Event(enable_timing=True)
     e = torch.cuda.Event(enable_timing=True)
     s.record()                      # current stream == launch stream of the wrapped kernel
@@ -47,7 +52,7 @@ def summary():
         nb = sum(r[2] for r in recs) / len(recs)
         fl = sum(r[3] for r in recs) / len(recs)
         avg_s = tot / len(recs) * 1e-3
-        out[name] = dict(calls=len(recs), total_ms=tot, avg_us=avg_s * 1e6, bytes_per_call=nb,
+        out[name] = dict(rocprof_key=_keys.get(name), calls=len(recs), total_ms=tot, avg_us=avg_s * 1e6, bytes_per_call=nb,
                          flops_per_call=fl, GBps=(nb / avg_s / 1e9) if avg_s > 0 else 0.0,
                          TFLOPs=(fl / avg_s / 1e12) if avg_s > 0 else 0.0)
     return out
