@@ -89,10 +89,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    # One process per GPU over RCCL ("nccl" IS RCCL on ROCm).  USIP_DIST_BACKEND=gloo + USIP_SHARE_DEVICE=1 is a
+    # debugging aid only: it lets the N>1 code path run with several ranks on ONE GPU (RCCL refuses that).
+    backend = os.environ.get("USIP_DIST_BACKEND", "nccl")
+    if os.environ.get("USIP_SHARE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from usip_amd import prof, synth
     from usip_amd.networks import DetectorOptions

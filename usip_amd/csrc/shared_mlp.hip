@@ -42,6 +42,8 @@ struct GemmArgs {
     float* stats;                      // [2][ntn][M] or null
     int M, K, P, nb;
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
+    int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
+                                        // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
 };
 
 // prologue on one element of the streamed operand, channel coefficients c0..c3
@@ -59,7 +61,7 @@ __device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1
 }
 
 template <int WM, int WN, int BK, int PRO, bool STATS, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
+__global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 {
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int NA = BM * BK / 256;           // A elements per thread per stage
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
     int cur = 0;
     const int kr = lane >> 5, c = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_stage((kt + 1) * BK);          // in flight under the MFMAs below
+        if (kt + 1 < nk && a.ablate == 0) load_stage((kt + 1) * BK);   // in flight under the MFMAs below
         // fragments of step kk+2 are read from LDS while the four MFMAs of step kk run
         float fa0 = As[cur][kr][wm * 64 + c], fa1 = As[cur][kr][wm * 64 + 32 + c];
         float fb0 = Bs[cur][kr][wn * 64 + c], fb1 = Bs[cur][kr][wn * 64 + 32 + c];
@@ -204,8 +206,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a)
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        if (kt + 1 < nk) store_stage(cur ^ 1, (kt + 1) * BK);
-        __syncthreads();
+        if (kt + 1 < nk && a.ablate < 2) store_stage(cur ^ 1, (kt + 1) * BK);
+        if (a.ablate < 2) __syncthreads();
         cur ^= 1;
     }
 
@@ -693,7 +695,9 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
     if (pro != PRO_NONE && !coef) return USIP_EINVAL;
     if (pro == PRO_BN_BWD && (!X2 || stats)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
-    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group};
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
+    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, ablate};
     hipStream_t st = (hipStream_t)stream;
     const int bk = usip_gemm_bk();
     if (M <= 64) return bk == 32 ? launch_gemm<1, 4, 32>(a, pro, st) : launch_gemm<1, 4, 16>(a, pro, st);
