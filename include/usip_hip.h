@@ -143,11 +143,13 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
 /* dW[m][n] = sum_{b,p} pro(G)[b][m][p] * X[b][n][p]   (pro 0: G = dY given; pro 2: G = dZ, G2 = Y,
  * coef = coef4 as above).  workspace: usip_mlp_wgrad_workspace(M, N, P, nb) floats of partial tiles,
  * reduced in fixed order (deterministic).  dW is written as dW[m*ldw + coloff + n], so a column
- * block of a wider weight matrix can be filled in place. */
+ * block of a wider weight matrix can be filled in place.  xcoef (may be NULL): [2][N]; X is then the
+ * PRE-BatchNorm output of the producing layer and relu(X*xcoef[0][n] + xcoef[1][n]) is formed on the fly
+ * (the activated tensor is never stored). */
 long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb);
 int usip_mlp_wgrad_blocks(int M, int N, int P, int nb);        /* workgroups launched (profiling aid) */
 int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro, const float* X,
-                       float* workspace, float* dW, int ldw, int coloff,
+                       const float* xcoef, float* workspace, float* dW, int ldw, int coloff,
                        int M, int N, int P, int nb, void* stream);
 
 /* ------------------------------------------------------------------ a-6 / a-7 / a-12  grouping, pooling
@@ -163,6 +165,10 @@ int usip_group_gather_backward_f32(const float* dout, const int32_t* idx, float*
 /* pooled[row] = max_k z[row][k], arg[row] = first k attaining it (torch.max over the K axis,
  * networks.py:706,710, layers.py:433,438); rows = B*C*M.  Backward: dz[row][k] = (k==arg)*dpooled. */
 int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, long long rows, int K, void* stream);
+/* The same pooling applied to relu?(y*coef[0][c] + coef[1][c]) formed on the fly from a layer's pre-BatchNorm
+ * output y [B][C][M][K] (K % 4 == 0, K/4 a power of two <= 64): BN-apply + ReLU + max in ONE pass over y. */
+int usip_group_max_act_f32(const float* y, const float* coef, int relu, float* pooled, int32_t* arg,
+                           int B, int C, int M, int K, void* stream);
 int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float* dz,
                                 long long rows, int K, void* stream);
 

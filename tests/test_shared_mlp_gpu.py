@@ -95,3 +95,37 @@ def test_shared_mlp_eval_mode_uses_running_stats():
     want = torch.relu(bn(conv(x)))
     got = Fh.conv1x1_bn_act(x, conv.weight, conv.bias, bn, True)
     assert _rel(got, want) <= 1e-5
+
+
+def test_lazy_activation_chain_equals_materialised_chain():
+    """conv-bn-relu x3 -> max over K with activations handed on as LazyAct (BN+ReLU applied in the consumer's
+    prologue, fused BN+ReLU+max) must equal the same chain with every activation materialised: same forward,
+    same parameter and input gradients (identical arithmetic per element, so essentially bit-equal)."""
+    from usip_amd import functional as Fh
+    from usip_amd import layers
+    torch.manual_seed(3)
+    B, C0, M, K = 2, 7, 24, 16
+    x = torch.randn(B, C0, M, K, device=DEV)
+    gy = torch.randn(B, 48, M, device=DEV)
+
+    def build():
+        torch.manual_seed(11)
+        mods = [layers.MyConv2d(C0, 32, (1, 1), activation="relu", normalization="batch"),
+                layers.MyConv2d(32, 40, (1, 1), activation="relu", normalization="batch"),
+                layers.MyConv2d(40, 48, (1, 1), activation="relu", normalization="batch")]
+        return [m.to(DEV).train() for m in mods]
+
+    outs = []
+    for lazy in (False, True):
+        mods = build()
+        xi = x.clone().requires_grad_(True)
+        h = xi
+        for m in mods:
+            h = m(h, None, defer=lazy)
+        if lazy:
+            assert isinstance(h, Fh.LazyAct)
+        pooled = Fh.group_max(h)
+        pooled.backward(gy)
+        outs.append([pooled.detach(), xi.grad] + [p.grad for m in mods for p in m.parameters()])
+    for a, b in zip(*outs):
+        assert _rel(a, b) <= 2e-6

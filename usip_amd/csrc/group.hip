@@ -75,9 +75,12 @@ __global__ __launch_bounds__(256) void group_max_kernel(
 }
 
 // K % 4 == 0 and L = K/4 a power of two <= 64: every lane owns 4 consecutive neighbours (one 16-B load).
+// coef != null: z is the producer's pre-BatchNorm output and the activation relu?(z*coef[0][c]+coef[1][c])
+// is applied on the fly (the activated tensor is never written): rows are (b, c, m), c = (row / M) % C.
 template <int L>
 __global__ __launch_bounds__(256) void group_max4_kernel(
-    const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows)
+    const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows,
+    const float* __restrict__ coef, int relu, int C, int M)
 {
     constexpr int RPB = 256 / L;
     const int sub = threadIdx.x % L;
@@ -85,7 +88,14 @@ __global__ __launch_bounds__(256) void group_max4_kernel(
     float best = -__builtin_inff();
     int bk = 0x7fffffff;
     if (row < rows) {
-        const float4 v = *reinterpret_cast<const float4*>(z + (row * L + sub) * 4);
+        float4 v = *reinterpret_cast<const float4*>(z + (row * L + sub) * 4);
+        if (coef) {
+            const int ch = (int)((row / M) % C);
+            const float s0 = coef[ch], s1 = coef[C + ch];
+            v.x = __builtin_fmaf(v.x, s0, s1); v.y = __builtin_fmaf(v.y, s0, s1);
+            v.z = __builtin_fmaf(v.z, s0, s1); v.w = __builtin_fmaf(v.w, s0, s1);
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        }
         best = v.x; bk = sub * 4;
         if (v.y > best) { best = v.y; bk = sub * 4 + 1; }
         if (v.z > best) { best = v.z; bk = sub * 4 + 2; }
@@ -192,6 +202,28 @@ extern "C" int usip_group_gather_backward_f32(const float* dout, const int32_t* 
     return USIP_OK;
 }
 
+extern "C" int usip_group_max_act_f32(const float* y, const float* coef, int relu, float* pooled, int32_t* arg,
+                                      int B, int C, int M, int K, void* stream)
+{
+    const long long rows = (long long)B * C * M;
+    const int L4 = K / 4;
+    if (B < 0 || C < 1 || M < 0 || K < 4 || K % 4 != 0 || (L4 & (L4 - 1)) != 0 || L4 > 64) return USIP_EINVAL;
+    if (rows == 0) return USIP_OK;
+    if (!y || !coef || !pooled || !arg || (reinterpret_cast<uintptr_t>(y) & 15u)) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define USIP_GM4(L_)                                                                             \
+    if (L4 == L_) {                                                                              \
+        const long long blocks = (rows + (256 / L_) - 1) / (256 / L_);                           \
+        if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                           \
+        USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, y, pooled, arg, rows, \
+                    coef, relu, C, M);                                                           \
+    }
+    USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
+#undef USIP_GM4
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
 extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, long long rows, int K,
                                   void* stream)
 {
@@ -205,7 +237,8 @@ extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, l
         if (L4 == L_) {                                                                          \
             const long long blocks = (rows + (256 / L_) - 1) / (256 / L_);                       \
             if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                       \
-            USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows); \
+            USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows, \
+                        (const float*)nullptr, 0, 1, 1);                                         \
         }
         USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
 #undef USIP_GM4

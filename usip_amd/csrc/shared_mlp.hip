@@ -296,6 +296,7 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
 struct WgradArgs {
     const float* G;  const float* G2; const float* coef;   // [nb][M][P] (+ Y and [4][M] for PRO_BN_BWD)
     const float* X;                                         // [nb][N][P]
+    const float* xcoef;                                     // [2][N] or null: X := relu(X*xcoef[0][n] + xcoef[1][n])
     float* part;                                            // [slices][M][N]
     int M, N, P, nb, seglen, segs;                          // segs position segments per cloud
 };
@@ -330,7 +331,7 @@ __device__ __forceinline__ void wgrad_load_rows(const float* __restrict__ base, 
     }
 }
 
-template <int TM, int TN, int PRO, bool VEC>
+template <int TM, int TN, int PRO, bool XPRO, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 {
     // 2 x 2 waves, each TM x TN MFMA tiles of 32 x 32: block tile 128 x 128 (TM = TN = 2) or 64 x 64
@@ -392,6 +393,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
         for (int i = 0; i < NX4; ++i) {
             const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
             float4 v = rx[i];
+            if (XPRO) {
+                const int ch = min(n0 + row, a.N - 1);
+                const float s0 = a.xcoef[ch], s1 = a.xcoef[a.N + ch];
+                v.x = fmaxf(__builtin_fmaf(v.x, s0, s1), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, s0, s1), 0.f);
+                v.z = fmaxf(__builtin_fmaf(v.z, s0, s1), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, s0, s1), 0.f);
+                if (!VEC) {                                  // scalar path zero-filled invalid lanes before the affine
+                    if (!(n0 + row < a.N && p + kq + 0 < pend)) v.x = 0.f;
+                    if (!(n0 + row < a.N && p + kq + 1 < pend)) v.y = 0.f;
+                    if (!(n0 + row < a.N && p + kq + 2 < pend)) v.z = 0.f;
+                    if (!(n0 + row < a.N && p + kq + 3 < pend)) v.w = 0.f;
+                }
+            }
             if (VEC && !(n0 + row < a.N && p + kq < pend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             Xs[buf][kq][row] = v.x; Xs[buf][kq + 1][row] = v.y;
             Xs[buf][kq + 2][row] = v.z; Xs[buf][kq + 3][row] = v.w;
@@ -739,8 +752,8 @@ extern "C" int usip_mlp_wgrad_blocks(int M, int N, int P, int nb)
 }
 
 extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro,
-                                  const float* X, float* workspace, float* dW, int ldw, int coloff,
-                                  int M, int N, int P, int nb, void* stream)
+                                  const float* X, const float* xcoef, float* workspace, float* dW, int ldw,
+                                  int coloff, int M, int N, int P, int nb, void* stream)
 {
     if (M < 1 || N < 1 || P < 1 || nb < 1 || ldw < N + coloff || coloff < 0) return USIP_EINVAL;
     if (!dW) return USIP_EINVAL;
@@ -749,26 +762,27 @@ extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* 
     if (pro == PRO_BN_BWD && (!G2 || !coef)) return USIP_EINVAL;
     int seglen, segs, small, tiles;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
-    WgradArgs a{G, G2, coef, X, workspace, M, N, P, nb, seglen, segs};
+    WgradArgs a{G, G2, coef, X, xcoef, workspace, M, N, P, nb, seglen, segs};
+    const bool xpro = xcoef != nullptr;
     const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
                      ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
                      (pro != PRO_BN_BWD || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
     const long long blocks = (long long)tiles * nb * segs;
     if (blocks > 0x7fffffffLL) return USIP_EINVAL;
     dim3 grid((unsigned)blocks), block(256);
-#define USIP_WGRAD_CASE(T_, P_, V_)                                                            \
-    if (small == (T_ == 1) && pro == P_ && vec == V_) {                                        \
-        USIP_LAUNCH((wgrad_kernel<T_, T_, P_, V_>), grid, block, 0, st, a);                    \
+#define USIP_WGRAD_CASE(T_, P_, X_, V_)                                                        \
+    if (small == (T_ == 1) && pro == P_ && xpro == X_ && vec == V_) {                          \
+        USIP_LAUNCH((wgrad_kernel<T_, T_, P_, X_, V_>), grid, block, 0, st, a);                \
         USIP_LAUNCH_CHECK();                                                                   \
     }
-    USIP_WGRAD_CASE(1, PRO_NONE, true)
-    USIP_WGRAD_CASE(1, PRO_NONE, false)
-    USIP_WGRAD_CASE(1, PRO_BN_BWD, true)
-    USIP_WGRAD_CASE(1, PRO_BN_BWD, false)
-    USIP_WGRAD_CASE(2, PRO_NONE, true)
-    USIP_WGRAD_CASE(2, PRO_NONE, false)
-    USIP_WGRAD_CASE(2, PRO_BN_BWD, true)
-    USIP_WGRAD_CASE(2, PRO_BN_BWD, false)
+#define USIP_WGRAD_CASES(T_, P_) \
+    USIP_WGRAD_CASE(T_, P_, false, true) USIP_WGRAD_CASE(T_, P_, false, false) \
+    USIP_WGRAD_CASE(T_, P_, true, true) USIP_WGRAD_CASE(T_, P_, true, false)
+    USIP_WGRAD_CASES(1, PRO_NONE)
+    USIP_WGRAD_CASES(1, PRO_BN_BWD)
+    USIP_WGRAD_CASES(2, PRO_NONE)
+    USIP_WGRAD_CASES(2, PRO_BN_BWD)
+#undef USIP_WGRAD_CASES
 #undef USIP_WGRAD_CASE
     const long long elems = (long long)M * N;
     USIP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st,

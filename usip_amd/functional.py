@@ -73,12 +73,41 @@ def gather_neighbours(x: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- shared MLP layer
+class LazyAct:
+    """Output of a shared-MLP layer kept as (pre-BatchNorm GEMM output y, BN coefficients coef[2,C]):
+    the activation relu(y*coef[0]+coef[1]) is formed by whoever consumes it -- the next layer's GEMM and
+    weight-gradient prologues, or the fused BN+ReLU+max pooling -- so the activated tensor is never written
+    to or read back from HBM.  `y` is the autograd-tracked tensor and STANDS FOR the activated output:
+    gradients flowing into it are gradients w.r.t. the activated output."""
+
+    def __init__(self, y: torch.Tensor, coef: torch.Tensor, relu: bool, shape):
+        self.y, self.coef, self.relu, self.shape = y, coef, relu, tuple(shape)
+
+    def materialize(self) -> torch.Tensor:
+        return _Materialize.apply(self.y, self.coef, self.relu).view(self.shape)
+
+
+class _Materialize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, coef, relu):
+        return ops.bn_apply(y, coef, relu)
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz, None, None            # y stands for the activated output already
+
+
+def as_tensor(x):
+    return x.materialize() if isinstance(x, LazyAct) else x
+
+
 class _SharedMLPLayer(torch.autograd.Function):
     """1x1 convolution (+bias) -> BatchNorm (batch statistics) -> ReLU as ONE autograd node on the
     HIP kernels of csrc/shared_mlp.hip (models/layers.py:208-216, :293-303 + autograd's backward).
 
-      forward : GEMM (+bias, + per-channel sum/sum^2 partials in its epilogue) -> statistics
-                finalise (+ running stats) -> BN+ReLU apply
+      forward : GEMM (+bias, + per-channel sum/sum^2 partials in its epilogue; the input may be a
+                LazyAct, activated in the GEMM's prologue) -> statistics finalise (+ running stats)
+                -> BN+ReLU apply, or nothing when the output is handed on as a LazyAct
       backward: one reduction pass (dgamma, dbeta) -> data-gradient GEMM and weight-gradient GEMM
                 that both rebuild dY = BN'(ReLU'(dZ)) from (dZ, Y) in their prologue; dY is never
                 written to memory.
@@ -87,51 +116,56 @@ class _SharedMLPLayer(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, xcoef, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
+                relu, defer):
         x = x.contiguous()
         wt = w2.detach().t().contiguous()                      # K-major matrix operand [Cin][Cout]
         nb, _, P = x.shape
         ctx.has_bn = gamma is not None
         ctx.relu = bool(relu)
         ctx.train_stats = bool(training)
+        pro = 0 if xcoef is None else 1
         if not ctx.has_bn:
             if relu:
                 raise NotImplementedError("usip_amd: ReLU without BatchNorm is outside the detector path")
-            y, _ = ops.mlp_gemm(wt, x, bias)
-            ctx.save_for_backward(x, w2)
-            return y
+            y, _ = ops.mlp_gemm(wt, x, bias, pro=pro, coef=xcoef)
+            ctx.save_for_backward(x, xcoef, w2)
+            return y, None
         if training:
-            y, stats = ops.mlp_gemm(wt, x, bias, want_stats=True)
+            y, stats = ops.mlp_gemm(wt, x, bias, want_stats=True, pro=pro, coef=xcoef)
             mean, invstd, coef = ops.bn_finalize(stats, nb * P, gamma, beta, eps, momentum,
                                                  running_mean, running_var)
         else:
-            y, _ = ops.mlp_gemm(wt, x, bias)
+            y, _ = ops.mlp_gemm(wt, x, bias, pro=pro, coef=xcoef)
             invstd = torch.rsqrt(running_var + eps)
             mean = running_mean
             scale = gamma * invstd
             coef = torch.stack((scale, beta - running_mean * scale)).contiguous()
-        z = ops.bn_apply(y, coef, relu)
-        ctx.save_for_backward(x, w2, y, coef, mean, invstd, gamma)
-        return z
+        ctx.save_for_backward(x, xcoef, w2, y, coef, mean, invstd, gamma)
+        if defer:
+            ctx.mark_non_differentiable(coef)
+            return y, coef
+        return ops.bn_apply(y, coef, relu), None
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, _dcoef):
         dz = dz.contiguous()
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        tail = (None,) * 8
         if not ctx.has_bn:
-            x, w2 = ctx.saved_tensors
+            x, xcoef, w2 = ctx.saved_tensors
             dx = ops.mlp_gemm(w2.contiguous(), dz, tag="dgrad")[0] if need_x else None
-            dw = ops.mlp_wgrad(dz, x) if need_w else None
-            db = ops.bn_backward_reduce(dz, None, None, None, None, None, False)[1] if ctx.needs_input_grad[2] else None
-            return dx, dw, db, None, None, None, None, None, None, None, None
+            dw = ops.mlp_wgrad(dz, x, xcoef=xcoef) if need_w else None
+            db = ops.bn_backward_reduce(dz, None, None, None, None, None, False)[1] if ctx.needs_input_grad[3] else None
+            return (dx, None, dw, db, None, None) + tail[:7]
         if not ctx.train_stats:
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
-        x, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
+        x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         dgamma, dbeta, coef4, _ = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu)
         dx = ops.mlp_gemm(w2.contiguous(), dz, pro=2, X2=y, coef=coef4, tag="dgrad")[0] if need_x else None
-        dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4) if need_w else None
-        db = torch.zeros_like(gamma) if ctx.needs_input_grad[2] else None
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+        dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef) if need_w else None
+        db = torch.zeros_like(gamma) if ctx.needs_input_grad[3] else None
+        return (dx, None, dw, db, dgamma, dbeta) + tail[:7]
 
 
 def _group_sums_supported(K: int) -> bool:
@@ -152,9 +186,9 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
     the reference up to fp32 summation order; half the multiply-adds of that layer."""
 
     @staticmethod
-    def forward(ctx, h, pooled, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-                relu, pooled_first):
-        B, Ch, M, K = h.shape
+    def forward(ctx, h, hcoef, dims, pooled, w2, bias, gamma, beta, running_mean, running_var, training, momentum,
+                eps, relu, pooled_first, defer):
+        B, Ch, M, K = dims
         Cp = pooled.shape[1]
         Cout = w2.shape[0]
         poff, hoff = (0, Cp) if pooled_first else (Ch, 0)
@@ -162,18 +196,22 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         pooled = pooled.contiguous()
         wt = w2.detach().t().contiguous()                                   # [Ctot][Cout]
         r, _ = ops.mlp_gemm(wt[poff:poff + Cp], pooled, tag="fwd_pooled")   # [B,Cout,M]
-        y, stats = ops.mlp_gemm(wt[hoff:hoff + Ch], h3, bias, want_stats=True, rowbias=r, rb_group=K)
+        y, stats = ops.mlp_gemm(wt[hoff:hoff + Ch], h3, bias, want_stats=True, rowbias=r, rb_group=K,
+                                pro=0 if hcoef is None else 1, coef=hcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum,
                                              running_mean, running_var)
-        z = ops.bn_apply(y, coef, relu)
-        ctx.save_for_backward(h3, pooled, w2, y, coef, mean, invstd, gamma)
+        ctx.save_for_backward(h3, hcoef, pooled, w2, y, coef, mean, invstd, gamma)
         ctx.dims = (B, Ch, Cp, Cout, M, K, poff, hoff)
+        ctx.h_shape = tuple(h.shape)
         ctx.relu = bool(relu)
-        return z.view(B, Cout, M, K)
+        if defer:
+            ctx.mark_non_differentiable(coef)
+            return y, coef
+        return ops.bn_apply(y, coef, relu), None
 
     @staticmethod
-    def backward(ctx, dz):
-        h3, pooled, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
+    def backward(ctx, dz, _dcoef):
+        h3, hcoef, pooled, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         B, Ch, Cp, Cout, M, K, poff, hoff = ctx.dims
         dz = dz.contiguous().view(B, Cout, M * K)
         dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu, group=K)
@@ -182,35 +220,75 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
                + float(K) * coef4[3].view(1, -1, 1)).contiguous()
         w2c = w2.contiguous()
         dpooled = dh = dw = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[3]:
             dpooled = ops.mlp_gemm(w2c, sdy, tag="dgrad_pooled", M=Cp, a_offset=poff)[0]
         if ctx.needs_input_grad[0]:
             dh = ops.mlp_gemm(w2c, dz, pro=2, X2=y, coef=coef4, tag="dgrad", M=Ch, a_offset=hoff)[0]
-            dh = dh.view(B, Ch, M, K)
-        if ctx.needs_input_grad[2]:
+            dh = dh.view(ctx.h_shape)
+        if ctx.needs_input_grad[4]:
             dw = torch.empty_like(w2c)
-            ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff)
+            ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff, xcoef=hcoef)
             ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
-        db = torch.zeros_like(gamma) if ctx.needs_input_grad[3] else None
-        return dh, dpooled, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+        db = torch.zeros_like(gamma) if ctx.needs_input_grad[5] else None
+        return (dh, None, None, dpooled, dw, db, dgamma, dbeta) + (None,) * 8
 
 
-def conv1x1_bn_act_pooled(h: torch.Tensor, pooled: torch.Tensor, weight: torch.Tensor,
-                          bias: Optional[torch.Tensor], bn, relu: bool, pooled_first: bool) -> torch.Tensor:
+def conv1x1_bn_act_pooled(h, pooled: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], bn,
+                          relu: bool, pooled_first: bool, defer: bool = False):
     """conv1x1_bn_act(cat((expand(pooled), h) if pooled_first else (h, expand(pooled)), dim=1)) without the
-    concatenated tensor.  h [B,Ch,M,K], pooled [B,Cp,M]."""
-    require_device(h, "the shared MLP")
-    K = h.shape[3]
+    concatenated tensor.  h [B,Ch,M,K] (tensor or LazyAct), pooled [B,Cp,M].  defer=True returns a LazyAct."""
+    hshape = h.shape
+    K = hshape[3]
     fused = (bn is not None and bn.training and bias is not None and _group_sums_supported(K)
              and torch.is_grad_enabled())
     if not fused:
+        ht = as_tensor(h)
         e = pooled.unsqueeze(3).expand(-1, -1, -1, K)
-        return conv1x1_bn_act(torch.cat((e, h) if pooled_first else (h, e), dim=1), weight, bias, bn, relu)
+        return conv1x1_bn_act(torch.cat((e, ht) if pooled_first else (ht, e), dim=1), weight, bias, bn, relu,
+                              defer=defer)
+    hcoef = None
+    if isinstance(h, LazyAct):
+        if not h.relu:
+            h = h.materialize()
+        else:
+            h, hcoef = h.y, h.coef
+    require_device(h, "the shared MLP")
     w2 = weight.reshape(weight.shape[0], weight.shape[1])
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _SharedMLPLayerPooled.apply(h, pooled, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       True, bn.momentum, bn.eps, relu, pooled_first)
+    out, coef = _SharedMLPLayerPooled.apply(h, hcoef, tuple(hshape), pooled, w2, bias, bn.weight, bn.bias,
+                                            bn.running_mean, bn.running_var, True, bn.momentum, bn.eps, relu,
+                                            pooled_first, defer)
+    oshape = (hshape[0], w2.shape[0], hshape[2], K)
+    return LazyAct(out, coef, relu, oshape) if defer else out.view(oshape)
+
+
+def conv1x1_bn_act(x, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                   bn: Optional[torch.nn.modules.batchnorm._BatchNorm], relu: bool, defer: bool = False):
+    """One shared-MLP layer: 1x1 convolution (+bias) -> BatchNorm (batch statistics when the
+    module is in training mode) -> ReLU  (models/layers.py:208-216, :293-303).
+    x [B,Cin,*positions] (tensor or LazyAct), weight [Cout,Cin,1(,1)] -> [B,Cout,*positions];
+    defer=True (BatchNorm layers only) returns a LazyAct instead of the activated tensor."""
+    shape = x.shape
+    xcoef = None
+    if isinstance(x, LazyAct):
+        if not x.relu:
+            x = x.materialize()
+        else:
+            x, xcoef = x.y, x.coef
+    require_device(x, "the shared MLP")
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    x3 = x.reshape(shape[0], shape[1], -1)
+    oshape = (shape[0], w2.shape[0]) + tuple(shape[2:])
+    if bn is None:
+        y, _ = _SharedMLPLayer.apply(x3, xcoef, w2, bias, None, None, None, None, False, 0.0, 0.0, relu, False)
+        return y.view(oshape)
+    training = bn.training or bn.running_mean is None
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    y, coef = _SharedMLPLayer.apply(x3, xcoef, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    training, bn.momentum, bn.eps, relu, defer)
+    return LazyAct(y, coef, relu, oshape) if defer else y.view(oshape)
 
 
 # --------------------------------------------------------------------------- grouping / pooling
@@ -231,8 +309,29 @@ class _GroupMax(torch.autograd.Function):
         return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K)
 
 
-def group_max(z: torch.Tensor) -> torch.Tensor:
-    """z [B,C,M,K] -> [B,C,M]."""
+class _GroupMaxAct(torch.autograd.Function):
+    """BN-apply + ReLU + max over K in one pass over the producing layer's pre-BN output."""
+
+    @staticmethod
+    def forward(ctx, y4, coef, relu):
+        pooled, arg = ops.group_max_act(y4.contiguous(), coef, relu)
+        ctx.save_for_backward(arg)
+        ctx.K = y4.shape[3]
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        (arg,) = ctx.saved_tensors
+        return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K), None, None
+
+
+def group_max(z) -> torch.Tensor:
+    """z [B,C,M,K] (tensor or LazyAct) -> [B,C,M]."""
+    if isinstance(z, LazyAct):
+        K = z.shape[3]
+        if _group_sums_supported(K):
+            return _GroupMaxAct.apply(z.y.view(z.shape), z.coef, z.relu)
+        z = z.materialize()
     require_device(z, "group_max")
     return _GroupMax.apply(z)
 
@@ -262,23 +361,3 @@ class _KnnGroup(torch.autograd.Function):
 def knn_group(feat, database, query, idx32):
     require_device(feat, "knn_group")
     return _KnnGroup.apply(feat, database, query, idx32)
-
-
-def conv1x1_bn_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                   bn: Optional[torch.nn.modules.batchnorm._BatchNorm], relu: bool) -> torch.Tensor:
-    """One shared-MLP layer: 1x1 convolution (+bias) -> BatchNorm (batch statistics when the
-    module is in training mode) -> ReLU  (models/layers.py:208-216, :293-303).
-    x [B,Cin,*positions], weight [Cout,Cin,1(,1)] -> [B,Cout,*positions]."""
-    require_device(x, "the shared MLP")
-    shape = x.shape
-    w2 = weight.reshape(weight.shape[0], weight.shape[1])
-    x3 = x.reshape(shape[0], shape[1], -1)
-    if bn is None:
-        y = _SharedMLPLayer.apply(x3, w2, bias, None, None, None, None, False, 0.0, 0.0, relu)
-    else:
-        training = bn.training or bn.running_mean is None
-        if bn.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        y = _SharedMLPLayer.apply(x3, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  training, bn.momentum, bn.eps, relu)
-    return y.view(shape[0], w2.shape[0], *shape[2:])

@@ -92,11 +92,13 @@ class MyConv2d(nn.Module):
             self.act = nn.ReLU()
         _init_conv(self.conv, in_channels)
 
-    def forward(self, x, epoch=None):
+    def forward(self, x, epoch=None, defer=False):
+        """defer=True (internal use by the fused networks): return a functional.LazyAct."""
         bn = getattr(self, "norm", None)
         if bn is not None:
             bn.decay_momentum(epoch)
-        return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu")
+        return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu",
+                                 defer=defer and bn is not None and self.activation == "relu")
 
 
 class EquivariantLayer(nn.Module):
@@ -119,11 +121,12 @@ class EquivariantLayer(nn.Module):
             self.act = nn.ReLU()
         _init_conv(self.conv, num_in_channels)
 
-    def forward(self, x, epoch=None):
+    def forward(self, x, epoch=None, defer=False):
         bn = getattr(self, "norm", None)
         if bn is not None:
             bn.decay_momentum(epoch)
-        return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu")
+        return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu",
+                                 defer=defer and bn is not None and self.activation == "relu")
 
 
 class PointNet(nn.Module):
@@ -147,9 +150,10 @@ class PointNet(nn.Module):
             self.layers[last].conv.bias.data.uniform_(-output_init_radius, output_init_radius)
 
     def forward(self, x, epoch=None):
+        # activations between layers stay lazy (BN+ReLU applied in the next GEMM's prologue)
         for layer in self.layers:
-            x = layer(x, epoch)
-        return x
+            x = layer(x, epoch, defer=True)
+        return Fh.as_tensor(x)
 
 
 class GeneralKNNFusionModule(nn.Module):
@@ -179,14 +183,14 @@ class GeneralKNNFusionModule(nn.Module):
         self.last_knn_I = knn_I
         h = Fh.knn_group(x, database.detach(), query.detach(), knn_I)    # :422-430
         for layer in self.layers_before:
-            h = layer(h, epoch)
-        pooled = Fh.group_max(h)                                         # :433
+            h = layer(h, epoch, defer=True)
+        pooled = Fh.group_max(h)                                         # :433 (BN+ReLU+max in one pass)
         first, rest = self.layers_after[0], list(self.layers_after)[1:]
         bn = getattr(first, "norm", None)
         if bn is not None:
             bn.decay_momentum(epoch)
         y = Fh.conv1x1_bn_act_pooled(h, pooled, first.conv.weight, first.conv.bias, bn,
-                                     first.activation == "relu", pooled_first=True)   # :435
+                                     first.activation == "relu", pooled_first=True, defer=True)   # :435
         for layer in rest:
-            y = layer(y, epoch)
+            y = layer(y, epoch, defer=True)
         return Fh.group_max(y)                                           # :438

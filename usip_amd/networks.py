@@ -42,7 +42,7 @@ class _DetectorTail(nn.Module):
         knn_feature = self.knnlayer_1(query=centre, database=centre, x=node_feature,
                                       K=self.opt.node_knn_k_1, epoch=epoch)
         agg = torch.cat((node_feature, knn_feature), dim=1)
-        y = self.mlp2(self.mlp1(agg))                                    # no epoch: networks.py:147-148
+        y = self.mlp2(self.mlp1(agg, defer=True), defer=True)            # no epoch: networks.py:147-148
         ks = self.mlp3(y)
         keypoints = ks[:, 0:3, :] + centre
         sigmas = self.softplus(ks[:, 3, :]) + self.opt.loss_sigma_lower_bound
@@ -118,12 +118,13 @@ class RPN_Detector_Ball(_DetectorTail):
         x_aug = torch.cat((x, sn), dim=1)
         ball_idx32 = ops.ball_query_coords(node, x, self.ball_radius, self.ball_k)        # :694-698 fused
         g = ops.group_gather(x_aug, ball_idx32, sub=node)                 # gather + decenter :699-703
-        h = self.conv3(self.conv2(self.conv1(g)))                         # no epoch: networks.py:705
+        # activations stay lazy between the layers: BN+ReLU is applied by the consumer's prologue
+        h = self.conv3(self.conv2(self.conv1(g, defer=True), defer=True), defer=True)   # no epoch: networks.py:705
         pooled = Fh.group_max(h)                                          # :706
         h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
                                      getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
-                                     pooled_first=False)                  # cat(h, expand(max)) :708-709
-        h = self.conv5(h)
+                                     pooled_first=False, defer=True)      # cat(h, expand(max)) :708-709
+        h = self.conv5(h, defer=True)
         second_max = Fh.group_max(h)                                      # :710
         ball_idx = ball_idx32.long()
         keypoints, sigmas = self._tail(node, second_max, epoch)

@@ -232,7 +232,7 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
     return dgamma, dbeta, coef4, gsum
 
 
-def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0):
+def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0, xcoef=None):
     """dW [M,N] = sum_{b,p} pro(G)[b,m,p] * X[b,n,p]; G [nb,M,P], X [nb,N,P].
     With `out` ([M, ldw] contiguous) the result is written into columns [coloff, coloff+N) of it."""
     nb, M, P = G.shape
@@ -244,13 +244,14 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     ldw = dW.shape[1]
     def _key():
         t = 1 if (M <= 64 and N <= 64) else 2
-        return "wgrad_kernel<%d, %d, %d, %s> |wg=%d" % (t, t, pro, "true" if P % 4 == 0 else "false",
-                                                       _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
+        return "wgrad_kernel<%d, %d, %d, %s, %s> |wg=%d" % (t, t, pro, "true" if xcoef is not None else "false",
+                                                           "true" if P % 4 == 0 else "false",
+                                                           _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
 
     with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
                                              4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
                                              rocprof_key=_key):
-        _lib.check(_lib.lib().usip_mlp_wgrad_f32(_ptr(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _ptr(ws), _ptr(dW),
+        _lib.check(_lib.lib().usip_mlp_wgrad_f32(_ptr(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _opt(xcoef), _ptr(ws), _ptr(dW),
                                                  int(ldw), int(coloff), M, N, P, nb, _stream(G)), "usip_mlp_wgrad_f32")
     return dW
 
@@ -293,6 +294,18 @@ def group_max(z):
     with torch.cuda.device(z.device), prof.kernel("group_max", 4.0 * B * C * M * (K + 2)):
         _lib.check(_lib.lib().usip_group_max_f32(_ptr(z), _ptr(pooled), _ptr(arg), B * C * M, K, _stream(z)),
                    "usip_group_max_f32")
+    return pooled, arg
+
+
+def group_max_act(y4, coef, relu: bool):
+    """max_k relu?(y*coef[0]+coef[1]) straight from a layer's pre-BN output y4 [B,C,M,K] -> (pooled, arg)."""
+    _need(y4, "y", torch.float32)
+    B, C, M, K = y4.shape
+    pooled = torch.empty((B, C, M), dtype=torch.float32, device=y4.device)
+    arg = torch.empty((B, C, M), dtype=torch.int32, device=y4.device)
+    with torch.cuda.device(y4.device), prof.kernel("group_max", 4.0 * B * C * M * (K + 2)):
+        _lib.check(_lib.lib().usip_group_max_act_f32(_ptr(y4), _ptr(coef), int(bool(relu)), _ptr(pooled), _ptr(arg),
+                                                     B, C, M, K, _stream(y4)), "usip_group_max_act_f32")
     return pooled, arg
 
 
