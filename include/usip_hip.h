@@ -88,9 +88,12 @@ int usip_som_cluster_f32(const float* x, const int32_t* min_idx, float* cluster_
  * min_d[b,i] = min_j |a[b,:,i] - b[b,:,j]|_2 and arg[b,i] = FIRST j attaining it, exactly what
  * torch.min(torch.norm(a.unsqueeze(3) - b.unsqueeze(2), dim=1), dim=2) returns
  * (models/losses.py:62-66, :81, :86, :135-143) without materialising the B x Ma x Nb matrix.
- * a f32 [B,3,Ma], b f32 [B,3,Nb] -> min_d f32 [B,Ma], arg i32 [B,Ma]. */
+ * a f32 [B,3,Ma], b f32 [B,3,Nb] -> min_d f32 [B,Ma], arg i32 [B,Ma].  With few queries and many candidates
+ * the candidate set is split over workgroups; ws_d / ws_j hold the per-chunk results
+ * (usip_nearest_workspace elements each; NULL = single-chunk kernel). */
+long long usip_nearest_workspace(int B, int Ma, int Nb);   /* elements of ws_d AND of ws_j (0: none needed) */
 int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
-                     int B, int Ma, int Nb, void* stream);
+                     float* ws_d, int32_t* ws_j, int B, int Ma, int Nb, void* stream);
 
 /* ------------------------------------------------------------------ a-5 / a-6 / a-7 / a-8  shared MLP
  * Replaces, per layer, nn.Conv1d/Conv2d(k=1) + MyBatchNorm + ReLU and their autograd backward

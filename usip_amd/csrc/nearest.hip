@@ -17,15 +17,21 @@ namespace {
 
 constexpr int R = 4;                 // query points per wave
 
+// The candidate set is split into gridDim.z contiguous chunks (more workgroups when there are few queries
+// and many candidates); chunk z writes its (distance, index) to slot z, nearest_merge_kernel takes the
+// minimum over chunks, lower chunk (= lower index) first on equal distances.
 __global__ __launch_bounds__(256) void nearest_kernel(
     const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ min_d,
-    int32_t* __restrict__ arg, int Ma, int Nb)
+    int32_t* __restrict__ arg, int Ma, int Nb, int chunk, long long slot_stride)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bi = blockIdx.y;
     const int i0 = (blockIdx.x * 4 + wave) * R;
     if (i0 >= Ma) return;
+    const int jbeg = blockIdx.z * chunk, jend = min(Nb, jbeg + chunk);
+    min_d += (long long)blockIdx.z * slot_stride;
+    arg += (long long)blockIdx.z * slot_stride;
     const float* ab = a + (long long)bi * 3 * Ma;
     const float* bb = b + (long long)bi * 3 * Nb;
     float ax[R], ay[R], az[R], best_s[R], best_d[R];
@@ -36,7 +42,7 @@ __global__ __launch_bounds__(256) void nearest_kernel(
         ax[r] = ab[i]; ay[r] = ab[Ma + i]; az[r] = ab[2 * Ma + i];
         best_s[r] = __builtin_inff(); best_d[r] = __builtin_inff(); best_j[r] = 0x7fffffff;
     }
-    for (int j = lane; j < Nb; j += 64) {
+    for (int j = jbeg + lane; j < jend; j += 64) {
         const float bx = bb[j], by = bb[Nb + j], bz = bb[2 * Nb + j];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -67,16 +73,55 @@ __global__ __launch_bounds__(256) void nearest_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void nearest_merge_kernel(
+    const float* __restrict__ pd, const int32_t* __restrict__ pj, float* __restrict__ min_d,
+    int32_t* __restrict__ arg, long long n, int chunks)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float d = pd[i];
+    int j = pj[i];
+    for (int c = 1; c < chunks; ++c) {
+        const float od = pd[(long long)c * n + i];
+        if (od < d) { d = od; j = pj[(long long)c * n + i]; }      // strict: the lower chunk keeps ties
+    }
+    min_d[i] = d;
+    arg[i] = j;
+}
+
 }  // namespace
 
+extern "C" long long usip_nearest_workspace(int B, int Ma, int Nb)
+{
+    // floats AND ints: chunks * B * Ma of each (0 when one chunk suffices)
+    const long long groups = (long long)B * ((Ma + 4 * R - 1) / (4 * R));
+    int chunks = 1;
+    while (groups * chunks < 1024 && Nb / (chunks * 2) >= 1024) chunks *= 2;
+    return chunks > 1 ? (long long)chunks * B * Ma : 0;
+}
+
 extern "C" int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
-                                int B, int Ma, int Nb, void* stream)
+                                float* ws_d, int32_t* ws_j, int B, int Ma, int Nb, void* stream)
 {
     if (B < 0 || Ma < 0 || Nb < 1) return USIP_EINVAL;
     if ((long long)B * Ma == 0) return USIP_OK;
     if (!a || !b || !min_d || !arg || B > 65535) return USIP_EINVAL;
-    dim3 grid(usip_ceil_div(Ma, 4 * R), B), block(256);
-    USIP_LAUNCH(nearest_kernel, grid, block, 0, (hipStream_t)stream, a, b, min_d, arg, Ma, Nb);
+    const long long n = (long long)B * Ma;
+    const long long ws = usip_nearest_workspace(B, Ma, Nb);
+    hipStream_t st = (hipStream_t)stream;
+    if (ws == 0 || !ws_d || !ws_j) {
+        dim3 grid(usip_ceil_div(Ma, 4 * R), B, 1), block(256);
+        USIP_LAUNCH(nearest_kernel, grid, block, 0, st, a, b, min_d, arg, Ma, Nb, Nb, 0LL);
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
+    }
+    const int chunks = (int)(ws / n);
+    const int chunk = ((Nb + chunks - 1) / chunks + 63) / 64 * 64;
+    dim3 grid(usip_ceil_div(Ma, 4 * R), B, chunks), block(256);
+    USIP_LAUNCH(nearest_kernel, grid, block, 0, st, a, b, ws_d, ws_j, Ma, Nb, chunk, n);
+    USIP_LAUNCH_CHECK();
+    USIP_LAUNCH(nearest_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws_d, ws_j, min_d, arg, n,
+                chunks);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -680,17 +680,6 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
 }  // namespace
 
 // ================================================================================================
-// K-step of the GEMM pipeline: 16 by default (measured faster: 2x the workgroups per CU), USIP_GEMM_BK=32 selects the deeper stage.
-static int usip_gemm_bk()
-{
-    static int bk = 0;
-    if (!bk) {
-        const char* e = getenv("USIP_GEMM_BK");
-        bk = (e && atoi(e) == 32) ? 32 : 16;
-    }
-    return bk;
-}
-
 extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 {
     const int BN = (M <= 64) ? 256 : 128;
@@ -712,9 +701,8 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
     if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, ablate};
     hipStream_t st = (hipStream_t)stream;
-    const int bk = usip_gemm_bk();
-    if (M <= 64) return bk == 32 ? launch_gemm<1, 4, 32>(a, pro, st) : launch_gemm<1, 4, 16>(a, pro, st);
-    return bk == 32 ? launch_gemm<2, 2, 32>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
+    // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
+    return (M <= 64) ? launch_gemm<1, 4, 16>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
 }
 
 // Workspace (floats) the weight-gradient needs, and the slicing it will use.

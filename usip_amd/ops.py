@@ -137,9 +137,12 @@ def nearest(a: torch.Tensor, b: torch.Tensor):
     Nb = b.shape[2]
     d = torch.empty((B, Ma), dtype=torch.float32, device=a.device)
     arg = torch.empty((B, Ma), dtype=torch.int32, device=a.device)
+    ws = int(_lib.lib().usip_nearest_workspace(B, Ma, Nb))
+    ws_d = torch.empty(ws, dtype=torch.float32, device=a.device) if ws else None
+    ws_j = torch.empty(ws, dtype=torch.int32, device=a.device) if ws else None
     with torch.cuda.device(a.device), prof.kernel("nearest", 4.0 * (3 * B * (Ma + Nb) + 2 * B * Ma), 8.0 * B * Ma * Nb):
-        _lib.check(_lib.lib().usip_nearest_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg), B, Ma, Nb, _stream(a)),
-                   "usip_nearest_f32")
+        _lib.check(_lib.lib().usip_nearest_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg), _opt(ws_d), _opt(ws_j),
+                                               B, Ma, Nb, _stream(a)), "usip_nearest_f32")
     return d, arg
 
 
