@@ -12,6 +12,25 @@ import torch.nn.functional as F
 from . import ops, prof
 
 
+# Gradient sink (opt-in, used by usip_amd.step.DetectorStep): when enabled, the shared-MLP backward writes
+# parameter gradients STRAIGHT into the parameters' .grad storage (views of the flat all-reduce bucket)
+# instead of returning them to autograd, which would launch one accumulate kernel per parameter.  Valid
+# when every parameter is used once per step and .grad was zeroed before the backward -- DetectorStep does both.
+GRAD_SINK = False
+
+
+def _sink(*params):
+    if not GRAD_SINK:
+        return None
+    out = []
+    for p in params:
+        g = getattr(p, "grad", None) if p is not None else None
+        if p is not None and (g is None or not g.is_contiguous()):
+            return None
+        out.append(g)
+    return tuple(out)
+
+
 def require_device(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise RuntimeError("usip_amd: %s needs device tensors; the HIP path has no CPU fallback" % what)
@@ -117,7 +136,8 @@ class _SharedMLPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, xcoef, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-                relu, defer):
+                relu, defer, sink):
+        ctx.sink = sink
         x = x.contiguous()
         wt = w2.detach().t().contiguous()                      # K-major matrix operand [Cin][Cout]
         nb, _, P = x.shape
@@ -152,20 +172,34 @@ class _SharedMLPLayer(torch.autograd.Function):
         dz = dz.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
         tail = (None,) * 8
+        sink = ctx.sink                      # (w.grad, b.grad[, gamma.grad, beta.grad]) or None
         if not ctx.has_bn:
             x, xcoef, w2 = ctx.saved_tensors
             dx = ops.mlp_gemm(w2.contiguous(), dz, tag="dgrad")[0] if need_x else None
-            dw = ops.mlp_wgrad(dz, x, xcoef=xcoef) if need_w else None
-            db = ops.bn_backward_reduce(dz, None, None, None, None, None, False)[1] if ctx.needs_input_grad[3] else None
-            return (dx, None, dw, db, None, None) + tail[:7]
+            dw = db = None
+            if need_w:
+                dw = ops.mlp_wgrad(dz, x, xcoef=xcoef, out=sink[0].view(w2.shape) if sink else None)
+            if ctx.needs_input_grad[3]:
+                db = ops.bn_backward_reduce(dz, None, None, None, None, None, False,
+                                            dbeta_out=sink[1] if sink else None)[1]
+            if sink:
+                dw = db = None               # already in .grad
+            return (dx, None, dw, db, None, None) + tail
         if not ctx.train_stats:
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
         x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
-        dgamma, dbeta, coef4, _ = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu)
+        dgamma, dbeta, coef4, _ = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu,
+                                                         dgamma_out=sink[2] if sink else None,
+                                                         dbeta_out=sink[3] if sink else None)
         dx = ops.mlp_gemm(w2.contiguous(), dz, pro=2, X2=y, coef=coef4, tag="dgrad")[0] if need_x else None
-        dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef) if need_w else None
+        dw = None
+        if need_w:
+            dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef,
+                               out=sink[0].view(w2.shape) if sink else None)
         db = torch.zeros_like(gamma) if ctx.needs_input_grad[3] else None
-        return (dx, None, dw, db, dgamma, dbeta) + tail[:7]
+        if sink:
+            dw = db = dgamma = dbeta = None  # written in place; the bias gradient is the zero already there
+        return (dx, None, dw, db, dgamma, dbeta) + tail
 
 
 def _group_sums_supported(K: int) -> bool:
@@ -187,7 +221,8 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, hcoef, dims, pooled, w2, bias, gamma, beta, running_mean, running_var, training, momentum,
-                eps, relu, pooled_first, defer):
+                eps, relu, pooled_first, defer, sink):
+        ctx.sink = sink
         B, Ch, M, K = dims
         Cp = pooled.shape[1]
         Cout = w2.shape[0]
@@ -214,7 +249,10 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         h3, hcoef, pooled, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         B, Ch, Cp, Cout, M, K, poff, hoff = ctx.dims
         dz = dz.contiguous().view(B, Cout, M * K)
-        dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu, group=K)
+        sink = ctx.sink
+        dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, ctx.relu, group=K,
+                                                            dgamma_out=sink[2] if sink else None,
+                                                            dbeta_out=sink[3] if sink else None)
         # sum over the K neighbours of dY = a1*dYhat + q1*y + q0
         sdy = (coef4[0].view(1, -1, 1) * gsum[0] + coef4[2].view(1, -1, 1) * gsum[1]
                + float(K) * coef4[3].view(1, -1, 1)).contiguous()
@@ -226,11 +264,13 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
             dh = ops.mlp_gemm(w2c, dz, pro=2, X2=y, coef=coef4, tag="dgrad", M=Ch, a_offset=hoff)[0]
             dh = dh.view(ctx.h_shape)
         if ctx.needs_input_grad[4]:
-            dw = torch.empty_like(w2c)
+            dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
             ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff, xcoef=hcoef)
             ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
         db = torch.zeros_like(gamma) if ctx.needs_input_grad[5] else None
-        return (dh, None, None, dpooled, dw, db, dgamma, dbeta) + (None,) * 8
+        if sink:
+            dw = db = dgamma = dbeta = None
+        return (dh, None, None, dpooled, dw, db, dgamma, dbeta) + (None,) * 9
 
 
 def conv1x1_bn_act_pooled(h, pooled: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], bn,
@@ -258,7 +298,7 @@ def conv1x1_bn_act_pooled(h, pooled: torch.Tensor, weight: torch.Tensor, bias: O
         bn.num_batches_tracked.add_(1)
     out, coef = _SharedMLPLayerPooled.apply(h, hcoef, tuple(hshape), pooled, w2, bias, bn.weight, bn.bias,
                                             bn.running_mean, bn.running_var, True, bn.momentum, bn.eps, relu,
-                                            pooled_first, defer)
+                                            pooled_first, defer, _sink(weight, bias, bn.weight, bn.bias))
     oshape = (hshape[0], w2.shape[0], hshape[2], K)
     return LazyAct(out, coef, relu, oshape) if defer else out.view(oshape)
 
@@ -281,13 +321,15 @@ def conv1x1_bn_act(x, weight: torch.Tensor, bias: Optional[torch.Tensor],
     x3 = x.reshape(shape[0], shape[1], -1)
     oshape = (shape[0], w2.shape[0]) + tuple(shape[2:])
     if bn is None:
-        y, _ = _SharedMLPLayer.apply(x3, xcoef, w2, bias, None, None, None, None, False, 0.0, 0.0, relu, False)
+        y, _ = _SharedMLPLayer.apply(x3, xcoef, w2, bias, None, None, None, None, False, 0.0, 0.0, relu, False,
+                                     _sink(weight, bias))
         return y.view(oshape)
     training = bn.training or bn.running_mean is None
     if bn.training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     y, coef = _SharedMLPLayer.apply(x3, xcoef, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                    training, bn.momentum, bn.eps, relu, defer)
+                                    training, bn.momentum, bn.eps, relu, defer,
+                                    _sink(weight, bias, bn.weight, bn.bias) if training else None)
     return LazyAct(y, coef, relu, oshape) if defer else y.view(oshape)
 
 

@@ -213,16 +213,17 @@ def bn_apply(Y, coef, relu: bool):
     return Z
 
 
-def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: int = 0):
+def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: int = 0,
+                       dgamma_out=None, dbeta_out=None):
     """-> (dgamma [C], dbeta [C], coef4 [4,C], gsum).  Y None: plain mode, returns (None, sum dZ, None, None).
     group > 0 additionally returns gsum [2,nb,C,P/group] (per-neighbourhood sums of dYhat and y)."""
     nb, C, P = dZ.shape
     dev = dZ.device
     partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
     dgamma = coef4 = gsum = None
     if Y is not None:
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
         coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
         if group:
             gsum = torch.empty((2, nb, C, P // group), dtype=torch.float32, device=dev)

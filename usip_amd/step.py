@@ -85,9 +85,14 @@ class DetectorStep:
 
     def step(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None, group=None):
         """forward + losses + backward (+ gradient all-reduce) (+ Adam when constructed with it)."""
+        from . import functional as Fh
         self.bucket.zero()                                    # detector.zero_grad() :186
-        loss = self.forward_losses(batch, epoch)
-        loss.backward()                                       # :205
+        Fh.GRAD_SINK = True       # every parameter is used once per step and the bucket was just zeroed:
+        try:                      # the backward kernels write dW/dgamma/dbeta straight into the bucket
+            loss = self.forward_losses(batch, epoch)
+            loss.backward()                                   # :205
+        finally:
+            Fh.GRAD_SINK = False
         self.bucket.all_reduce_mean(group)
         if self.optimizer is not None:
             self.optimizer.step()                             # :207
