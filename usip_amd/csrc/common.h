@@ -53,3 +53,14 @@ __device__ __forceinline__ float4 usip_load_stream4(const float* p)
     usip_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const usip_f32x4*>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+
+// Sum over the 16 lanes of a DPP row, result in every lane of the row: quad_perm xor 1, xor 2, then the two
+// mirror steps.  Pure VALU (v_add_f32 with a DPP modifier): no ds_bpermute, no LDS traffic.
+__device__ __forceinline__ float usip_row16_sum(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));  // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));  // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, false)); // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, false)); // row_mirror
+    return v;
+}

@@ -211,35 +211,42 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
         cur ^= 1;
     }
 
-    // ---- epilogue: + bias, store, BatchNorm partial statistics ------------------------------
+    // ---- epilogue: + bias (+ row bias), store, BatchNorm partial statistics ------------------
     float* Yb = a.Y + (long long)b * a.M * a.P;
     float* red = &As[0][0][0];                               // [2][WN][BM] scratch (LDS is free now)
     const int half = lane >> 5;
+    // the lane's two output columns and, for the pooled-concat layer, their neighbourhood index
+    // (ONE integer division per column instead of one per element)
+    int colj[2], grpj[2];
+    const int ngrp = a.rowbias ? a.P / a.rb_group : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        colj[j] = p0 + wn * 64 + j * 32 + c;
+        grpj[j] = a.rowbias ? min(colj[j], a.P - 1) / a.rb_group : 0;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int row = m0 + row_l;
-            const float bv = (a.bias && row < a.M) ? a.bias[row] : 0.0f;
+            const int rowc = min(row, a.M - 1);
+            const float bv = a.bias ? a.bias[rowc] : 0.0f;
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = p0 + wn * 64 + j * 32 + c;
                 float v = acc[i][j][r] + bv;
-                if (row < a.M && col < a.P) {
-                    if (a.rowbias)
-                        v += a.rowbias[((long long)b * a.M + row) * (a.P / a.rb_group) + col / a.rb_group];
-                    Yb[(long long)row * a.P + col] = v;
+                if (a.rowbias) v += a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
+                if (row < a.M && colj[j] < a.P) {
+                    Yb[(long long)row * a.P + colj[j]] = v;
                     if (STATS) { s += v; q = __builtin_fmaf(v, v, q); }
                 }
             }
             if (STATS) {
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
-                    s += __shfl_xor(s, off);
-                    q += __shfl_xor(q, off);
-                }
+                // 32-lane sum: four DPP steps inside each row of 16 lanes (VALU, no LDS crossbar), then one
+                // cross-row exchange
+                s = usip_row16_sum(s); q = usip_row16_sum(q);
+                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
                 if (c == 0) {
                     red[wn * BM + row_l] = s;
                     red[WN * BM + wn * BM + row_l] = q;
