@@ -106,6 +106,9 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
  *   W itself ([Cout][Cin]) for the data gradient dX = W^T . dY.
  *   pro: 0 identity | 1 relu(x*coef[0][k] + coef[1][k]) | 2 BatchNorm+ReLU backward of X = dZ,
  *        X2 = pre-BN output, coef = the [4][K] array written by usip_bn_backward_reduce_f32.
+ *        3 as 2, but dZ is not a tensor: the layer fed ONLY a max over pool_group neighbours, so
+ *          dZ[k][p] = (p % pool_group == pool_arg[k][p / pool_group]) ? pool_dp[k][p / pool_group] : 0
+ *          is formed on the fly from the two [nb][K][P/pool_group] arrays (X may be NULL).
  *   rowbias (may be NULL): [nb][M][P/rb_group], added as Y[b][m][p] += rowbias[b][m][p / rb_group]:
  *   the contribution of input channels that are constant inside a neighbourhood of rb_group
  *   positions (the max-pooled feature the reference expands and concatenates, networks.py:706-709,
@@ -114,8 +117,9 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
  *   tiles = usip_mlp_gemm_tiles(M, P, nb); summed in fixed order by usip_bn_finalize_f32. */
 int usip_mlp_gemm_tiles(int M, int P, int nb);
 int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2, const float* coef,
-                      int pro, const float* bias, const float* rowbias, int rb_group, float* Y, float* stats,
-                      int M, int K, int P, int nb, void* stream);
+                      int pro, const float* bias, const float* rowbias, int rb_group,
+                      const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                      float* Y, float* stats, int M, int K, int P, int nb, void* stream);
 
 /* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
  * coefficients coef[2][C] = (gamma*invstd, beta - mean*gamma*invstd), and the running-statistics
@@ -143,8 +147,16 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
                                 float* partial, float* dgamma, float* dbeta, float* coef4,
                                 float* gsum, int group, int nb, int C, int P, void* stream);
 
+/* usip_bn_backward_reduce_f32 for a layer whose output fed ONLY a max over K neighbours: the incoming
+ * gradient is (k == arg) ? dpooled : 0, so the sums run over B*C*M arg-max elements instead of B*C*M*K.
+ * dpooled f32 / arg i32 [nb][C][M], Y [nb][C][M][K]; outputs as usip_bn_backward_reduce_f32. */
+int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int32_t* arg, const float* Y,
+                                     const float* coef_fwd, const float* mean, const float* invstd,
+                                     const float* gamma, int relu, float* partial, float* dgamma, float* dbeta,
+                                     float* coef4, int nb, int C, int M, int K, void* stream);
+
 /* dW[m][n] = sum_{b,p} pro(G)[b][m][p] * X[b][n][p]   (pro 0: G = dY given; pro 2: G = dZ, G2 = Y,
- * coef = coef4 as above).  workspace: usip_mlp_wgrad_workspace(M, N, P, nb) floats of partial tiles,
+ * coef = coef4 as above; pro 3: dZ synthesised from pool_dp / pool_arg as in usip_mlp_gemm_f32).  workspace: usip_mlp_wgrad_workspace(M, N, P, nb) floats of partial tiles,
  * reduced in fixed order (deterministic).  dW is written as dW[m*ldw + coloff + n], so a column
  * block of a wider weight matrix can be filled in place.  xcoef (may be NULL): [2][N]; X is then the
  * PRE-BatchNorm output of the producing layer and relu(X*xcoef[0][n] + xcoef[1][n]) is formed on the fly
@@ -152,7 +164,8 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
 long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb);
 int usip_mlp_wgrad_blocks(int M, int N, int P, int nb);        /* workgroups launched (profiling aid) */
 int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro, const float* X,
-                       const float* xcoef, float* workspace, float* dW, int ldw, int coloff,
+                       const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                       float* workspace, float* dW, int ldw, int coloff,
                        int M, int N, int P, int nb, void* stream);
 
 /* ------------------------------------------------------------------ a-6 / a-7 / a-12  grouping, pooling

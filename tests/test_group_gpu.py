@@ -98,3 +98,43 @@ def test_pooled_concat_layer_matches_cat_reference(cfg):
     for name, a, t, f32 in zip(["y", "dh", "dpooled", "dw", "dgamma", "dbeta"], got, truth, aten):
         err, aten_err = _rel(a, t), _rel(f32, t)
         assert err <= max(1e-5, 4 * aten_err), (name, err, aten_err)
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 128, 40, 64), (2, 512, 512, 24, 16), (1, 20, 12, 6, 32), (1, 8, 8, 5, 5)])
+def test_layer_plus_max_fused_matches_reference(cfg):
+    """conv1x1 + BN + ReLU + max over K as one node (sparse pooled backward, PRO_BN_BWD_POOL) against plain
+    PyTorch in float64 / float32."""
+    from usip_amd import functional as Fh
+    B, Cin, Cout, M, K = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cin, M, K, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5).to(DEV)
+    b = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    gp = torch.randn(B, Cout, M, generator=g).to(DEV)
+
+    def ref(dtype):
+        xx = x.detach().clone().to(dtype).requires_grad_(True)
+        ww = w.detach().clone().to(dtype).requires_grad_(True)
+        ga = gamma.detach().clone().to(dtype).requires_grad_(True)
+        be = beta.detach().clone().to(dtype).requires_grad_(True)
+        y = torch.einsum("oc,bcmk->bomk", ww, xx) + b.to(dtype).view(1, -1, 1, 1)
+        z = torch.relu(F.batch_norm(y, None, None, ga, be, True, 0.1, 1e-5))
+        p, _ = torch.max(z, dim=3)
+        p.backward(gp.to(dtype))
+        return [p.detach(), xx.grad, ww.grad, ga.grad, be.grad]
+
+    truth, aten = ref(torch.float64), ref(torch.float32)
+    xs = x.detach().clone().requires_grad_(True)
+    ws = w.detach().clone().view(Cout, Cin, 1, 1).requires_grad_(True)
+    bs = b.detach().clone().requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(Cout).to(DEV).train()
+    bn.weight.data.copy_(gamma)
+    bn.bias.data.copy_(beta)
+    p = Fh.conv1x1_bn_relu_max(xs, ws, bs, bn)
+    p.backward(gp)
+    got = [p.detach(), xs.grad, ws.grad.view(Cout, Cin), bn.weight.grad, bn.bias.grad]
+    for name, a, t, f32 in zip(["pooled", "dx", "dw", "dgamma", "dbeta"], got, truth, aten):
+        err, aten_err = _rel(a, t), _rel(f32, t)
+        assert err <= max(1e-5, 4 * aten_err), (name, err, aten_err)

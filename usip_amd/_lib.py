@@ -27,8 +27,10 @@ SIGNATURES = {
     "usip_nearest_workspace": ([_int, _int, _int], ctypes.c_longlong),
     "usip_nearest_f32": ([_f32p, _f32p, _f32p, _i32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_tiles": ([_int, _int, _int], _int),
-    "usip_mlp_gemm_f32": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _f32p,
-                           _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_gemm_f32": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
+                           _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
+    "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p,
+                                          _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _flt, _flt, _f32p, _f32p, _f32p,
                               _f32p, _f32p, _stream], _int),
     "usip_bn_apply_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
@@ -36,8 +38,8 @@ SIGNATURES = {
                                      _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_workspace": ([_int, _int, _int, _int], ctypes.c_longlong),
     "usip_mlp_wgrad_blocks": ([_int, _int, _int, _int], _int),
-    "usip_mlp_wgrad_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int,
-                            _stream], _int),
+    "usip_mlp_wgrad_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int,
+                            _int, _int, _int, _int, _stream], _int),
     "usip_group_max_act_f32": ([_f32p, _f32p, _int, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_group_gather_f32": ([_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int,
                                _stream], _int),

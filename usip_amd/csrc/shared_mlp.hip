@@ -30,7 +30,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2 };
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2, PRO_BN_BWD_POOL = 3 };
+// PRO_BN_BWD_POOL: the layer's output went ONLY into a max over K neighbours, so its incoming gradient is
+// dZ[c][m][k] = (k == arg[c][m]) ? dpooled[c][m] : 0.  It is synthesised from the two small [C][M] arrays
+// instead of being written as a dense tensor by the pooling backward and read back three times.
 
 struct GemmArgs {
     const float* At; int lda;          // [K][M], row stride lda
@@ -42,6 +45,7 @@ struct GemmArgs {
     float* stats;                      // [2][ntn][M] or null
     int M, K, P, nb;
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
+    const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
     int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
                                         // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
 };
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     constexpr int NA = BM * BK / 256;           // A elements per thread per stage
     constexpr int NB4 = BK * BN / 4 / 256;      // X float4 per thread per stage (VEC)
     constexpr int NBS = BK * BN / 256;          // X scalars per thread per stage (!VEC)
-    constexpr bool TWO = (PRO == PRO_BN_BWD);   // second streamed tensor (the layer's pre-BN output)
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;   // second streamed tensor (the layer's pre-BN output)
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
@@ -86,6 +91,9 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     const int m0 = mt * BM, p0 = pt * BN;
     const float* Xb = a.X + (long long)b * a.K * a.P;
     const float* X2b = TWO ? a.X2 + (long long)b * a.K * a.P : nullptr;
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const float* pdp = POOL ? a.pool_dp + (long long)b * a.K * pgrp : nullptr;
+    const int* parg = POOL ? a.pool_arg + (long long)b * a.K * pgrp : nullptr;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -114,8 +122,15 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 #pragma unroll
             for (int i = 0; i < NB4; ++i) {
                 const int f = tid + i * 256, k = f / (BN / 4), col = (f % (BN / 4)) * 4;
-                const long long off = (long long)min(k0 + k, a.K - 1) * a.P + min(p0 + col, a.P - 4);
-                rx[i] = *reinterpret_cast<const float4*>(Xb + off);
+                const int kc = min(k0 + k, a.K - 1), pc = min(p0 + col, a.P - 4);
+                const long long off = (long long)kc * a.P + pc;
+                if (POOL) {
+                    // raw (dpooled, arg) of this float4's neighbourhood; dZ is formed when the registers go to LDS
+                    const long long g = (long long)kc * pgrp + pc / a.pool_group;
+                    rx[i] = make_float4(pdp[g], __int_as_float(parg[g]), __int_as_float(pc % a.pool_group), 0.f);
+                } else {
+                    rx[i] = *reinterpret_cast<const float4*>(Xb + off);
+                }
                 if (TWO) ry[i] = *reinterpret_cast<const float4*>(X2b + off);
             }
         } else {
@@ -153,10 +168,16 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
                     float c2 = 0.f, c3 = 0.f;
                     float4 w = v;
                     if (TWO) { c2 = a.coef[2 * a.K + kc]; c3 = a.coef[3 * a.K + kc]; w = ry[i]; }
-                    v.x = ok ? pro_apply<PRO>(v.x, w.x, c0, c1, c2, c3) : 0.f;
-                    v.y = ok ? pro_apply<PRO>(v.y, w.y, c0, c1, c2, c3) : 0.f;
-                    v.z = ok ? pro_apply<PRO>(v.z, w.z, c0, c1, c2, c3) : 0.f;
-                    v.w = ok ? pro_apply<PRO>(v.w, w.w, c0, c1, c2, c3) : 0.f;
+                    if (POOL) {
+                        const int hit = __float_as_int(v.y) - __float_as_int(v.z);   // arg - (first k of the float4)
+                        const float g = v.x;
+                        v = make_float4(hit == 0 ? g : 0.f, hit == 1 ? g : 0.f, hit == 2 ? g : 0.f, hit == 3 ? g : 0.f);
+                    }
+                    constexpr int PA = POOL ? PRO_BN_BWD : PRO;
+                    v.x = ok ? pro_apply<PA>(v.x, w.x, c0, c1, c2, c3) : 0.f;
+                    v.y = ok ? pro_apply<PA>(v.y, w.y, c0, c1, c2, c3) : 0.f;
+                    v.z = ok ? pro_apply<PA>(v.z, w.z, c0, c1, c2, c3) : 0.f;
+                    v.w = ok ? pro_apply<PA>(v.w, w.w, c0, c1, c2, c3) : 0.f;
                 }
                 *reinterpret_cast<float4*>(&Bs[buf][k][col]) = v;
             }
@@ -274,8 +295,8 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     const int tpc = (a.P + BN - 1) / BN, nmt = (a.M + BM - 1) / BM;
     const long long total = (long long)a.nb * tpc * nmt;
     if (total > 0x7fffffffLL) return USIP_EINVAL;
-    const bool vec = (a.P % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15u) == 0) &&
-                     (pro != PRO_BN_BWD || (reinterpret_cast<uintptr_t>(a.X2) & 15u) == 0);
+    const bool vec = (a.P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(a.X) & 15u) == 0) &&
+                     ((pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) || (reinterpret_cast<uintptr_t>(a.X2) & 15u) == 0);
     const bool stats = a.stats != nullptr;
     dim3 grid((unsigned)total), block(256);
 #define USIP_GEMM_CASE(P_, S_, V_)                                                              \
@@ -294,6 +315,7 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     USIP_GEMM_CASE(PRO_AFFINE_RELU, false, false)
     USIP_GEMM_CASE(PRO_BN_BWD, false, true)
     USIP_GEMM_CASE(PRO_BN_BWD, false, false)
+    USIP_GEMM_CASE(PRO_BN_BWD_POOL, false, true)
 #undef USIP_GEMM_CASE
     return USIP_EINVAL;
 }
@@ -304,6 +326,7 @@ struct WgradArgs {
     const float* G;  const float* G2; const float* coef;   // [nb][M][P] (+ Y and [4][M] for PRO_BN_BWD)
     const float* X;                                         // [nb][N][P]
     const float* xcoef;                                     // [2][N] or null: X := relu(X*xcoef[0][n] + xcoef[1][n])
+    const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][M][P/group] each
     float* part;                                            // [slices][M][N]
     int M, N, P, nb, seglen, segs;                          // segs position segments per cloud
 };
@@ -362,8 +385,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const int m0 = (tile / nnt) * BM, n0 = (tile % nnt) * BN;
     const int b = slice / a.segs, seg = slice % a.segs;
     const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
-    const float* Gb = a.G + (long long)b * a.M * a.P;
-    const float* G2b = (PRO == PRO_BN_BWD) ? a.G2 + (long long)b * a.M * a.P : nullptr;
+    const float* Gb = (PRO == PRO_BN_BWD_POOL) ? nullptr : a.G + (long long)b * a.M * a.P;
+    const float* G2b = (PRO == PRO_BN_BWD || PRO == PRO_BN_BWD_POOL) ? a.G2 + (long long)b * a.M * a.P : nullptr;
     const float* Xb = a.X + (long long)b * a.N * a.P;
 
     f32x16 acc[TM][TN];
@@ -374,8 +397,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    constexpr bool TWO = (PRO == PRO_BN_BWD);
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
     float4 rg[NG4], rg2[TWO ? NG4 : 1], rx[NX4], rdummy[1];
+    // POOL: raw (dpooled, arg, first k) of the float4's neighbourhood instead of a dZ load
+    auto load_pool = [&](int p) {
+#pragma unroll
+        for (int i = 0; i < NG4; ++i) {
+            const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
+            const int rc = min(m0 + row, a.M - 1), pc = min(p + kq, a.P - 4);
+            const long long g = ((long long)b * a.M + rc) * pgrp + pc / a.pool_group;
+            rg[i] = make_float4(a.pool_dp[g], __int_as_float(a.pool_arg[g]), __int_as_float(pc % a.pool_group), 0.f);
+            rg2[i] = *reinterpret_cast<const float4*>(G2b + (long long)rc * a.P + pc);
+        }
+    };
     auto store_stage = [&](int buf, int p) {
 #pragma unroll
         for (int i = 0; i < NG4; ++i) {
@@ -388,6 +424,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
                 const float c0 = a.coef[ch], c1 = a.coef[a.M + ch], c2 = a.coef[2 * a.M + ch],
                             c3 = a.coef[3 * a.M + ch];
                 const float4 w = rg2[i];
+                if (POOL) {
+                    const int hit = __float_as_int(v.y) - __float_as_int(v.z);
+                    const float g = v.x;
+                    v = make_float4(hit == 0 ? g : 0.f, hit == 1 ? g : 0.f, hit == 2 ? g : 0.f, hit == 3 ? g : 0.f);
+                }
                 v.x = (rok && p + kq + 0 < pend) ? pro_apply<PRO_BN_BWD>(v.x, w.x, c0, c1, c2, c3) : 0.f;
                 v.y = (rok && p + kq + 1 < pend) ? pro_apply<PRO_BN_BWD>(v.y, w.y, c0, c1, c2, c3) : 0.f;
                 v.z = (rok && p + kq + 2 < pend) ? pro_apply<PRO_BN_BWD>(v.z, w.z, c0, c1, c2, c3) : 0.f;
@@ -420,7 +461,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 
     const int nst = (pend - pbeg + BKP - 1) / BKP;
     if (nst > 0) {
-        wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
+        if (POOL) load_pool(pbeg);
+        else wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
         wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx, rdummy);
         store_stage(0, pbeg);
     }
@@ -429,7 +471,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const int kr = lane >> 5, c = lane & 31;
     for (int s = 0; s < nst; ++s) {
         if (s + 1 < nst) {
-            wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
+            if (POOL) load_pool(pbeg + (s + 1) * BKP);
+            else wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
             wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx, rdummy);
         }
         float fa[TM], fb[TN];
@@ -655,6 +698,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+// The same two sums when dZ = (k == arg) ? dpooled : 0: only the arg-max element of every neighbourhood
+// contributes, so the pass touches B*C*M elements (and gathers one y each) instead of B*C*M*K.
+__global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(
+    const float* __restrict__ dpooled, const int* __restrict__ arg, const float* __restrict__ Y,
+    const float* __restrict__ coef, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ partial, int relu, int C, int M, int K, int nrows)
+{
+    __shared__ float red[2][4];
+    const long long rowid = blockIdx.x;
+    const int ch = (int)(rowid % C);
+    const float sc = coef[ch], sh = coef[C + ch], mu = mean[ch], is = invstd[ch];
+    const float* y = Y + rowid * M * K;
+    float s1 = 0.f, s2 = 0.f;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        const float yv = y[(long long)m * K + arg[rowid * M + m]];
+        const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dpooled[rowid * M + m] : 0.f;
+        s1 += d;
+        s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[rowid] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[nrows + rowid] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
 // dgamma = sum2, dbeta = sum1, and the PRO_BN_BWD coefficients
 //   dY = gamma*invstd * (dYhat - mean(dYhat) - yhat * mean(dYhat*yhat)) = a1*dYhat + q1*y + q0
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
@@ -695,18 +767,22 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 
 extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
                                  const float* coef, int pro, const float* bias, const float* rowbias,
-                                 int rb_group, float* Y, float* stats,
-                                 int M, int K, int P, int nb, void* stream)
+                                 int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                                 float* Y, float* stats, int M, int K, int P, int nb, void* stream)
 {
     if (M < 1 || K < 1 || P < 0 || nb < 0 || lda < M) return USIP_EINVAL;
     if ((long long)P * nb == 0) return USIP_OK;
-    if (!At || !X || !Y || pro < 0 || pro > 2) return USIP_EINVAL;
+    if (!At || !Y || pro < 0 || pro > 3) return USIP_EINVAL;
+    if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
     if (pro != PRO_NONE && !coef) return USIP_EINVAL;
-    if (pro == PRO_BN_BWD && (!X2 || stats)) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || stats)) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 4 || pool_group % 4 != 0 ||
+                                   P % pool_group != 0 || P % 4 != 0)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
-    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, ablate};
+    GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
+               ablate};
     hipStream_t st = (hipStream_t)stream;
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
     return (M <= 64) ? launch_gemm<1, 4, 16>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
@@ -747,21 +823,27 @@ extern "C" int usip_mlp_wgrad_blocks(int M, int N, int P, int nb)
 }
 
 extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro,
-                                  const float* X, const float* xcoef, float* workspace, float* dW, int ldw,
+                                  const float* X, const float* xcoef, const float* pool_dp, const int32_t* pool_arg,
+                                  int pool_group, float* workspace, float* dW, int ldw,
                                   int coloff, int M, int N, int P, int nb, void* stream)
 {
     if (M < 1 || N < 1 || P < 1 || nb < 1 || ldw < N + coloff || coloff < 0) return USIP_EINVAL;
     if (!dW) return USIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (!G || !X || !workspace || (pro != PRO_NONE && pro != PRO_BN_BWD)) return USIP_EINVAL;
-    if (pro == PRO_BN_BWD && (!G2 || !coef)) return USIP_EINVAL;
+    if (!X || !workspace || (pro != PRO_NONE && pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL)) return USIP_EINVAL;
+    if (pro != PRO_BN_BWD_POOL && !G) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!G2 || !coef)) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 4 || pool_group % 4 != 0 ||
+                                   P % pool_group != 0 || P % 4 != 0 || (reinterpret_cast<uintptr_t>(G2) & 15u)))
+        return USIP_EINVAL;
     int seglen, segs, small, tiles;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
-    WgradArgs a{G, G2, coef, X, xcoef, workspace, M, N, P, nb, seglen, segs};
+    WgradArgs a{G, G2, coef, X, xcoef, pool_dp, pool_arg, pool_group, workspace, M, N, P, nb, seglen, segs};
     const bool xpro = xcoef != nullptr;
-    const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
+    const bool vec = (P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
                      ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
-                     (pro != PRO_BN_BWD || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
+                     (pro == PRO_NONE || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
+    if (pro == PRO_BN_BWD_POOL && !vec) return USIP_EINVAL;
     const long long blocks = (long long)tiles * nb * segs;
     if (blocks > 0x7fffffffLL) return USIP_EINVAL;
     dim3 grid((unsigned)blocks), block(256);
@@ -777,6 +859,8 @@ extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* 
     USIP_WGRAD_CASES(1, PRO_BN_BWD)
     USIP_WGRAD_CASES(2, PRO_NONE)
     USIP_WGRAD_CASES(2, PRO_BN_BWD)
+    USIP_WGRAD_CASE(1, PRO_BN_BWD_POOL, false, true) USIP_WGRAD_CASE(1, PRO_BN_BWD_POOL, true, true)
+    USIP_WGRAD_CASE(2, PRO_BN_BWD_POOL, false, true) USIP_WGRAD_CASE(2, PRO_BN_BWD_POOL, true, true)
 #undef USIP_WGRAD_CASES
 #undef USIP_WGRAD_CASE
     const long long elems = (long long)M * N;
@@ -860,6 +944,25 @@ extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, cons
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
                 (double)nb * (double)P, gamma, coef_fwd, mean, invstd, dgamma, dbeta, plain ? nullptr : coef4);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int32_t* arg, const float* Y,
+                                                const float* coef_fwd, const float* mean, const float* invstd,
+                                                const float* gamma, int relu, float* partial, float* dgamma,
+                                                float* dbeta, float* coef4, int nb, int C, int M, int K, void* stream)
+{
+    if (nb < 1 || C < 1 || M < 1 || K < 1 || !dpooled || !arg || !Y || !coef_fwd || !mean || !invstd || !partial)
+        return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)nb * C;
+    if (rows > 0x7fffffffLL) return USIP_EINVAL;
+    USIP_LAUNCH(bn_bwd_pool_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dpooled, arg, Y, coef_fwd, mean,
+                invstd, partial, relu, C, M, K, (int)rows);
+    USIP_LAUNCH_CHECK();
+    USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
+                (double)nb * (double)M * (double)K, gamma, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

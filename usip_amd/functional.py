@@ -202,6 +202,73 @@ class _SharedMLPLayer(torch.autograd.Function):
         return (dx, None, dw, db, dgamma, dbeta) + tail
 
 
+class _SharedMLPLayerMax(torch.autograd.Function):
+    """conv1x1 -> BatchNorm -> ReLU -> max over the K neighbours as ONE autograd node, for layers whose
+    output feeds only the pooling (conv5 of the ball detector, the last layer of the KNN fusion):
+      forward : GEMM (+stats) -> finalise -> fused BN+ReLU+max straight from the GEMM output
+      backward: the incoming gradient is dpooled [B,C,M]; dZ = (k == arg) ? dpooled : 0 is never
+                materialised -- the BN reduction visits only the B*C*M arg-max elements and the data- and
+                weight-gradient GEMMs synthesise dZ in their prologue (PRO_BN_BWD_POOL)."""
+
+    @staticmethod
+    def forward(ctx, x, xcoef, dims, w2, bias, gamma, beta, running_mean, running_var, momentum, eps, sink):
+        B, Cin, M, K = dims
+        x3 = x.contiguous().view(B, Cin, M * K)
+        wt = w2.detach().t().contiguous()
+        Cout = w2.shape[0]
+        y, stats = ops.mlp_gemm(wt, x3, bias, want_stats=True, pro=0 if xcoef is None else 1, coef=xcoef)
+        mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum, running_mean, running_var)
+        pooled, arg = ops.group_max_act(y.view(B, Cout, M, K), coef, True)
+        ctx.save_for_backward(x3, xcoef, w2, y, coef, mean, invstd, gamma, arg)
+        ctx.dims, ctx.sink, ctx.x_shape = (B, Cin, Cout, M, K), sink, tuple(x.shape)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x3, xcoef, w2, y, coef, mean, invstd, gamma, arg = ctx.saved_tensors
+        B, Cin, Cout, M, K = ctx.dims
+        sink = ctx.sink
+        dpooled = dpooled.contiguous()
+        dgamma, dbeta, coef4 = ops.bn_pool_backward_reduce(dpooled, arg, y.view(B, Cout, M, K), coef, mean, invstd,
+                                                           gamma, True, dgamma_out=sink[2] if sink else None,
+                                                           dbeta_out=sink[3] if sink else None)
+        pool = (dpooled, arg, K)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.mlp_gemm(w2.contiguous(), None, pro=3, X2=y, coef=coef4, tag="dgrad", pool=pool)[0]
+            dx = dx.view(ctx.x_shape)
+        if ctx.needs_input_grad[3]:
+            dw = ops.mlp_wgrad(None, x3, pro=3, G2=y, coef4=coef4, xcoef=xcoef, pool=pool,
+                               out=sink[0].view(w2.shape) if sink else None)
+        db = torch.zeros_like(gamma) if ctx.needs_input_grad[4] else None
+        if sink:
+            dw = db = dgamma = dbeta = None
+        return (dx, None, None, dw, db, dgamma, dbeta) + (None,) * 5
+
+
+def conv1x1_bn_relu_max(x, weight: torch.Tensor, bias: Optional[torch.Tensor], bn) -> torch.Tensor:
+    """max_k relu(bn(conv1x1(x))) for x [B,Cin,M,K] (tensor or LazyAct) -> [B,Cout,M]; the layer's
+    activated output exists nowhere else, so neither it nor its gradient is ever materialised."""
+    shape = x.shape
+    K = shape[3]
+    fused = (bn is not None and bn.training and bias is not None and _group_sums_supported(K)
+             and torch.is_grad_enabled())
+    if not fused:
+        return group_max(conv1x1_bn_act(x, weight, bias, bn, True, defer=True))
+    xcoef = None
+    if isinstance(x, LazyAct):
+        if not x.relu:
+            x = x.materialize()
+        else:
+            x, xcoef = x.y, x.coef
+    require_device(x, "the shared MLP")
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _SharedMLPLayerMax.apply(x, xcoef, tuple(shape), w2, bias, bn.weight, bn.bias, bn.running_mean,
+                                    bn.running_var, bn.momentum, bn.eps, _sink(weight, bias, bn.weight, bn.bias))
+
+
 def _group_sums_supported(K: int) -> bool:
     lpg = K // 4
     return K >= 4 and K % 4 == 0 and (lpg & (lpg - 1)) == 0 and lpg <= 64

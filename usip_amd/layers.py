@@ -191,6 +191,12 @@ class GeneralKNNFusionModule(nn.Module):
             bn.decay_momentum(epoch)
         y = Fh.conv1x1_bn_act_pooled(h, pooled, first.conv.weight, first.conv.bias, bn,
                                      first.activation == "relu", pooled_first=True, defer=True)   # :435
-        for layer in rest:
+        for layer in rest[:-1]:
+            y = layer(y, epoch, defer=True)
+        if rest and getattr(rest[-1], "norm", None) is not None and rest[-1].activation == "relu":
+            last = rest[-1]                                              # last layer + max over K fused
+            last.norm.decay_momentum(epoch)
+            return Fh.conv1x1_bn_relu_max(y, last.conv.weight, last.conv.bias, last.norm)   # :436-438
+        for layer in rest[-1:]:
             y = layer(y, epoch, defer=True)
         return Fh.group_max(y)                                           # :438

@@ -124,8 +124,11 @@ class RPN_Detector_Ball(_DetectorTail):
         h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
                                      getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
                                      pooled_first=False, defer=True)      # cat(h, expand(max)) :708-709
-        h = self.conv5(h, defer=True)
-        second_max = Fh.group_max(h)                                      # :710
+        if getattr(self.conv5, "norm", None) is not None and self.conv5.activation == "relu":
+            second_max = Fh.conv1x1_bn_relu_max(h, self.conv5.conv.weight, self.conv5.conv.bias,
+                                                self.conv5.norm)          # conv5 + max over K fused :709-710
+        else:
+            second_max = Fh.group_max(self.conv5(h, defer=True))
         ball_idx = ball_idx32.long()
         keypoints, sigmas = self._tail(node, second_max, epoch)
         self.last_indices = dict(ball_idx=ball_idx, knn_I=self.knnlayer_1.last_knn_I)

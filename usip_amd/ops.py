@@ -153,14 +153,19 @@ def _opt(t):
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
-             M: Optional[int] = None, a_offset: int = 0):
+             M: Optional[int] = None, a_offset: int = 0, pool=None):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
     (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,tiles,M] when want_stats)."""
     _need(At, "At", torch.float32)
-    _need(X, "X", torch.float32)
     K, lda = At.shape
     M = lda if M is None else int(M)
+    pool_dp = pool_arg = None
+    pool_group = 0
+    if pool is not None:                      # pro == 3: (dpooled [nb,K,G], arg i32 [nb,K,G], group); X unused
+        pool_dp, pool_arg, pool_group = pool
+        X = X2
+    _need(X, "X", torch.float32)
     nb, Kx, P = X.shape
     if Kx != K or a_offset < 0 or a_offset + M > lda:
         raise RuntimeError("mlp_gemm: operand shapes do not match (At %s, X %s, M %d, offset %d)"
@@ -182,9 +187,10 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P, rocprof_key=_key):
-        _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, lda, _ptr(X), _opt(X2), _opt(coef), int(pro), _opt(bias),
-                                                _opt(rowbias), int(rb_group), _ptr(Y), _opt(stats), M, K, P, nb,
-                                                _stream(X)), "usip_mlp_gemm_f32")
+        _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, lda, None if pool is not None else _ptr(X), _opt(X2),
+                                                _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
+                                                _opt(pool_dp), _opt(pool_arg), int(pool_group),
+                                                _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), "usip_mlp_gemm_f32")
     return Y, stats
 
 
@@ -236,12 +242,36 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
     return dgamma, dbeta, coef4, gsum
 
 
-def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0, xcoef=None):
+def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, relu: bool,
+                            dgamma_out=None, dbeta_out=None):
+    """BN(+ReLU) backward sums for a layer that fed only a max over K: -> (dgamma, dbeta, coef4)."""
+    nb, C, M, K = Y4.shape
+    dev = Y4.device
+    partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("bn_backward_reduce_pooled", 4.0 * nb * C * M * 3):
+        _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _ptr(coef_fwd),
+                                                               _ptr(mean), _ptr(invstd), _opt(gamma), int(bool(relu)),
+                                                               _ptr(partial), _ptr(dgamma), _ptr(dbeta), _ptr(coef4),
+                                                               nb, C, M, K, _stream(Y4)),
+                   "usip_bn_pool_backward_reduce_f32")
+    return dgamma, dbeta, coef4
+
+
+def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0, xcoef=None, pool=None):
     """dW [M,N] = sum_{b,p} pro(G)[b,m,p] * X[b,n,p]; G [nb,M,P], X [nb,N,P].
     With `out` ([M, ldw] contiguous) the result is written into columns [coloff, coloff+N) of it."""
-    nb, M, P = G.shape
+    pool_dp = pool_arg = None
+    pool_group = 0
+    if pool is not None:                      # pro == 3: G is not a tensor
+        pool_dp, pool_arg, pool_group = pool
+        nb, M, P = G2.shape
+    else:
+        nb, M, P = G.shape
     N = X.shape[1]
-    dev = G.device
+    dev = X.device
     ws_n = _lib.lib().usip_mlp_wgrad_workspace(M, N, P, nb)
     ws = torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev)
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
@@ -255,8 +285,9 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
                                              4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
                                              rocprof_key=_key):
-        _lib.check(_lib.lib().usip_mlp_wgrad_f32(_ptr(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _opt(xcoef), _ptr(ws), _ptr(dW),
-                                                 int(ldw), int(coloff), M, N, P, nb, _stream(G)), "usip_mlp_wgrad_f32")
+        _lib.check(_lib.lib().usip_mlp_wgrad_f32(_opt(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _opt(xcoef),
+                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group), _ptr(ws), _ptr(dW),
+                                                 int(ldw), int(coloff), M, N, P, nb, _stream(X)), "usip_mlp_wgrad_f32")
     return dW
 
 
