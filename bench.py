@@ -119,12 +119,19 @@ def main():
         st.step(batch)
     torch.cuda.synchronize()
     barrier()
+    # Per-kernel HIP events cost ~3 us of stream bubble each (~0.7 ms per step for ~220 of them): they are
+    # recorded on every 4th step of the timed region, which keeps the headline number within ~1.5 % of an
+    # uninstrumented run while the kernel durations still come from inside the timed region.
+    sample_every = 4
+    timed_steps_sampled = 0
     if not args.no_kernel_timing:
         prof.reset()
-        prof.enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        sampled = (not args.no_kernel_timing) and (i % sample_every == 0)
+        prof.enable(sampled)
+        timed_steps_sampled += int(sampled)
         st.step(batch)
     torch.cuda.synchronize()
     barrier()
@@ -171,9 +178,9 @@ def main():
                 mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
                 ach = r["TFLOPs"] if mfma else r["GBps"]
                 peak = PEAK_F32_TFLOPS if mfma else PEAK_HBM_GBPS
-                kernels.append({"kernel": name, "calls_per_step": r["calls"] / args.steps,
+                kernels.append({"kernel": name, "calls_per_step": r["calls"] / timed_steps_sampled,
                                 "avg_us": round(r["avg_us"], 2),
-                                "share_of_step": round(r["total_ms"] / (elapsed * 1e3), 4),
+                                "share_of_step": round(r["total_ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
                                 "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 3), "peak": peak,
                                 "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
                                 "traffic": (traffic_db.get(r.get("rocprof_key") or "", {}).get("hbm_bytes_per_launch")),
@@ -210,8 +217,11 @@ def main():
                 out["roofline"] = {
                     "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": (top["traffic"] / top["traffic_calls"]) if top["traffic_calls"] else None,
-                    "kernel": top_name, "launches_per_step": top["calls"] / args.steps,
-                    "avg_us": round(avg_s * 1e6, 2), "share_of_step": round(top["ms"] / (elapsed * 1e3), 4),
+                    "kernel": top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
+                    "avg_us": round(avg_s * 1e6, 2),
+                    "share_of_step": round(top["ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
+                    "timing": "HIP events on the launch stream, every %d-th step of the timed region (%d steps)"
+                              % (sample_every, timed_steps_sampled),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
                     "traffic_source": traffic_src,
                     "attainable_peak_note": "tools/mfma_peak.hip sustains 138-149 TFLOP/s fp32 MFMA on this chip "
