@@ -94,6 +94,11 @@ int usip_som_cluster_f32(const float* x, const int32_t* min_idx, float* cluster_
 long long usip_nearest_workspace(int B, int Ma, int Nb);   /* elements of ws_d AND of ws_j (0: none needed) */
 int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
                      float* ws_d, int32_t* ws_j, int B, int Ma, int Nb, void* stream);
+/* Its backward (what autograd derives through torch.norm + torch.min + gather in the reference):
+ * ga[b][:][i] = gd[b][i] * (a_i - b_J) / d, zero where d == 0; gb (may be NULL, else pre-zeroed)
+ * receives the negative, scatter-added at J. */
+int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
+                              const float* gd, float* ga, float* gb, int B, int Ma, int Nb, void* stream);
 
 /* ------------------------------------------------------------------ a-5 / a-6 / a-7 / a-8  shared MLP
  * Replaces, per layer, nn.Conv1d/Conv2d(k=1) + MyBatchNorm + ReLU and their autograd backward
@@ -103,7 +108,9 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
  *
  * usip_mlp_gemm_f32:  Y[b][m][p] = sum_k At[k][m] * pro(X[b][k][p]) + bias[m]
  *   At is the matrix operand K-major ([K][M], row stride lda): W^T for the forward product,
- *   W itself ([Cout][Cin]) for the data gradient dX = W^T . dY.
+ *   W itself ([Cout][Cin]) for the data gradient dX = W^T . dY.  A NEGATIVE lda means the operand is
+ *   stored M-major ([M][K], row stride -lda) and is read transposed, so the forward product can use W
+ *   in place as well.
  *   pro: 0 identity | 1 relu(x*coef[0][k] + coef[1][k]) | 2 BatchNorm+ReLU backward of X = dZ,
  *        X2 = pre-BN output, coef = the [4][K] array written by usip_bn_backward_reduce_f32.
  *        3 as 2, but dZ is not a tensor: the layer fed ONLY a max over pool_group neighbours, so

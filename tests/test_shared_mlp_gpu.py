@@ -129,3 +129,14 @@ def test_lazy_activation_chain_equals_materialised_chain():
         outs.append([pooled.detach(), xi.grad] + [p.grad for m in mods for p in m.parameters()])
     for a, b in zip(*outs):
         assert _rel(a, b) <= 2e-6
+
+
+def test_gemm_reads_transposed_operand_in_place():
+    """C ABI: a negative lda makes usip_mlp_gemm_f32 read the matrix operand stored [M][K] transposed in place."""
+    from usip_amd import ops
+    g = torch.Generator().manual_seed(5)
+    W = torch.randn(48, 36, generator=g).to(DEV)
+    X = torch.randn(2, 36, 200, generator=g).to(DEV)
+    y1, _ = ops.mlp_gemm(W.t().contiguous(), X)
+    y2, _ = ops.mlp_gemm(W, X, a_trans=True)
+    assert torch.equal(y1, y2)

@@ -89,7 +89,44 @@ __global__ __launch_bounds__(256) void nearest_merge_kernel(
     arg[i] = j;
 }
 
+// Backward of (min distance, arg-min): ga[b,:,i] = gd[b,i] * (a_i - b_J) / d (0 where d == 0, as the
+// sub-gradient of torch.norm at zero), and, when gb != null, gb[b,:,J] -= the same (float atomics: several
+// queries may share a partner).  gb must be zeroed by the caller.
+__global__ __launch_bounds__(256) void nearest_bwd_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
+    const int32_t* __restrict__ arg, const float* __restrict__ gd, float* __restrict__ ga,
+    float* __restrict__ gb, int Ma, int Nb)
+{
+    const int bi = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Ma) return;
+    const long long q = (long long)bi * Ma + i;
+    const int j = arg[q];
+    const float dist = d[q];
+    const float sc = dist > 0.f ? gd[q] / dist : 0.f;
+    const float* ab = a + (long long)bi * 3 * Ma;
+    const float* bb = b + (long long)bi * 3 * Nb;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float g = (ab[c * Ma + i] - bb[c * Nb + j]) * sc;
+        ga[((long long)bi * 3 + c) * Ma + i] = g;
+        if (gb) atomicAdd(&gb[((long long)bi * 3 + c) * Nb + j], -g);
+    }
+}
+
 }  // namespace
+
+extern "C" int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
+                                         const float* gd, float* ga, float* gb, int B, int Ma, int Nb, void* stream)
+{
+    if (B < 0 || Ma < 0 || Nb < 1) return USIP_EINVAL;
+    if ((long long)B * Ma == 0) return USIP_OK;
+    if (!a || !b || !d || !arg || !gd || !ga || B > 65535) return USIP_EINVAL;
+    USIP_LAUNCH(nearest_bwd_kernel, dim3(usip_ceil_div(Ma, 256), B), dim3(256), 0, (hipStream_t)stream,
+                a, b, d, arg, gd, ga, gb, Ma, Nb);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
 
 extern "C" long long usip_nearest_workspace(int B, int Ma, int Nb)
 {

@@ -46,6 +46,7 @@ struct GemmArgs {
     int M, K, P, nb;
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
+    int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
     int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
                                         // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
 };
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int e = tid + i * 256, k = e / BM, m = e % BM;
-            ra[i] = a.At[(long long)min(k0 + k, a.K - 1) * a.lda + min(m0 + m, a.M - 1)];
+            const int kc = min(k0 + k, a.K - 1), mc = min(m0 + m, a.M - 1);
+            ra[i] = a.a_trans ? a.At[(long long)mc * a.lda + kc] : a.At[(long long)kc * a.lda + mc];
         }
         if (VEC) {
 #pragma unroll
@@ -770,7 +772,11 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
                                  int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                                  float* Y, float* stats, int M, int K, int P, int nb, void* stream)
 {
-    if (M < 1 || K < 1 || P < 0 || nb < 0 || lda < M) return USIP_EINVAL;
+    // lda < 0 selects the transposed storage of the matrix operand: At is [M][K] with row stride -lda
+    // (the forward product can then read W itself instead of a transposed copy made every step)
+    const int a_trans = lda < 0 ? 1 : 0;
+    if (a_trans) lda = -lda;
+    if (M < 1 || K < 1 || P < 0 || nb < 0 || lda < (a_trans ? K : M)) return USIP_EINVAL;
     if ((long long)P * nb == 0) return USIP_OK;
     if (!At || !Y || pro < 0 || pro > 3) return USIP_EINVAL;
     if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
@@ -782,7 +788,7 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
-               ablate};
+               a_trans, ablate};
     hipStream_t st = (hipStream_t)stream;
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
     return (M <= 64) ? launch_gemm<1, 4, 16>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);

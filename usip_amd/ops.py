@@ -153,13 +153,18 @@ def _opt(t):
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
-             M: Optional[int] = None, a_offset: int = 0, pool=None):
+             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
     (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,tiles,M] when want_stats)."""
     _need(At, "At", torch.float32)
-    K, lda = At.shape
-    M = lda if M is None else int(M)
+    if a_trans:                               # At is [M_total, lda]: the operand is rows [m0, m0+M) x cols [a_offset, a_offset+K)
+        M_rows, lda = At.shape
+        M = M_rows if M is None else int(M)
+        K = X2.shape[1] if X is None else X.shape[1]
+    else:
+        K, lda = At.shape
+        M = lda if M is None else int(M)
     pool_dp = pool_arg = None
     pool_group = 0
     if pool is not None:                      # pro == 3: (dpooled [nb,K,G], arg i32 [nb,K,G], group); X unused
@@ -167,7 +172,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         X = X2
     _need(X, "X", torch.float32)
     nb, Kx, P = X.shape
-    if Kx != K or a_offset < 0 or a_offset + M > lda:
+    if Kx != K or a_offset < 0 or a_offset + (K if a_trans else M) > lda:
         raise RuntimeError("mlp_gemm: operand shapes do not match (At %s, X %s, M %d, offset %d)"
                            % (tuple(At.shape), tuple(X.shape), M, a_offset))
     Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
@@ -187,7 +192,8 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P, rocprof_key=_key):
-        _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, lda, None if pool is not None else _ptr(X), _opt(X2),
+        _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, -lda if a_trans else lda,
+                                                None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group),
                                                 _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), "usip_mlp_gemm_f32")
@@ -352,6 +358,18 @@ def group_max_backward(dpooled, arg, K: int):
         _lib.check(_lib.lib().usip_group_max_backward_f32(_ptr(dpooled), _ptr(arg), _ptr(dz), B * C * M, int(K),
                                                           _stream(dpooled)), "usip_group_max_backward_f32")
     return dz
+
+
+def nearest_backward(a, b, d, arg32, gd, need_gb: bool):
+    """-> (ga [B,3,Ma], gb [B,3,Nb] or None)."""
+    B, _, Ma = a.shape
+    Nb = b.shape[2]
+    ga = torch.empty_like(a)
+    gb = torch.zeros_like(b) if need_gb else None
+    with torch.cuda.device(a.device), prof.kernel("nearest_bwd", 4.0 * B * Ma * 12):
+        _lib.check(_lib.lib().usip_nearest_backward_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg32), _ptr(gd), _ptr(ga),
+                                                        _opt(gb), B, Ma, Nb, _stream(a)), "usip_nearest_backward_f32")
+    return ga, gb
 
 
 def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
