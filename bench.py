@@ -186,18 +186,16 @@ def main():
                                 "traffic": (traffic_db.get(r.get("rocprof_key") or "", {}).get("hbm_bytes_per_launch")),
                                 "rocprof_key": r.get("rocprof_key")})
             if kernels:
-                # The dominant KERNEL (device function), all its launches in the timed region together:
-                # one gemm_kernel serves the forward and data-gradient products of every layer shape.
-                def family(label):
-                    head = label.split()[0]
-                    if head.startswith("shared_mlp_gemm"):
-                        return "gemm_kernel (shared-MLP fwd + dgrad, csrc/shared_mlp.hip)"
-                    if head.startswith("shared_mlp_wgrad"):
-                        return "wgrad_kernel (shared-MLP weight gradient, csrc/shared_mlp.hip)"
-                    return head
+                # The dominant KERNEL (device function = template instantiation, as rocprofv3 lists it), all its
+                # launches in the timed region together.
+                def family(label, r):
+                    # the device function as rocprof names it (template instantiation); launches of one
+                    # instantiation at different layer shapes are the same kernel
+                    key = r.get("rocprof_key")
+                    return key.split(" |wg=")[0] if key else label.split()[0]
                 fam = {}
                 for name, r in summ.items():
-                    f = fam.setdefault(family(name), dict(ms=0.0, calls=0, flops=0.0, nbytes=0.0, traffic=0.0,
+                    f = fam.setdefault(family(name, r), dict(ms=0.0, calls=0, flops=0.0, nbytes=0.0, traffic=0.0,
                                                           traffic_calls=0, mfma=False))
                     f["ms"] += r["total_ms"]
                     f["calls"] += r["calls"]
@@ -217,7 +215,7 @@ def main():
                 out["roofline"] = {
                     "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": (top["traffic"] / top["traffic_calls"]) if top["traffic_calls"] else None,
-                    "kernel": top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
+                    "kernel": top_name + " (csrc/shared_mlp.hip)" if top["mfma"] else top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
                     "avg_us": round(avg_s * 1e6, 2),
                     "share_of_step": round(top["ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
                     "timing": "HIP events on the launch stream, every %d-th step of the timed region (%d steps)"

@@ -247,6 +247,19 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
         colj[j] = p0 + wn * 64 + j * 32 + c;
         grpj[j] = a.rowbias ? min(colj[j], a.P - 1) / a.rb_group : 0;
     }
+    // Row bias of this tile -> LDS once ([BM][G], G = neighbourhoods the tile's columns span) instead of one
+    // global load per output element.
+    float* rbs = red + 2 * WN * BM;
+    const int g0 = a.rowbias ? p0 / a.rb_group : 0;
+    const int G = a.rowbias ? (min(p0 + BN, a.P) - 1) / a.rb_group - g0 + 1 : 0;
+    const bool rb_lds = a.rowbias && BM * G <= 2 * BK * BM - 2 * WN * BM;
+    if (rb_lds) {
+        for (int e = tid; e < BM * G; e += 256) {
+            const int rl = e / G, g = e % G;
+            rbs[e] = (m0 + rl < a.M) ? a.rowbias[((long long)b * a.M + m0 + rl) * ngrp + g0 + g] : 0.f;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -259,7 +272,9 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float v = acc[i][j][r] + bv;
-                if (a.rowbias) v += a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
+                if (a.rowbias)
+                    v += rb_lds ? rbs[row_l * G + grpj[j] - g0]
+                                : a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
                 if (row < a.M && colj[j] < a.P) {
                     Yb[(long long)row * a.P + colj[j]] = v;
                     if (STATS) { s += v; q = __builtin_fmaf(v, v, q); }
