@@ -40,7 +40,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--model", default="ball", choices=["ball", "som"])
+    ap.add_argument("--model", default="ball", choices=["ball", "som", "descriptor"],
+                    help="ball = RPN_Detector_Ball (the K=64 headline model), som = RPN_Detector, "
+                         "descriptor = DescriptorLiteOld step (BASELINE configs[4], SURVEY 8 f-1)")
     ap.add_argument("--pairs", type=int, default=8, help="pairs per GPU (B); the detector sees 2B clouds")
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--m", type=int, default=512)
@@ -108,8 +110,25 @@ def main():
 
     opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=16)
     torch.manual_seed(0)                                   # identical replicas, no broadcast needed
-    st = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer)
-    batch = batch_to_device(synth.make_pair_batch(1234 + rank, args.pairs, args.n, args.m, 4, args.cloud), dev)
+    if args.model == "descriptor":
+        # BASELINE configs[4]: N=16384, 256 keypoints, 4 (anchor, positive) pairs per GPU; keypoints are cloud
+        # points, sigmas U(0.1, 3), in-batch negatives = the next pair's anchor
+        import numpy as np
+        from usip_amd.step import DescriptorStep
+        args.no_cpu_baseline = True
+        kp = 256 if args.m == 512 else args.m
+        pairs = 4 if args.pairs == 8 else args.pairs
+        st = DescriptorStep(opt, dev, with_optimizer=not args.no_optimizer)
+        b0 = synth.make_pair_batch(1234 + rank, pairs, args.n, kp, 4, args.cloud)
+        rng = np.random.default_rng(99 + rank)
+        batch = batch_to_device(dict(anc_pc=b0["src_pc"], pos_pc=b0["dst_pc"], anc_sn=b0["src_sn"], pos_sn=b0["dst_sn"],
+                                     anc_kp=b0["src_node"], pos_kp=b0["dst_node"],
+                                     anc_sigmas=rng.uniform(0.1, 3.0, (pairs, kp)).astype(np.float32),
+                                     neg_idx=np.roll(np.arange(pairs), 1).astype(np.int64)), dev)
+        args.pairs = pairs
+    else:
+        st = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer)
+        batch = batch_to_device(synth.make_pair_batch(1234 + rank, args.pairs, args.n, args.m, 4, args.cloud), dev)
 
     def barrier():
         if world > 1:
@@ -146,13 +165,17 @@ def main():
     if rank == 0:
         clouds = world * 2 * args.pairs * args.steps
         out = {
-            "metric": "point-clouds/sec detector fwd+bwd", "value": clouds / elapsed, "unit": "point-clouds/s",
+            "metric": "point-clouds/sec %s fwd+bwd" % ("descriptor" if args.model == "descriptor" else "detector"),
+            "value": clouds / elapsed, "unit": "point-clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "KITTI detector N=%d M=%d K=64 batch=%d pairs/GPU (BASELINE configs[2])"
-                                   % (args.n, args.m, args.pairs),
-                       "detector": "RPN_Detector_Ball" if args.model == "ball" else "RPN_Detector",
+            "config": {"workload": ("KITTI descriptor head N=%d, 256 keypoints, K=64, batch=%d pairs/GPU (BASELINE "
+                                    "configs[4])" % (args.n, args.pairs)) if args.model == "descriptor" else
+                                   ("KITTI detector N=%d M=%d K=64 batch=%d pairs/GPU (BASELINE configs[2])"
+                                    % (args.n, args.m, args.pairs)),
+                       "detector": {"ball": "RPN_Detector_Ball", "som": "RPN_Detector",
+                                    "descriptor": "DescriptorLiteOld (descriptor head, 256 keypoints)"}[args.model],
                        "clouds_per_gpu": 2 * args.pairs, "surface_normal_len": 4, "node_knn_k_1": 16,
                        "ball_radius": 2, "ball_k": 64, "cloud": args.cloud,
                        "step": "fwd+losses+bwd" + ("+allreduce" if world > 1 else "") +

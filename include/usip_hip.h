@@ -98,7 +98,13 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
  * ga[b][:][i] = gd[b][i] * (a_i - b_J) / d, zero where d == 0; gb (may be NULL, else pre-zeroed)
  * receives the negative, scatter-added at J. */
 int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
-                              const float* gd, float* ga, float* gb, int B, int Ma, int Nb, void* stream);
+                              const float* gd, float* ga, float* gb, int B, int C, int Ma, int Nb, void* stream);
+
+/* f-1 (descriptor head): the same minimum / first arg-minimum for C-dimensional points a [B][C][Ma],
+ * b [B][C][Nb] (Nb <= 1024) -- the M x M descriptor-distance matrices of DescPairScanLoss
+ * (models/losses.py:207-218: torch.norm over B x C x M x M, 268 MB at B=8) are never built. */
+int usip_nearest_nd_f32(const float* a, const float* b, float* min_d, int32_t* arg,
+                        int B, int C, int Ma, int Nb, void* stream);
 
 /* ------------------------------------------------------------------ a-5 / a-6 / a-7 / a-8  shared MLP
  * Replaces, per layer, nn.Conv1d/Conv2d(k=1) + MyBatchNorm + ReLU and their autograd backward

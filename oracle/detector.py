@@ -249,6 +249,53 @@ def detector_step(P: Params, bufs, batch: Dict[str, torch.Tensor], model: str, n
     return res
 
 
+# --------------------------------------------------------------------------- descriptor head (f-1)
+def descriptor_forward(P: Params, bufs, x, sn, keypoints, perm, radius: float, K: int, train: bool = True):
+    """DescriptorLiteOld.forward (networks.py:333-385) with the random permutation given explicitly."""
+    x = x[:, :, perm]
+    sn = sn[:, :, perm]
+    x_aug = torch.cat((x, sn), dim=1)
+    dist = pairwise_norm(keypoints, x).detach()
+    ball_idx = ball_query_op(dist, radius, K).long()
+    g = gather_neighbours(x_aug, ball_idx)
+    g = torch.cat((g[:, 0:3] - keypoints.unsqueeze(3), g[:, 3:]), dim=1)
+    h = g
+    for name in ("conv1", "conv2", "conv3"):
+        h = shared_mlp(h, P, bufs, name, train)
+    pooled, _ = torch.max(h, dim=3, keepdim=True)
+    h = torch.cat((h, pooled.expand_as(h)), dim=1)
+    h = shared_mlp(h, P, bufs, "conv4", train)
+    h = shared_mlp(h, P, bufs, "conv5", train)              # no norm parameters -> plain conv
+    d, _ = torch.max(h, dim=3, keepdim=False)
+    d = d / (torch.norm(d, dim=1, keepdim=True) + 1e-5)
+    return d, g, ball_idx
+
+
+def desc_pair_scan_loss(anc, pos, neg, anc_sigmas, gamma: float, sigma_max: float):
+    """DescPairScanLoss.forward (losses.py:200-237)."""
+    d_pos, _ = torch.min(torch.norm(anc.unsqueeze(3) - pos.unsqueeze(2), dim=1), dim=2)
+    d_neg, _ = torch.min(torch.norm(anc.unsqueeze(3) - neg.unsqueeze(2), dim=1), dim=2)
+    before = d_pos - d_neg + gamma
+    active = torch.mean((before > 0).float(), dim=1)
+    w = torch.clamp(sigma_max - anc_sigmas, min=0)
+    w = (w / torch.mean(w, dim=1, keepdim=True)).detach()
+    return w * torch.clamp(before, min=0), active
+
+
+def descriptor_step(P: Params, bufs, batch, perm, radius=2, K=64, gamma=0.5, sigma_max=3.0):
+    """ModelDescriptor.optimize minus the optimizer update (keypoint_descriptor.py:126-157)."""
+    B = batch["anc_pc"].shape[0]
+    desc, feat, ball_idx = descriptor_forward(
+        P, bufs, torch.cat((batch["anc_pc"], batch["pos_pc"]), 0), torch.cat((batch["anc_sn"], batch["pos_sn"]), 0),
+        torch.cat((batch["anc_kp"], batch["pos_kp"]), 0), perm, radius, K, True)
+    anc, pos = desc[:B], desc[B:]
+    trip, active = desc_pair_scan_loss(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"], gamma, sigma_max)
+    loss = torch.mean(trip)
+    loss.backward()
+    return dict(descriptors=desc, x_features=feat, ball_idx=ball_idx, triplet=trip, active=active,
+                loss=loss.detach())
+
+
 def to_numpy(d):
     return {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
             for k, v in d.items() if v is not None}

@@ -333,11 +333,61 @@ def gen_detectors(networks, losses, som):
          **{"idx/" + k: v for k, v in rec.items()}, **out)
 
 
+def gen_descriptor(networks, losses):
+    """DescriptorLiteOld + DescPairScanLoss as ModelDescriptor.optimize drives them
+    (models/keypoint_descriptor.py:126-159), with the random point permutation of
+    networks.py:345-347 recorded (ball_query picks the FIRST K points inside the ball, so the
+    permutation is observable)."""
+    rng = np.random.default_rng(606)
+    B, N, M, Cs = 2, 2048, 32, 4
+    opt = Opt(surface_normal_len=Cs, descriptor_len=128, ball_radius=2, ball_nsamples=64,
+              triple_loss_gamma=0.5, sigma_max=3.0)
+    anc = np.stack([synth.make_cloud(rng, N, "slab:14") for _ in range(B)])
+    pos = np.stack([synth.make_cloud(rng, N, "slab:14") for _ in range(B)])
+    anc_sn = np.stack([synth.make_normals(rng, N, Cs) for _ in range(B)])
+    pos_sn = np.stack([synth.make_normals(rng, N, Cs) for _ in range(B)])
+    anc_kp = np.ascontiguousarray(np.stack([anc[b][:, rng.permutation(N)[:M]] for b in range(B)]))
+    pos_kp = np.ascontiguousarray(np.stack([pos[b][:, rng.permutation(N)[:M]] for b in range(B)]))
+    anc_kp[0, :, 0] = 500.0                         # a keypoint with an empty ball
+    anc_sigmas = rng.uniform(0.1, 3.5, (B, M)).astype(np.float32)
+    neg_idx = np.array([1, 0], dtype=np.int64)
+    perm = rng.permutation(N).astype(np.int64)
+    net = networks.DescriptorLiteOld(opt)
+    load_filled(net)
+    net.train()
+    orig = np.random.permutation
+    np.random.permutation = lambda n: perm.copy()
+    try:
+        desc, x_feat = net(torch.from_numpy(np.concatenate([anc, pos])), torch.from_numpy(np.concatenate([anc_sn, pos_sn])),
+                           torch.from_numpy(np.concatenate([anc_kp, pos_kp])), True, None)
+    finally:
+        np.random.permutation = orig
+    anc_d, pos_d = desc[:B], desc[B:]
+    net.zero_grad()
+    trip, active = losses.DescPairScanLoss(opt)(anc_d, pos_d, anc_d[torch.from_numpy(neg_idx), :, :],
+                                                torch.from_numpy(anc_sigmas))
+    loss = torch.mean(trip)
+    loss.backward()
+    out = dict(anc_pc=anc, pos_pc=pos, anc_sn=anc_sn, pos_sn=pos_sn, anc_kp=anc_kp, pos_kp=pos_kp,
+               anc_sigmas=anc_sigmas, neg_idx=neg_idx, perm=perm, descriptors=desc.detach().numpy(),
+               x_features=x_feat.detach().numpy(), triplet=trip.detach().numpy(), active=active.numpy(),
+               loss=loss.detach().numpy())
+    out.update(grad_digest(net))
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out["buf/" + k] = v.numpy().copy()
+    save("descriptor_micro.npz", **out)
+
+
 if __name__ == "__main__":
     ref_im, networks, losses, layers, som = import_reference()
+    if "--only-descriptor" in sys.argv:
+        gen_descriptor(networks, losses)
+        sys.exit(0)
     gen_index_max(ref_im)
     gen_dist_ball()
     gen_som(som)
     gen_layers(layers)
     gen_losses(losses)
     gen_detectors(networks, losses, som)
+    gen_descriptor(networks, losses)

@@ -243,3 +243,36 @@ def test_full_size_step_properties():
     st2 = DetectorStep("ball", opt, DEV)
     st2.forward_losses(batch)
     assert torch.equal(st2.last["loss"].detach(), loss1) and torch.equal(st2.last["keypoints"].detach(), kp1)
+
+
+def test_descriptor_step_matches_reference():
+    """SURVEY 8 f-1 (BASELINE configs[4] path): DescriptorLiteOld + DescPairScanLoss step against the fixture
+    captured from the reference: ball indices bit-exact, floats 1e-5, gradients flip-tolerant as above."""
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DescriptorStep, batch_to_device
+    g = load_golden("descriptor_micro.npz")
+    opt = DetectorOptions(surface_normal_len=4)
+    st = DescriptorStep(opt, DEV)
+    st.load_numpy_state(synth.fill_parameters({k: tuple(v.shape) for k, v in st.descriptor.state_dict().items()}))
+    st.descriptor.fixed_permutation = g["perm"]
+    batch = batch_to_device({k: g[k] for k in ("anc_pc", "pos_pc", "anc_sn", "pos_sn", "anc_kp", "pos_kp",
+                                               "anc_sigmas", "neg_idx")}, DEV)
+    st.step(batch)
+    torch.cuda.synchronize()
+    for k in ("descriptors", "x_features", "triplet", "active", "loss"):
+        assert_close(st.last[k].detach().cpu().numpy(), g[k], name=k)
+    from oracle import detector as od
+    ref_idx = od.ball_query_op(od.pairwise_norm(torch.from_numpy(np.concatenate([g["anc_kp"], g["pos_kp"]])),
+                                                torch.from_numpy(np.concatenate([g["anc_pc"], g["pos_pc"]]))[:, :, g["perm"]]),
+                               2.0, 64)
+    assert np.array_equal(st.descriptor.last_indices["ball_idx"].cpu().numpy(), ref_idx.numpy())
+    for k, v in st.descriptor.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(v.cpu().numpy(), g["buf/" + k], name=k)
+    biggest = max(float(v) for k, v in g.items() if k.startswith("grad_norm/"))
+    for k, p in st.descriptor.named_parameters():
+        if float(g["grad_norm/" + k]) < 1e-5 * biggest:
+            continue
+        gr = p.grad.detach().cpu().numpy().ravel().astype(np.float64)
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["grad_norm/" + k])) <= 2e-2 * float(g["grad_norm/" + k]), k

@@ -141,3 +141,32 @@ def test_detector_step_oracle_matches_reference(fix):
         assert err <= 2e-5, (k, err)
     for k, v in bufs.items():
         assert_close(v.numpy(), g["buf/" + k], name=k)
+
+
+def _descriptor_inputs(g):
+    from usip_amd import synth
+    from usip_amd.networks import DescriptorLiteOld, DetectorOptions
+    opt = DetectorOptions(surface_normal_len=4)
+    shapes = {k: tuple(v.shape) for k, v in DescriptorLiteOld(opt).state_dict().items()}
+    filled = synth.fill_parameters(shapes)
+    batch = {k: torch.from_numpy(g[k]) for k in ("anc_pc", "pos_pc", "anc_sn", "pos_sn", "anc_kp", "pos_kp",
+                                                 "anc_sigmas", "neg_idx")}
+    return opt, filled, batch
+
+
+def test_descriptor_step_oracle_matches_reference():
+    """oracle restatement of DescriptorLiteOld + DescPairScanLoss against the fixture captured
+    from the reference (ball indices from the unpinned ball_query restatement)."""
+    g = load_golden("descriptor_micro.npz")
+    opt, filled, batch = _descriptor_inputs(g)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
+         if not ("running_" in k or "num_batches" in k)}
+    bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
+    res = od.descriptor_step(P, bufs, batch, torch.from_numpy(g["perm"]))
+    for k in ("descriptors", "x_features", "triplet", "active", "loss"):
+        assert_close(res[k].detach().numpy(), g[k], rel=1e-6, name=k)
+    for k, p in P.items():
+        gn = float(g["grad_norm/" + k])
+        if gn < 1e-5 * max(float(v) for kk, v in g.items() if kk.startswith("grad_norm/")):
+            continue
+        assert_close(p.grad.numpy().ravel()[:48], g["grad_head/" + k], rel=1e-5, name=k)

@@ -89,13 +89,64 @@ __global__ __launch_bounds__(256) void nearest_merge_kernel(
     arg[i] = j;
 }
 
+// General-dimension variant for the descriptor loss (DescPairScanLoss, models/losses.py:207-218): points are
+// C-dimensional descriptors [B][C][M] (C = 128, M = 256 keypoints).  One wave per query; every lane keeps up
+// to TJ candidate partial sums in registers while the channel loop streams b[c][j] coalesced along j.
+constexpr int TJ = 16;               // candidates per lane -> Nb <= 1024
+
+__global__ __launch_bounds__(256) void nearest_nd_kernel(
+    const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ min_d,
+    int32_t* __restrict__ arg, int C, int Ma, int Nb)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    if (i >= Ma) return;
+    const float* ab = a + (long long)bi * C * Ma;
+    const float* bb = b + (long long)bi * C * Nb;
+    float s[TJ];
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) s[t] = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float av = ab[(long long)c * Ma + i];
+#pragma unroll
+        for (int t = 0; t < TJ; ++t) {
+            const int j = t * 64 + lane;
+            if (j < Nb) {
+                const float df = av - bb[(long long)c * Nb + j];
+                s[t] = __builtin_fmaf(df, df, s[t]);
+            }
+        }
+    }
+    float best = __builtin_inff();
+    int bj = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) {
+        const int j = t * 64 + lane;
+        if (j < Nb) {
+            const float d = sqrtf(s[t]);
+            if (d < best) { best = d; bj = j; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(best, off);
+        const int oj = __shfl_xor(bj, off);
+        if (od < best || (od == best && oj < bj)) { best = od; bj = oj; }
+    }
+    if (lane == 0) {
+        min_d[(long long)bi * Ma + i] = best;
+        arg[(long long)bi * Ma + i] = (bj == 0x7fffffff) ? 0 : bj;
+    }
+}
+
 // Backward of (min distance, arg-min): ga[b,:,i] = gd[b,i] * (a_i - b_J) / d (0 where d == 0, as the
 // sub-gradient of torch.norm at zero), and, when gb != null, gb[b,:,J] -= the same (float atomics: several
 // queries may share a partner).  gb must be zeroed by the caller.
 __global__ __launch_bounds__(256) void nearest_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
     const int32_t* __restrict__ arg, const float* __restrict__ gd, float* __restrict__ ga,
-    float* __restrict__ gb, int Ma, int Nb)
+    float* __restrict__ gb, int C, int Ma, int Nb)
 {
     const int bi = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -104,26 +155,38 @@ __global__ __launch_bounds__(256) void nearest_bwd_kernel(
     const int j = arg[q];
     const float dist = d[q];
     const float sc = dist > 0.f ? gd[q] / dist : 0.f;
-    const float* ab = a + (long long)bi * 3 * Ma;
-    const float* bb = b + (long long)bi * 3 * Nb;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float g = (ab[c * Ma + i] - bb[c * Nb + j]) * sc;
-        ga[((long long)bi * 3 + c) * Ma + i] = g;
-        if (gb) atomicAdd(&gb[((long long)bi * 3 + c) * Nb + j], -g);
+    const float* ab = a + (long long)bi * C * Ma;
+    const float* bb = b + (long long)bi * C * Nb;
+    for (int c = 0; c < C; ++c) {
+        const float g = (ab[(long long)c * Ma + i] - bb[(long long)c * Nb + j]) * sc;
+        ga[((long long)bi * C + c) * Ma + i] = g;
+        if (gb) atomicAdd(&gb[((long long)bi * C + c) * Nb + j], -g);
     }
 }
 
 }  // namespace
 
 extern "C" int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
-                                         const float* gd, float* ga, float* gb, int B, int Ma, int Nb, void* stream)
+                                         const float* gd, float* ga, float* gb, int B, int C, int Ma, int Nb,
+                                         void* stream)
 {
-    if (B < 0 || Ma < 0 || Nb < 1) return USIP_EINVAL;
+    if (B < 0 || Ma < 0 || Nb < 1 || C < 1) return USIP_EINVAL;
     if ((long long)B * Ma == 0) return USIP_OK;
     if (!a || !b || !d || !arg || !gd || !ga || B > 65535) return USIP_EINVAL;
     USIP_LAUNCH(nearest_bwd_kernel, dim3(usip_ceil_div(Ma, 256), B), dim3(256), 0, (hipStream_t)stream,
-                a, b, d, arg, gd, ga, gb, Ma, Nb);
+                a, b, d, arg, gd, ga, gb, C, Ma, Nb);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_nearest_nd_f32(const float* a, const float* b, float* min_d, int32_t* arg,
+                                   int B, int C, int Ma, int Nb, void* stream)
+{
+    if (B < 0 || C < 1 || Ma < 0 || Nb < 1 || Nb > 64 * TJ) return USIP_EINVAL;
+    if ((long long)B * Ma == 0) return USIP_OK;
+    if (!a || !b || !min_d || !arg || B > 65535) return USIP_EINVAL;
+    USIP_LAUNCH(nearest_nd_kernel, dim3(usip_ceil_div(Ma, 4), B), dim3(256), 0, (hipStream_t)stream,
+                a, b, min_d, arg, C, Ma, Nb);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -45,7 +45,7 @@ class _NearestDistance(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
-        d, arg32 = ops.nearest(a, b)
+        d, arg32 = ops.nearest(a, b) if a.shape[1] == 3 else ops.nearest_nd(a, b)
         arg = arg32.long()
         ctx.save_for_backward(a, b, d, arg32)
         ctx.mark_non_differentiable(arg)
@@ -62,7 +62,8 @@ class _NearestDistance(torch.autograd.Function):
 
 
 def nearest_distance(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """a [B,3,Ma], b [B,3,Nb] -> (min distance [B,Ma], arg-min int64 [B,Ma])."""
+    """a [B,C,Ma], b [B,C,Nb] -> (min distance [B,Ma], arg-min int64 [B,Ma]).  C == 3: coordinates (exact
+    oracle arithmetic); any other C: descriptors (Nb <= 1024)."""
     require_device(a, "nearest_distance")
     return _NearestDistance.apply(a, b)
 

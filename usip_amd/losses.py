@@ -59,3 +59,24 @@ class KeypointOnPCLoss(nn.Module):
         if sn is not None:
             raise NotImplementedError("usip_amd: point_to_plane keypoint-on-pc loss is outside the path")
         return self.single_side_chamfer(keypoint, pc)
+
+
+class DescPairScanLoss(nn.Module):
+    """Descriptor triplet loss with in-batch negatives (models/losses.py:190-237):
+    for every anchor keypoint the nearest positive-scan and nearest negative-scan descriptor,
+    clamp(d_pos - d_neg + gamma, 0) weighted by clamp(sigma_max - sigma, 0) normalised to mean 1.
+    forward(anc BxCxM, pos BxCxM, neg BxCxM, anc_sigmas BxM) -> (loss BxM, active_percentage B).
+    The two B x C x M x M difference tensors of the reference are replaced by the fused nearest kernel."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+
+    def forward(self, anc_descriptors, pos_descriptors, neg_descriptors, anc_sigmas):
+        d_pos, _ = Fh.nearest_distance(anc_descriptors, pos_descriptors)
+        d_neg, _ = Fh.nearest_distance(anc_descriptors, neg_descriptors)
+        before_clamp = d_pos - d_neg + self.opt.triple_loss_gamma
+        active_percentage = torch.mean((before_clamp > 0).float(), dim=1)
+        w = torch.clamp(self.opt.sigma_max - anc_sigmas, min=0)
+        w = (w / torch.mean(w, dim=1, keepdim=True)).detach()
+        return w * torch.clamp(before_clamp, min=0), active_percentage

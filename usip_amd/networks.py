@@ -135,6 +135,53 @@ class RPN_Detector_Ball(_DetectorTail):
         return node, keypoints, sigmas, None
 
 
+class DescriptorLiteOld(nn.Module):
+    """Descriptor head (models/networks.py:310-385): ball grouping around the detected
+    keypoints (radius opt.ball_radius, opt.ball_nsamples samples) -> conv1..3 -> max over K -> conv4 on
+    cat(features, max) -> conv5 (plain conv) -> max over K -> L2 normalisation.
+    forward(x Bx3xN, sn BxCsxN, keypoints Bx3xM) -> (descriptor BxCxM, x_features Bx(3+Cs)xMxK).
+
+    The reference permutes the points with np.random.permutation on every call (networks.py:345-347)
+    because ball_query keeps the FIRST K points inside the ball; set `fixed_permutation` (int64 array or
+    tensor of length N) to make a call reproducible."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        d = int(opt.descriptor_len)
+        kw = dict(kernel_size=(1, 1), stride=1, padding=0, bias=True, activation=opt.activation,
+                  normalization=opt.normalization, **_bn_kw(opt))
+        self.conv1 = MyConv2d(3 + opt.surface_normal_len, d // 4, **kw)
+        self.conv2 = MyConv2d(d // 4, d // 2, **kw)
+        self.conv3 = MyConv2d(d // 2, d, **kw)
+        self.conv4 = MyConv2d(2 * d, d, **kw)
+        self.conv5 = MyConv2d(d, d, kernel_size=(1, 1), stride=1, padding=0, bias=True,
+                              activation=None, normalization=None)
+        self.fixed_permutation = None
+
+    def forward(self, x, sn, keypoints, is_train=False, epoch=None):
+        Fh.require_device(x, "DescriptorLiteOld")
+        import numpy as np
+        N, K = x.shape[2], int(self.opt.ball_nsamples)
+        perm = self.fixed_permutation if self.fixed_permutation is not None else np.random.permutation(N)
+        perm = torch.as_tensor(perm, dtype=torch.int64, device=x.device)       # networks.py:345-347
+        x = x[:, :, perm].contiguous()
+        x_aug = torch.cat((x, sn[:, :, perm]), dim=1) if self.opt.surface_normal_len > 0 else x
+        keypoints = keypoints.detach().contiguous()
+        ball_idx32 = ops.ball_query_coords(keypoints, x, float(self.opt.ball_radius), K)      # :352-356 fused
+        x_features = ops.group_gather(x_aug.contiguous(), ball_idx32, sub=keypoints)          # :358-370
+        h = self.conv3(self.conv2(self.conv1(x_features, defer=True), defer=True), defer=True)   # :373
+        pooled = Fh.group_max(h)                                                               # :374
+        h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
+                                     getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
+                                     pooled_first=False, defer=True)                           # :375-377
+        y = self.conv5(h)                                                                      # plain conv
+        descriptor = Fh.group_max(y)                                                           # :379
+        descriptor = descriptor / (torch.norm(descriptor, dim=1, keepdim=True) + 1e-5)         # :380
+        self.last_indices = dict(ball_idx=ball_idx32)
+        return descriptor, x_features
+
+
 class DetectorOptions:
     """The fields of the reference's argparse namespace that the detector path reads
     (kitti/options_detector.py:14-60), with the KITTI defaults."""
@@ -152,6 +199,12 @@ class DetectorOptions:
         self.keypoint_on_pc_alpha = 0.01
         self.keypoint_on_pc_type = "point_to_point"
         self.lr = 0.001
+        # descriptor head (kitti/options_descriptor.py:53-59)
+        self.descriptor_len = 128
+        self.ball_radius = 2
+        self.ball_nsamples = 64
+        self.triple_loss_gamma = 0.5
+        self.sigma_max = 3.0
         for k, v in kw.items():
             setattr(self, k, v)
 

@@ -360,15 +360,30 @@ def group_max_backward(dpooled, arg, K: int):
     return dz
 
 
+def nearest_nd(a: torch.Tensor, b: torch.Tensor):
+    """f-1: (min_j |a_i - b_j| [B,Ma], first arg-min i32 [B,Ma]) for C-dimensional a [B,C,Ma], b [B,C,Nb<=1024]."""
+    _need(a, "a", torch.float32)
+    _need(b, "b", torch.float32)
+    B, C, Ma = a.shape
+    Nb = b.shape[2]
+    d = torch.empty((B, Ma), dtype=torch.float32, device=a.device)
+    arg = torch.empty((B, Ma), dtype=torch.int32, device=a.device)
+    with torch.cuda.device(a.device), prof.kernel("nearest_nd", 4.0 * B * C * (Ma + Nb), 3.0 * B * C * Ma * Nb):
+        _lib.check(_lib.lib().usip_nearest_nd_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg), B, C, Ma, Nb, _stream(a)),
+                   "usip_nearest_nd_f32")
+    return d, arg
+
+
 def nearest_backward(a, b, d, arg32, gd, need_gb: bool):
-    """-> (ga [B,3,Ma], gb [B,3,Nb] or None)."""
-    B, _, Ma = a.shape
+    """-> (ga [B,C,Ma], gb [B,C,Nb] or None)."""
+    B, C, Ma = a.shape
     Nb = b.shape[2]
     ga = torch.empty_like(a)
     gb = torch.zeros_like(b) if need_gb else None
     with torch.cuda.device(a.device), prof.kernel("nearest_bwd", 4.0 * B * Ma * 12):
         _lib.check(_lib.lib().usip_nearest_backward_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg32), _ptr(gd), _ptr(ga),
-                                                        _opt(gb), B, Ma, Nb, _stream(a)), "usip_nearest_backward_f32")
+                                                        _opt(gb), B, C, Ma, Nb, _stream(a)),
+                   "usip_nearest_backward_f32")
     return ga, gb
 
 

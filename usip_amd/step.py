@@ -99,6 +99,49 @@ class DetectorStep:
         return loss
 
 
+class DescriptorStep:
+    """ModelDescriptor.optimize (models/keypoint_descriptor.py:126-159): siamese descriptor forward on
+    cat(anchor, positive), triplet loss with in-batch negatives, backward (+ all-reduce) (+ Adam)."""
+
+    def __init__(self, opt, device, with_optimizer: bool = False):
+        from .losses import DescPairScanLoss
+        from .networks import DescriptorLiteOld
+        self.opt = opt
+        self.device = torch.device(device)
+        self.descriptor = DescriptorLiteOld(opt).to(self.device)
+        self.triplet_criteria = DescPairScanLoss(opt)
+        self.bucket = FlatGradBucket(self.descriptor)
+        self.optimizer = torch.optim.Adam(self.descriptor.parameters(), lr=opt.lr, betas=(0.9, 0.999)) \
+            if with_optimizer else None
+        self.last: Dict[str, torch.Tensor] = {}
+
+    def load_numpy_state(self, state: Dict):
+        sd = self.descriptor.state_dict()
+        self.descriptor.load_state_dict({k: torch.as_tensor(v).reshape(sd[k].shape) for k, v in state.items()})
+
+    def step(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None, group=None):
+        from . import functional as Fh
+        B = batch["anc_pc"].shape[0]
+        self.bucket.zero()
+        Fh.GRAD_SINK = True
+        try:
+            self.descriptor.train()
+            desc, x_feat = self.descriptor(torch.cat((batch["anc_pc"], batch["pos_pc"]), 0),
+                                           torch.cat((batch["anc_sn"], batch["pos_sn"]), 0),
+                                           torch.cat((batch["anc_kp"], batch["pos_kp"]), 0), True, epoch)
+            anc, pos = desc[:B], desc[B:]
+            triplet, active = self.triplet_criteria(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"])
+            loss = torch.mean(triplet)
+            loss.backward()
+        finally:
+            Fh.GRAD_SINK = False
+        self.bucket.all_reduce_mean(group)
+        if self.optimizer is not None:
+            self.optimizer.step()
+        self.last = dict(descriptors=desc, x_features=x_feat, triplet=triplet, active=active, loss=loss)
+        return loss
+
+
 def batch_to_device(batch_np: Dict, device) -> Dict[str, torch.Tensor]:
     return {k: torch.as_tensor(v).to(device) for k, v in batch_np.items()}
 
