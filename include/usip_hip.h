@@ -208,6 +208,21 @@ int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float*
 int usip_knn_f32(const float* query, const float* database, int32_t* idx,
                  int B, int M, int N, int K, void* stream);
 
+/* ------------------------------------------------------------------ f-3  farthest-point sampling of nodes
+ * Replaces FarthestSampler.sample (data/kitti_detector_loader.py:69-83; also oxford_detector_loader.py,
+ * modelnet_shrec_loader.py): out_idx[b][0] = first_idx[b], then k-1 times the first arg-max of the running
+ * minimum squared distance, evaluated in float64 exactly as numpy does.  pts f32 [B][3][n], n <= 16384;
+ * out_idx i32 [B][k] (indices into the n points; gather them for the node coordinates). */
+int usip_fps_f32(const float* pts, const int32_t* first_idx, int32_t* out_idx, int B, int n, int k, void* stream);
+
+/* ------------------------------------------------------------------ f-4  inference post-processing
+ * Greedy non-maximum suppression by sigma (evaluation/save_keypoints.py:180-216): order[b][0..count[b]) are
+ * the indices kept, in the order they are picked (ascending sigma; ties: lower index), each pick removing every
+ * keypoint whose float32 distance to it is not > radius.  keypoints f32 [B][3][M], sigmas f32 [B][M], M <= 1024.
+ * The reference's "keep the desired_keypoint_num smallest sigmas" (:346-351) is the first entries of order. */
+int usip_nms_f32(const float* keypoints, const float* sigmas, float radius, int32_t* order, int32_t* count,
+                 int B, int M, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

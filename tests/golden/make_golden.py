@@ -379,8 +379,71 @@ def gen_descriptor(networks, losses):
     save("descriptor_micro.npz", **out)
 
 
+def _extract(path, name):
+    """Compile ONE top-level function / class of a reference file (found with ast) into a namespace, so the
+    reference's own code runs without importing a module whose other imports are absent here."""
+    import ast
+    src = open(path).read()
+    node = next(n for n in ast.parse(src).body if getattr(n, "name", None) == name)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def gen_pre_post(networks):
+    """f-3 farthest-point sampling and f-4 NMS / top-k: outputs of the reference's own FarthestSampler
+    (data/kitti_detector_loader.py:69-83) and nms() (evaluation/save_keypoints.py:180-216), plus an eval-mode
+    forward of RPN_Detector (keypoint_detector.py:247-251)."""
+    rng = np.random.default_rng(707)
+    Sampler = _extract("/root/reference/data/kitti_detector_loader.py", "FarthestSampler")
+    nms = _extract("/root/reference/evaluation/save_keypoints.py", "nms")
+    out = {}
+    # FPS: 3 clouds, n = 1800 points, k = 96 nodes; the reference draws the first index with np.random.randint
+    B, n, k = 3, 1800, 96
+    pts = np.stack([synth.make_cloud(rng, n, "slab:20").T.copy() for _ in range(B)])       # [B,n,3]
+    first = rng.integers(0, n, B)
+    orig = np.random.randint
+    sel = []
+    for b in range(B):
+        np.random.randint = lambda *a, **kw: int(first[b])
+        try:
+            far = Sampler().sample(pts[b], k)                                              # [k,3] float64
+        finally:
+            np.random.randint = orig
+        idx = [int(np.nonzero((pts[b].astype(np.float64) == far[i]).all(1))[0][0]) for i in range(k)]
+        sel.append(idx)
+    out.update(fps_pts=pts, fps_first=first.astype(np.int32), fps_idx=np.asarray(sel, dtype=np.int32))
+    # NMS + top-k: 2 clouds of 256 keypoints
+    M = 256
+    kp = np.stack([synth.make_cloud(rng, M, "slab:12").T.copy() for _ in range(2)])        # [2,M,3]
+    sg = rng.uniform(0.01, 2.0, (2, M)).astype(np.float32)
+    sg[0, 10] = sg[0, 3]                                                                   # a sigma tie
+    for b in range(2):
+        vk, vs = nms(kp[b], sg[b], 2.0)
+        out["nms_kept_%d" % b] = vk.astype(np.float32)
+        out["nms_sigma_%d" % b] = vs.astype(np.float32)
+        order = np.argsort(vs)[:40]
+        out["nms_top40_%d" % b] = vk[order].astype(np.float32)
+    out.update(nms_kp=kp, nms_sigma=sg, nms_radius=np.float32(2.0))
+    # eval-mode forward
+    opt = Opt(surface_normal_len=3, node_knn_k_1=8, loss_sigma_lower_bound=1e-3)
+    batch = synth.make_pair_batch(seed=808, pairs=1, n=1024, m=32, cs=3, kind="sphere")
+    net = networks.RPN_Detector(opt)
+    load_filled(net)
+    net.eval()
+    with torch.no_grad():
+        _, kpt, sig, _ = net(torch.from_numpy(batch["src_pc"]), torch.from_numpy(batch["src_sn"]),
+                             torch.from_numpy(batch["src_node"]), False, None)
+    out.update(eval_pc=batch["src_pc"], eval_sn=batch["src_sn"], eval_node=batch["src_node"],
+               eval_keypoints=kpt.numpy(), eval_sigmas=sig.numpy())
+    save("pre_post_cases.npz", **out)
+
+
 if __name__ == "__main__":
     ref_im, networks, losses, layers, som = import_reference()
+    if "--only-prepost" in sys.argv:
+        gen_pre_post(networks)
+        sys.exit(0)
     if "--only-descriptor" in sys.argv:
         gen_descriptor(networks, losses)
         sys.exit(0)
@@ -391,3 +454,4 @@ if __name__ == "__main__":
     gen_losses(losses)
     gen_detectors(networks, losses, som)
     gen_descriptor(networks, losses)
+    gen_pre_post(networks)

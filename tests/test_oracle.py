@@ -170,3 +170,35 @@ def test_descriptor_step_oracle_matches_reference():
         if gn < 1e-5 * max(float(v) for kk, v in g.items() if kk.startswith("grad_norm/")):
             continue
         assert_close(p.grad.numpy().ravel()[:48], g["grad_head/" + k], rel=1e-5, name=k)
+
+
+def test_fps_and_nms_oracles_match_reference_functions():
+    """f-3 / f-4: numpy restatements against outputs of the reference's own FarthestSampler and nms()."""
+    from oracle import postproc
+    g = load_golden("pre_post_cases.npz")
+    for b in range(g["fps_pts"].shape[0]):
+        idx = postproc.fps_indices(g["fps_pts"][b], int(g["fps_first"][b]), g["fps_idx"].shape[1])
+        assert np.array_equal(idx, g["fps_idx"][b])
+    for b in range(2):
+        order = postproc.nms_order(g["nms_kp"][b], g["nms_sigma"][b], float(g["nms_radius"]))
+        assert np.array_equal(g["nms_kp"][b][order], g["nms_kept_%d" % b])
+        assert np.array_equal(g["nms_sigma"][b][order], g["nms_sigma_%d" % b])
+        top = postproc.export_keypoints(g["nms_kp"][b], g["nms_sigma"][b], float(g["nms_radius"]), 40)
+        assert np.array_equal(top, g["nms_top40_%d" % b])
+
+
+def test_checkpoint_prefix_fixup_and_bin_format(tmp_path):
+    """f-4 host logic: 'module.'-prefixed checkpoints load (kitti/train_detector.py:42-51); the .bin file is
+    float32 M x 3 row-major (save_keypoints.py:392-393)."""
+    from usip_amd import inference
+    from usip_amd.networks import DetectorOptions, build_detector
+    net = build_detector("som", DetectorOptions(surface_normal_len=3))
+    sd = {"module." + k: v.clone() + 1 for k, v in net.state_dict().items() if v.dtype.is_floating_point}
+    sd.update({"module." + k: v for k, v in net.state_dict().items() if not v.dtype.is_floating_point})
+    inference.load_detector_state(net, sd)
+    assert torch.equal(net.mlp3.conv.bias, sd["module.mlp3.conv.bias"])
+    kp = np.arange(12, dtype=np.float64).reshape(4, 3)
+    path = str(tmp_path / "000001.bin")
+    inference.write_keypoints_bin(path, kp)
+    back = np.fromfile(path, dtype=np.float32).reshape(-1, 3)
+    assert np.array_equal(back, kp.astype(np.float32))

@@ -1,0 +1,86 @@
+"""GPU parity of the steps either side of the detector path: farthest-point sampling,
+eval-mode forward, sigma-ordered NMS + top-k export -- against outputs of the reference's own functions
+(tests/golden/pre_post_cases.npz) and against the numpy oracle at larger sizes."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden
+from oracle import postproc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_fps_matches_reference_sampler():
+    from usip_amd import inference, ops
+    g = load_golden("pre_post_cases.npz")
+    pts = torch.from_numpy(np.ascontiguousarray(g["fps_pts"].transpose(0, 2, 1))).to(DEV)     # [B,3,n]
+    first = torch.from_numpy(g["fps_first"]).to(DEV)
+    k = g["fps_idx"].shape[1]
+    idx = ops.fps(pts, first, k)
+    assert np.array_equal(idx.cpu().numpy(), g["fps_idx"])
+    nodes = inference.sample_nodes(pts, k, first)
+    want = np.take_along_axis(g["fps_pts"], g["fps_idx"][:, :, None].astype(np.int64), axis=1).transpose(0, 2, 1)
+    assert np.array_equal(nodes.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("shape", [(2, 5461, 512), (1, 16384, 64), (3, 100, 100), (1, 1500, 1)])
+def test_fps_vs_oracle_at_loader_sizes(shape):
+    """KITTI loader size: N/3 = 5461 candidates, 512 nodes (kitti_detector_loader.py:144)."""
+    from usip_amd import ops, synth
+    B, n, k = shape
+    rng = np.random.default_rng(n + k)
+    pts = np.stack([synth.make_cloud(rng, n, "slab") for _ in range(B)])
+    first = rng.integers(0, n, B).astype(np.int32)
+    got = ops.fps(torch.from_numpy(pts).to(DEV), torch.from_numpy(first).to(DEV), k).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], postproc.fps_indices(pts[b].T, int(first[b]), k))
+
+
+def test_nms_and_topk_match_reference_nms():
+    from usip_amd import inference
+    g = load_golden("pre_post_cases.npz")
+    kp = torch.from_numpy(np.ascontiguousarray(g["nms_kp"].transpose(0, 2, 1))).to(DEV)      # [B,3,M]
+    sg = torch.from_numpy(g["nms_sigma"]).to(DEV)
+    full = inference.select_keypoints(kp, sg, float(g["nms_radius"]), 10 ** 6)
+    top = inference.select_keypoints(kp, sg, float(g["nms_radius"]), 40)
+    for b in range(2):
+        assert np.array_equal(full[b], g["nms_kept_%d" % b])
+        assert np.array_equal(top[b], g["nms_top40_%d" % b])
+    # NMS disabled (radius < 0.01): everything kept, ascending sigma
+    none = inference.select_keypoints(kp, sg, 0.0, 10 ** 6)
+    assert none[0].shape == (g["nms_kp"].shape[1], 3)
+    assert np.array_equal(none[1], g["nms_kp"][1][np.argsort(g["nms_sigma"][1], kind="stable")])
+
+
+@pytest.mark.parametrize("M,radius", [(512, 2.0), (1000, 0.7), (64, 50.0)])
+def test_nms_vs_oracle(M, radius):
+    from usip_amd import ops, synth
+    rng = np.random.default_rng(M)
+    B = 3
+    kp = np.stack([synth.make_cloud(rng, M, "slab:15") for _ in range(B)])
+    sg = rng.uniform(0.001, 3.0, (B, M)).astype(np.float32)
+    order, count = ops.nms(torch.from_numpy(kp).to(DEV), torch.from_numpy(sg).to(DEV), radius)
+    order, count = order.cpu().numpy(), count.cpu().numpy()
+    for b in range(B):
+        want = postproc.nms_order(kp[b].T.copy(), sg[b], radius)
+        assert int(count[b]) == len(want) and np.array_equal(order[b, :len(want)], want)
+
+
+def test_eval_mode_forward_matches_reference_run_model():
+    """run_model (keypoint_detector.py:247-251): eval mode uses the BatchNorm running statistics."""
+    from usip_amd import inference, synth
+    from usip_amd.networks import DetectorOptions, build_detector
+    g = load_golden("pre_post_cases.npz")
+    opt = DetectorOptions(surface_normal_len=3, node_knn_k_1=8, loss_sigma_lower_bound=1e-3)
+    net = build_detector("som", opt)
+    sd = net.state_dict()
+    filled = synth.fill_parameters({k: tuple(v.shape) for k, v in sd.items()})
+    inference.load_detector_state(net, {"module." + k: torch.from_numpy(np.asarray(v)).reshape(sd[k].shape)
+                                        for k, v in filled.items()})
+    net = net.to(DEV)
+    kp, sig = inference.run_model(net, torch.from_numpy(g["eval_pc"]).to(DEV), torch.from_numpy(g["eval_sn"]).to(DEV),
+                                  torch.from_numpy(g["eval_node"]).to(DEV))
+    assert_close(kp.cpu().numpy(), g["eval_keypoints"], name="keypoints")
+    assert_close(sig.cpu().numpy(), g["eval_sigmas"], name="sigmas")

@@ -400,6 +400,31 @@ def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
+def fps(pts: torch.Tensor, first_idx: torch.Tensor, k: int) -> torch.Tensor:
+    """f-3: farthest-point sampling. pts f32 [B,3,n], first_idx i32 [B] -> i32 [B,k] indices."""
+    _need_pts(pts, "pts")
+    _need(first_idx, "first_idx", torch.int32)
+    B, _, n = pts.shape
+    out = torch.empty((B, int(k)), dtype=torch.int32, device=pts.device)
+    with torch.cuda.device(pts.device), prof.kernel("fps", 12.0 * B * n, 8.0 * B * n * k):
+        _lib.check(_lib.lib().usip_fps_f32(_ptr(pts), _ptr(first_idx), _ptr(out), B, n, int(k), _stream(pts)),
+                   "usip_fps_f32")
+    return out
+
+
+def nms(keypoints: torch.Tensor, sigmas: torch.Tensor, radius: float):
+    """f-4: greedy NMS by sigma. keypoints f32 [B,3,M], sigmas f32 [B,M] -> (order i32 [B,M], count i32 [B])."""
+    _need_pts(keypoints, "keypoints")
+    _need(sigmas, "sigmas", torch.float32)
+    B, _, M = keypoints.shape
+    order = torch.zeros((B, M), dtype=torch.int32, device=keypoints.device)
+    count = torch.empty((B,), dtype=torch.int32, device=keypoints.device)
+    with torch.cuda.device(keypoints.device), prof.kernel("nms", 16.0 * B * M):
+        _lib.check(_lib.lib().usip_nms_f32(_ptr(keypoints), _ptr(sigmas), float(radius), _ptr(order), _ptr(count),
+                                           B, M, _stream(keypoints)), "usip_nms_f32")
+    return order, count
+
+
 def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:
     """index_max.forward_cpu / forward_multi_thread_cpu (index_max.cpp:33-112): HOST tensors."""
     for t, name, dt in ((data, "data", torch.float32), (index, "index", torch.int32)):
