@@ -77,6 +77,16 @@ def main():
             fh.write("%7d %11.1f %10.2f %7.2f %10s %10s  %s\n" % (
                 n, tot, avg, pct, "%.2f" % (rd / 1e6) if rd is not None else "-",
                 "%.2f" % (wr / 1e6) if wr is not None else "-", k[:110]))
+        # per device function (all launch geometries together): what bench.py's `roofline.kernel` refers to
+        sym = defaultdict(lambda: [0, 0.0])
+        for k, n, tot, avg, pct, rd, wr in rows:
+            name = k.split(" |wg=")[0]
+            sym[name][0] += n
+            sym[name][1] += tot
+        fh.write("\n# per device function, all launch geometries together\n")
+        fh.write("%7s %11s %10s %7s  %s\n" % ("calls", "total_us", "avg_us", "share%", "kernel"))
+        for name, (n, tot) in sorted(sym.items(), key=lambda kv: -kv[1][1])[:25]:
+            fh.write("%7d %11.1f %10.2f %7.2f  %s\n" % (n, tot, tot / n, 100 * tot / total, name[:120]))
     json.dump(traffic, open(out_json, "w"), indent=1)
     print(open(out_txt).read()[:6000])
 
