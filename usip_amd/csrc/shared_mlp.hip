@@ -46,6 +46,8 @@ struct GemmArgs {
     int M, K, P, nb;
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
+    const float* epi_y; const float* epi_coef;   // EPI_BWD_STATS: Y is dZ of a layer whose pre-BN output is epi_y
+                                        // [nb][M][P] and whose (a1, a0, mean, invstd) are epi_coef [4][M]
     int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
     int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
                                         // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
@@ -65,7 +67,13 @@ __device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1
     return x;
 }
 
-template <int WM, int WN, int BK, int PRO, bool STATS, bool VEC>
+// EPI: 0 none | 1 forward BatchNorm statistics of Y (sum, sum^2) | 2 BACKWARD statistics: Y is the gradient
+// dZ w.r.t. the activated output of the layer that produced this GEMM's input; with that layer's pre-BN
+// output y (epi_y) the epilogue accumulates sum(dYhat) and sum(dYhat * yhat), dYhat = dZ * [y*a1+a0 > 0],
+// so the producing layer's BatchNorm backward needs no separate pass over (dZ, y).
+enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BWD_STATS = 2 };
+
+template <int WM, int WN, int BK, int PRO, int EPI, bool VEC>
 __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -262,12 +270,29 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        // EPI_BWD_STATS: the 32 y values this lane needs for tile row-block i, as 32 independent loads from
+        // clamped addresses issued back to back (one load-use-wait per element would be 64 serial HBM trips)
+        float yv[EPI == EPI_BWD_STATS ? 16 : 1][2];
+        if (EPI == EPI_BWD_STATS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    yv[r][j] = a.epi_y[((long long)b * a.M + rowc) * a.P + min(colj[j], a.P - 1)];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int row = m0 + row_l;
             const int rowc = min(row, a.M - 1);
             const float bv = a.bias ? a.bias[rowc] : 0.0f;
+            float e1 = 0.f, e0 = 0.f, emu = 0.f, eis = 0.f;
+            if (EPI == EPI_BWD_STATS) {
+                e1 = a.epi_coef[rowc]; e0 = a.epi_coef[a.M + rowc];
+                emu = a.epi_coef[2 * a.M + rowc]; eis = a.epi_coef[3 * a.M + rowc];
+            }
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -277,10 +302,16 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
                                 : a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
                 if (row < a.M && colj[j] < a.P) {
                     Yb[(long long)row * a.P + colj[j]] = v;
-                    if (STATS) { s += v; q = __builtin_fmaf(v, v, q); }
+                    if (EPI == EPI_STATS) { s += v; q = __builtin_fmaf(v, v, q); }
+                    if (EPI == EPI_BWD_STATS) {
+                        const float yy = yv[EPI == EPI_BWD_STATS ? r : 0][j];
+                        const float d = (__builtin_fmaf(yy, e1, e0) > 0.f) ? v : 0.f;
+                        s += d;
+                        q = __builtin_fmaf(d, (yy - emu) * eis, q);
+                    }
                 }
             }
-            if (STATS) {
+            if (EPI != EPI_NONE) {
                 // 32-lane sum: four DPP steps inside each row of 16 lanes (VALU, no LDS crossbar), then one
                 // cross-row exchange
                 s = usip_row16_sum(s); q = usip_row16_sum(q);
@@ -292,7 +323,7 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
             }
         }
     }
-    if (STATS) {
+    if (EPI != EPI_NONE) {
         __syncthreads();
         if (tid < BM && m0 + tid < a.M) {
             float s = 0.f, q = 0.f;
@@ -314,25 +345,30 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     if (total > 0x7fffffffLL) return USIP_EINVAL;
     const bool vec = (a.P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(a.X) & 15u) == 0) &&
                      ((pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) || (reinterpret_cast<uintptr_t>(a.X2) & 15u) == 0);
-    const bool stats = a.stats != nullptr;
+    const int epi = a.stats == nullptr ? EPI_NONE : (a.epi_y ? EPI_BWD_STATS : EPI_STATS);
     dim3 grid((unsigned)total), block(256);
-#define USIP_GEMM_CASE(P_, S_, V_)                                                              \
-    if (pro == P_ && stats == S_ && vec == V_) {                                                \
-        USIP_LAUNCH((gemm_kernel<WM, WN, BK, P_, S_, V_>), grid, block, 0, st, a);                  \
+#define USIP_GEMM_CASE(P_, E_, V_)                                                              \
+    if (pro == P_ && epi == E_ && vec == V_) {                                                  \
+        USIP_LAUNCH((gemm_kernel<WM, WN, BK, P_, E_, V_>), grid, block, 0, st, a);              \
         USIP_LAUNCH_CHECK();                                                                    \
         return USIP_OK;                                                                         \
     }
-    USIP_GEMM_CASE(PRO_NONE, true, true)
-    USIP_GEMM_CASE(PRO_NONE, true, false)
-    USIP_GEMM_CASE(PRO_NONE, false, true)
-    USIP_GEMM_CASE(PRO_NONE, false, false)
-    USIP_GEMM_CASE(PRO_AFFINE_RELU, true, true)
-    USIP_GEMM_CASE(PRO_AFFINE_RELU, true, false)
-    USIP_GEMM_CASE(PRO_AFFINE_RELU, false, true)
-    USIP_GEMM_CASE(PRO_AFFINE_RELU, false, false)
-    USIP_GEMM_CASE(PRO_BN_BWD, false, true)
-    USIP_GEMM_CASE(PRO_BN_BWD, false, false)
-    USIP_GEMM_CASE(PRO_BN_BWD_POOL, false, true)
+    USIP_GEMM_CASE(PRO_NONE, EPI_STATS, true)
+    USIP_GEMM_CASE(PRO_NONE, EPI_STATS, false)
+    USIP_GEMM_CASE(PRO_NONE, EPI_NONE, true)
+    USIP_GEMM_CASE(PRO_NONE, EPI_NONE, false)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, EPI_STATS, true)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, EPI_STATS, false)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, EPI_NONE, true)
+    USIP_GEMM_CASE(PRO_AFFINE_RELU, EPI_NONE, false)
+    USIP_GEMM_CASE(PRO_BN_BWD, EPI_NONE, true)
+    USIP_GEMM_CASE(PRO_BN_BWD, EPI_NONE, false)
+    USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_NONE, true)
+    USIP_GEMM_CASE(PRO_NONE, EPI_BWD_STATS, true)
+    USIP_GEMM_CASE(PRO_NONE, EPI_BWD_STATS, false)
+    USIP_GEMM_CASE(PRO_BN_BWD, EPI_BWD_STATS, true)
+    USIP_GEMM_CASE(PRO_BN_BWD, EPI_BWD_STATS, false)
+    USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_BWD_STATS, true)
 #undef USIP_GEMM_CASE
     return USIP_EINVAL;
 }
@@ -596,6 +632,8 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(
         invstd_out[ch] = invstd;
         coef[ch] = sc;                                        // z = relu(fma(y, sc, sh))
         coef[C + ch] = bt - (float)mean * sc;
+        coef[2 * C + ch] = (float)mean;                       // rows 2, 3: what a consumer's backward epilogue
+        coef[3 * C + ch] = invstd;                            // needs to form yhat
         if (running_mean) {
             const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
             running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * (float)mean;
@@ -785,6 +823,7 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
                                  const float* coef, int pro, const float* bias, const float* rowbias,
                                  int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                                 const float* epi_y, const float* epi_coef,
                                  float* Y, float* stats, int M, int K, int P, int nb, void* stream)
 {
     // lda < 0 selects the transposed storage of the matrix operand: At is [M][K] with row stride -lda
@@ -796,14 +835,15 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
     if (!At || !Y || pro < 0 || pro > 3) return USIP_EINVAL;
     if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
     if (pro != PRO_NONE && !coef) return USIP_EINVAL;
-    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || stats)) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || (stats && !epi_y))) return USIP_EINVAL;
+    if (epi_y && (!epi_coef || !stats)) return USIP_EINVAL;
     if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 4 || pool_group % 4 != 0 ||
                                    P % pool_group != 0 || P % 4 != 0)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
-               a_trans, ablate};
+               epi_y, epi_coef, a_trans, ablate};
     hipStream_t st = (hipStream_t)stream;
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
     return (M <= 64) ? launch_gemm<1, 4, 16>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
@@ -984,6 +1024,50 @@ extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int3
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
                 (double)nb * (double)M * (double)K, gamma, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(64) void bn_bwd_finalize_tiles_kernel(
+    const float* __restrict__ stats, int ntn, const float* __restrict__ pool_partial, int pool_rows_nb,
+    int C, double count, const float* __restrict__ coef_fwd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ coef4)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = lane; t < ntn; t += 64) {
+        s1 += (double)stats[(long long)t * C + ch];
+        s2 += (double)stats[(long long)ntn * C + (long long)t * C + ch];
+    }
+    if (pool_partial) {
+        const long long nrows = (long long)pool_rows_nb * C;
+        for (int b = lane; b < pool_rows_nb; b += 64) {
+            s1 += (double)pool_partial[(long long)b * C + ch];
+            s2 += (double)pool_partial[nrows + (long long)b * C + ch];
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) {
+        if (dbeta) dbeta[ch] = (float)s1;
+        if (dgamma) dgamma[ch] = (float)s2;
+        const float a1 = coef_fwd[ch], a0 = coef_fwd[C + ch], mu = coef_fwd[2 * C + ch], is = coef_fwd[3 * C + ch];
+        const float c1m = (float)(s1 / count), c2m = (float)(s2 / count);
+        coef4[ch] = a1;
+        coef4[C + ch] = a0;
+        coef4[2 * C + ch] = -a1 * c2m * is;
+        coef4[3 * C + ch] = a1 * (c2m * is * mu - c1m);
+    }
+}
+}  // namespace
+
+extern "C" int usip_bn_backward_finalize_tiles_f32(const float* stats, int tiles, const float* pool_partial,
+                                                   int pool_nb, int C, long long count, const float* coef_fwd4,
+                                                   float* dgamma, float* dbeta, float* coef4, void* stream)
+{
+    if (!stats || tiles < 1 || C < 1 || count < 1 || !coef_fwd4 || !coef4) return USIP_EINVAL;
+    USIP_LAUNCH(bn_bwd_finalize_tiles_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, tiles, pool_partial,
+                pool_partial ? pool_nb : 0, C, (double)count, coef_fwd4, dgamma, dbeta, coef4);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -153,7 +153,7 @@ def _opt(t):
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
-             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False):
+             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, epi=None):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
     (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,tiles,M] when want_stats)."""
@@ -177,6 +177,10 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                            % (tuple(At.shape), tuple(X.shape), M, a_offset))
     Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
     stats = None
+    epi_y = epi_coef = None
+    if epi is not None:                       # (y, coef[4,M]) of the layer that produced this GEMM's output rows
+        epi_y, epi_coef = epi
+        want_stats = True
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, tiles, M), dtype=torch.float32, device=X.device)
@@ -185,8 +189,8 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         wm, wn = (1, 4) if M <= 64 else (2, 2)
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         vec = P % 4 == 0
-        return "gemm_kernel<%d, %d, 16, %d, %s, %s> |wg=%d" % (
-            wm, wn, pro, "true" if want_stats else "false", "true" if vec else "false",
+        return "gemm_kernel<%d, %d, 16, %d, %d, %s> |wg=%d" % (
+            wm, wn, pro, (2 if epi is not None else 1) if want_stats else 0, "true" if vec else "false",
             tiles * ((M + wm * 64 - 1) // (wm * 64)))
 
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
@@ -196,6 +200,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                 None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group),
+                                                _opt(epi_y), _opt(epi_coef),
                                                 _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), "usip_mlp_gemm_f32")
     return Y, stats
 
@@ -206,7 +211,7 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     dev = stats.device
     mean = torch.empty(C, dtype=torch.float32, device=dev)
     invstd = torch.empty(C, dtype=torch.float32, device=dev)
-    coef = torch.empty((2, C), dtype=torch.float32, device=dev)
+    coef = torch.empty((4, C), dtype=torch.float32, device=dev)      # (scale, shift, mean, invstd)
     with torch.cuda.device(dev), prof.kernel("bn_finalize", 4.0 * 2 * tiles * C):
         _lib.check(_lib.lib().usip_bn_finalize_f32(_ptr(stats), tiles, C, int(count), _opt(gamma), _opt(beta),
                                                    float(eps), float(momentum), _opt(running_mean),
@@ -246,6 +251,22 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
                                                           nb, C, P, _stream(dZ)),
                    "usip_bn_backward_reduce_f32")
     return dgamma, dbeta, coef4, gsum
+
+
+def bn_backward_finalize_tiles(stats, count, coef_fwd4, dgamma_out=None, dbeta_out=None, pool_partial=None,
+                               pool_nb: int = 0):
+    """Backward BN sums that arrived as GEMM-epilogue tiles -> (dgamma, dbeta, coef4)."""
+    _, tiles, C = stats.shape
+    dev = stats.device
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("bn_backward_finalize", 8.0 * tiles * C):
+        _lib.check(_lib.lib().usip_bn_backward_finalize_tiles_f32(_ptr(stats), tiles, _opt(pool_partial), int(pool_nb), C,
+                                                                  int(count), _ptr(coef_fwd4), _ptr(dgamma), _ptr(dbeta),
+                                                                  _ptr(coef4), _stream(stats)),
+                   "usip_bn_backward_finalize_tiles_f32")
+    return dgamma, dbeta, coef4
 
 
 def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, relu: bool,
