@@ -131,7 +131,7 @@ int usip_nearest_nd_f32(const float* a, const float* b, float* min_d, int32_t* a
  *   epi_coef its [4][M] coefficients from usip_bn_finalize_f32; `stats` then receives the per-tile BACKWARD sums
  *   (sum dYhat, sum dYhat*yhat), finalised by usip_bn_backward_finalize_tiles_f32 -- the layer's BatchNorm
  *   backward needs no pass of its own over (dZ, y).
- *   stats (may be NULL): [2][tiles][M] per-tile (sum, sum of squares) of Y over valid positions,
+ *   stats (may be NULL): [2][M][tiles] per-tile (sum, sum of squares) of Y over valid positions,
  *   tiles = usip_mlp_gemm_tiles(M, P, nb); summed in fixed order by usip_bn_finalize_f32. */
 int usip_mlp_gemm_tiles(int M, int P, int nb);
 int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2, const float* coef,
@@ -166,7 +166,7 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
                                 float* partial, float* dgamma, float* dbeta, float* coef4,
                                 float* gsum, int group, int nb, int C, int P, void* stream);
 
-/* Finalisation of backward sums that arrived as GEMM-epilogue tiles (stats [2][tiles][C], see epi_y above), plus,
+/* Finalisation of backward sums that arrived as GEMM-epilogue tiles (stats [2][C][tiles], see epi_y above), plus,
  * optionally, the per-(cloud, channel) partial sums of a pooled consumer (pool_partial [2][pool_nb*C], as written by
  * usip_bn_pool_backward_reduce_f32 with dgamma = dbeta = coef4 = NULL).  coef_fwd4 is the layer's [4][C] array. */
 int usip_bn_backward_finalize_tiles_f32(const float* stats, int tiles, const float* pool_partial, int pool_nb,

@@ -42,7 +42,7 @@ struct GemmArgs {
     const float* coef;                 // [4][K] prologue coefficients per input channel
     const float* bias;                 // [M] or null
     float* Y;                          // [nb][M][P]
-    float* stats;                      // [2][ntn][M] or null
+    float* stats;                      // [2][M][ntn] or null
     int M, K, P, nb;
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
@@ -330,8 +330,9 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 #pragma unroll
             for (int w = 0; w < WN; ++w) { s += red[w * BM + tid]; q += red[WN * BM + w * BM + tid]; }
             const long long ntn = (long long)a.nb * tpc;
-            a.stats[(long long)tn * a.M + m0 + tid] = s;
-            a.stats[ntn * a.M + (long long)tn * a.M + m0 + tid] = q;
+            // layout [2][M][tiles]: the finalisation kernels then read a channel's partials contiguously
+            a.stats[(long long)(m0 + tid) * ntn + tn] = s;
+            a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn] = q;
         }
     }
 }
@@ -617,8 +618,8 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(
     const int ch = blockIdx.x, lane = threadIdx.x;
     double s = 0.0, q = 0.0;
     for (int t = lane; t < ntn; t += 64) {
-        s += (double)stats[(long long)t * C + ch];
-        q += (double)stats[(long long)ntn * C + (long long)t * C + ch];
+        s += (double)stats[(long long)ch * ntn + t];
+        q += (double)stats[(long long)ntn * C + (long long)ch * ntn + t];
     }
     s = wave_sum(s); q = wave_sum(q);
     if (lane == 0) {
@@ -1037,8 +1038,8 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_tiles_kernel(
     const int ch = blockIdx.x, lane = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int t = lane; t < ntn; t += 64) {
-        s1 += (double)stats[(long long)t * C + ch];
-        s2 += (double)stats[(long long)ntn * C + (long long)t * C + ch];
+        s1 += (double)stats[(long long)ch * ntn + t];
+        s2 += (double)stats[(long long)ntn * C + (long long)ch * ntn + t];
     }
     if (pool_partial) {
         const long long nrows = (long long)pool_rows_nb * C;

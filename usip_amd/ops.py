@@ -156,7 +156,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
              M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, epi=None):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
-    (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,tiles,M] when want_stats)."""
+    (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,M,tiles] when want_stats)."""
     _need(At, "At", torch.float32)
     if a_trans:                               # At is [M_total, lda]: the operand is rows [m0, m0+M) x cols [a_offset, a_offset+K)
         M_rows, lda = At.shape
@@ -183,7 +183,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         want_stats = True
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
-        stats = torch.empty((2, tiles, M), dtype=torch.float32, device=X.device)
+        stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
     a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
@@ -207,7 +207,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
 
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
     """-> (mean [C], invstd [C], coef [2,C]); updates running_mean/var in place when given."""
-    _, tiles, C = stats.shape
+    _, C, tiles = stats.shape
     dev = stats.device
     mean = torch.empty(C, dtype=torch.float32, device=dev)
     invstd = torch.empty(C, dtype=torch.float32, device=dev)
@@ -256,7 +256,7 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
 def bn_backward_finalize_tiles(stats, count, coef_fwd4, dgamma_out=None, dbeta_out=None, pool_partial=None,
                                pool_nb: int = 0):
     """Backward BN sums that arrived as GEMM-epilogue tiles -> (dgamma, dbeta, coef4)."""
-    _, tiles, C = stats.shape
+    _, C, tiles = stats.shape
     dev = stats.device
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
