@@ -1,6 +1,5 @@
 """ATen operator census of one training step with Python source attribution (torch profiler)."""
 import os, sys
-from collections import Counter
 import torch
 from torch.profiler import profile, ProfilerActivity
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,15 +16,8 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
     st.step(batch)
     torch.cuda.synchronize()
-want = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add", "aten::add_", "aten::contiguous", "aten::clone")
-cnt = Counter()
-for ev in prof.events():
-    if ev.name in want:
-        where = "?"
-        for fr in ev.stack:
-            if "usip_amd" in fr or "bench" in fr or "optim" in fr:
-                where = fr.split("/")[-1]
-                break
-        cnt[(ev.name, where)] += 1
-for (name, where), n in cnt.most_common(45):
-    print("%4d  %-18s %s" % (n, name, where))
+names = sys.argv[1:] or ["aten::fill_", "aten::zero_", "aten::copy_", "aten::add"]
+for ev in prof.key_averages(group_by_stack_n=6):
+    if ev.key in names:
+        src = [f for f in ev.stack if "site-packages/torch" not in f and "dist-packages/torch" not in f][:2]
+        print("%4d  %-14s %s" % (ev.count, ev.key, " <- ".join(s.split("/")[-1] for s in src) or str(ev.stack[:1])))

@@ -44,8 +44,9 @@ class _DetectorTail(nn.Module):
         agg = torch.cat((node_feature, knn_feature), dim=1)
         y = self.mlp2(self.mlp1(agg, defer=True), defer=True)            # no epoch: networks.py:147-148
         ks = self.mlp3(y)
-        keypoints = ks[:, 0:3, :] + centre
-        sigmas = self.softplus(ks[:, 3, :]) + self.opt.loss_sigma_lower_bound
+        offset, raw_sigma = torch.split(ks, [3, 1], dim=1)     # one SplitBackward instead of two zero-filled slices
+        keypoints = offset + centre
+        sigmas = self.softplus(raw_sigma.squeeze(1)) + self.opt.loss_sigma_lower_bound
         return keypoints, sigmas
 
 

@@ -69,11 +69,12 @@ class DetectorStep:
                                          torch.cat((batch["src_sn"], batch["dst_sn"]), 0),
                                          torch.cat((batch["src_node"], batch["dst_node"]), 0),
                                          True, epoch)         # forward_siamese :141-156
-        kp_src, kp_dst = kp[:B], kp[B:]
+        kp_src, kp_dst = torch.split(kp, B, dim=0)            # :147-149 (split: one backward node, no zero fills)
+        sg_src, sg_dst = torch.split(sg, B, dim=0)
         kp_t = torch.matmul(batch["R"], kp_src)               # :182
         kp_t = kp_t * batch["scale"].unsqueeze(1).unsqueeze(2)   # :183
         kp_t = kp_t + batch["shift"]                          # :184
-        loss_chamfer, pure, weighted = self.chamfer_criteria(kp_t, kp_dst, sg[:B], sg[B:])
+        loss_chamfer, pure, weighted = self.chamfer_criteria(kp_t, kp_dst, sg_src, sg_dst)
         alpha = self.opt.keypoint_on_pc_alpha
         on_src = torch.mean(self.keypoint_on_pc_criteria(kp_src, batch["src_pc"], None)) * alpha
         on_dst = torch.mean(self.keypoint_on_pc_criteria(kp_dst, batch["dst_pc"], None)) * alpha
@@ -88,11 +89,19 @@ class DetectorStep:
         from . import functional as Fh
         self.bucket.zero()                                    # detector.zero_grad() :186
         Fh.GRAD_SINK = True       # every parameter is used once per step and the bucket was just zeroed:
-        try:                      # the backward kernels write dW/dgamma/dbeta straight into the bucket
+        Fh.DEFER_BN_COUNTERS = True   # the backward kernels write dW/dgamma/dbeta straight into the bucket
+        try:
             loss = self.forward_losses(batch, epoch)
             loss.backward()                                   # :205
         finally:
             Fh.GRAD_SINK = False
+            Fh.DEFER_BN_COUNTERS = False
+        if getattr(self, "_bn_counters", None) is None:
+            self._bn_counters = [m.num_batches_tracked for m in self.detector.modules()
+                                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+                                 and m.num_batches_tracked is not None]
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)         # every BatchNorm ran exactly once
         self.bucket.all_reduce_mean(group)
         if self.optimizer is not None:
             self.optimizer.step()                             # :207
@@ -129,7 +138,7 @@ class DescriptorStep:
             desc, x_feat = self.descriptor(torch.cat((batch["anc_pc"], batch["pos_pc"]), 0),
                                            torch.cat((batch["anc_sn"], batch["pos_sn"]), 0),
                                            torch.cat((batch["anc_kp"], batch["pos_kp"]), 0), True, epoch)
-            anc, pos = desc[:B], desc[B:]
+            anc, pos = torch.split(desc, B, dim=0)
             triplet, active = self.triplet_criteria(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"])
             loss = torch.mean(triplet)
             loss.backward()
