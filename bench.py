@@ -245,8 +245,9 @@ def main():
                               % (sample_every, timed_steps_sampled),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
                     "traffic_source": traffic_src,
-                    "attainable_peak_note": "tools/mfma_peak.hip sustains 138-149 TFLOP/s fp32 MFMA on this chip "
-                                            "(clock 2.1-2.3 GHz under load)" if top["mfma"] else None}
+                    "attainable_peak_note": "a pure fp32-MFMA loop (tools/mfma_peak.hip) sustains 121-141 TFLOP/s with "
+                                            "random operands on this chip (clock 1.85-2.15 GHz under load), see "
+                                            "profiles/r01_mfma_attainable_peak.txt" if top["mfma"] else None}
                 out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.model)
