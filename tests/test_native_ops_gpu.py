@@ -168,3 +168,52 @@ def test_knn_matches_oracle_topk(shape):
     assert torch.equal(got_d, want_d)                       # same distances in the same order (bit-exact values)
     distinct = (want_d[..., 1:] != want_d[..., :-1]).all(-1)
     assert torch.equal(got[distinct], want_i[distinct])     # identical indices wherever there is no exact tie
+
+
+# ------------------------------------------------------------------ degenerate / extreme inputs
+def test_empty_and_degenerate_inputs_do_not_launch_garbage():
+    """Zero-sized dimensions return correctly shaped outputs without touching memory; K larger than any
+    hit count pads cyclically; a single point / single node works."""
+    ops = _ops()
+    f32, i32 = torch.float32, torch.int32
+    assert ops.index_max(torch.empty(0, 4, 16, device=DEV), torch.empty(0, 16, dtype=i32, device=DEV), 8).shape == (0, 4, 8)
+    assert ops.ball_query(torch.empty(0, 5, 32, device=DEV), 1.0, 4).shape == (0, 5, 4)
+    assert ops.ball_query(torch.empty(2, 0, 32, device=DEV), 1.0, 4).shape == (2, 0, 4)
+    assert ops.pairwise_dist(torch.empty(0, 3, 4, device=DEV), torch.empty(0, 3, 9, device=DEV)).shape == (0, 4, 9)
+    assert ops.ball_query_coords(torch.empty(0, 3, 4, device=DEV), torch.empty(0, 3, 9, device=DEV), 1.0, 4).shape == (0, 4, 4)
+    # one point, one node, K far above the number of hits: the single hit is repeated
+    x = torch.tensor([[[1.0], [2.0], [3.0]]], device=DEV)
+    out = ops.ball_query_coords(x.clone(), x, 0.5, 7)
+    assert out.tolist() == [[[0] * 7]]
+    d = ops.pairwise_dist(x.clone(), x)
+    assert float(d) == 0.0 and ops.ball_query(d, 0.0, 3).tolist() == [[[0, 0, 0]]]      # <= is inclusive at 0
+    # radius below every distance: all-zero row; negative radius and NaN radius: no hit either
+    far = torch.full((1, 2, 40), 5.0, device=DEV)
+    for r in (1.0, -1.0, float("nan")):
+        assert int(ops.ball_query(far, r, 6).abs().sum()) == 0
+    xs = torch.randn(1, 3, 40, device=DEV)
+    nd = xs[:, :, :2].contiguous() + 100.0
+    for r in (1.0, -1.0, float("nan")):
+        assert int(ops.ball_query_coords(nd, xs, r, 6).abs().sum()) == 0
+    # infinite radius: the first K points
+    assert ops.ball_query_coords(nd, xs, float("inf"), 6).tolist() == [[list(range(6))] * 2]
+    # index_max with K = 1 and with every value at the floor
+    data = torch.full((1, 2, 10), -1000.0, device=DEV)
+    assert int(ops.index_max(data, torch.zeros(1, 10, dtype=i32, device=DEV), 1).abs().sum()) == 0
+
+
+def test_largest_supported_group_sizes():
+    """K at the kernels' documented limits: ball_query K = 8192 (LDS list), fused coords K = 1024."""
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    dist = rng.uniform(0, 1, (1, 3, 20000)).astype(np.float32)
+    want = native.ball_query(dist, 0.9, 8192)
+    assert np.array_equal(ops.ball_query(torch.from_numpy(dist).to(DEV), 0.9, 8192).cpu().numpy(), want)
+    x = rng.uniform(-1, 1, (1, 3, 5000)).astype(np.float32)
+    node = np.ascontiguousarray(x[:, :, :5])
+    d = native.pairwise_dist(node, x)
+    want = native.ball_query(d, 0.8, 1024)
+    got = ops.ball_query_coords(torch.from_numpy(node).to(DEV), torch.from_numpy(x).to(DEV), 0.8, 1024)
+    assert np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(RuntimeError, match="USIP_EINVAL"):
+        ops.ball_query(torch.from_numpy(dist).to(DEV), 0.9, 8193)
