@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--m", type=int, default=512)
     ap.add_argument("--cloud", default="slab")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="f32 = fp32 MFMA (parity mode, the headline); bf16 = bf16 multiply / fp32 accumulate in the "
+                         "shared-MLP kernels, tensors stay fp32 (perf mode of BASELINE configs[1]; NOT the headline)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -104,8 +107,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from usip_amd import prof, synth
+    from usip_amd import ops, prof, synth
     from usip_amd.networks import DetectorOptions
+    ops.set_matmul_mode(args.precision)
+    mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
     from usip_amd.step import DetectorStep, batch_to_device
 
     opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=16)
@@ -169,7 +174,9 @@ def main():
             "value": clouds / elapsed, "unit": "point-clouds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "bf16 multiply, f32 accumulate and storage (perf mode)",
+            "data": "synthetic",
             "config": {"workload": ("KITTI descriptor head N=%d, 256 keypoints, K=64, batch=%d pairs/GPU (BASELINE "
                                     "configs[4])" % (args.n, args.pairs)) if args.model == "descriptor" else
                                    ("KITTI detector N=%d M=%d K=64 batch=%d pairs/GPU (BASELINE configs[2])"
@@ -192,6 +199,8 @@ def main():
             traffic_db, traffic_src = {}, None
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+                if ("bf16" in os.path.basename(f)) != (args.precision == "bf16"):
+                    continue                               # each precision mode has its own kernels and PMC passes
                 try:
                     traffic_db, traffic_src = json.load(open(f)), os.path.basename(f)
                 except (OSError, ValueError):
@@ -200,7 +209,7 @@ def main():
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
                 ach = r["TFLOPs"] if mfma else r["GBps"]
-                peak = PEAK_F32_TFLOPS if mfma else PEAK_HBM_GBPS
+                peak = mfma_peak if mfma else PEAK_HBM_GBPS
                 kernels.append({"kernel": name, "calls_per_step": r["calls"] / timed_steps_sampled,
                                 "avg_us": round(r["avg_us"], 2),
                                 "share_of_step": round(r["total_ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
@@ -232,13 +241,14 @@ def main():
                 top_name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
                 avg_s = top["ms"] * 1e-3 / top["calls"]
                 if top["mfma"]:
-                    ach, peak, unit, bound = top["flops"] / top["calls"] / avg_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s", "mfma"
+                    ach, peak, unit, bound = top["flops"] / top["calls"] / avg_s / 1e12, mfma_peak, "TFLOP/s", "mfma"
                 else:
                     ach, peak, unit, bound = top["nbytes"] / top["calls"] / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
                 out["roofline"] = {
                     "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": (top["traffic"] / top["traffic_calls"]) if top["traffic_calls"] else None,
-                    "kernel": top_name + " (csrc/shared_mlp.hip)" if top["mfma"] else top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
+                    "kernel": top_name + (" (csrc/shared_mlp_bf16.hip)" if "bf16" in top_name else " (csrc/shared_mlp.hip)")
+                    if top["mfma"] else top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
                     "avg_us": round(avg_s * 1e6, 2),
                     "share_of_step": round(top["ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
                     "timing": "HIP events on the launch stream, every %d-th step of the timed region (%d steps)"
@@ -247,7 +257,7 @@ def main():
                     "traffic_source": traffic_src,
                     "attainable_peak_note": "a pure fp32-MFMA loop (tools/mfma_peak.hip) sustains 121-141 TFLOP/s with "
                                             "random operands on this chip (clock 1.85-2.15 GHz under load), see "
-                                            "profiles/r01_mfma_attainable_peak.txt" if top["mfma"] else None}
+                                            "profiles/r01_mfma_attainable_peak.txt" if (top["mfma"] and args.precision == "f32") else None}
                 out["kernels"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.model)

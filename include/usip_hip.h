@@ -139,6 +139,15 @@ int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
                       const float* pool_dp, const int32_t* pool_arg, int pool_group,
                       const float* epi_y, const float* epi_coef,
                       float* Y, float* stats, int M, int K, int P, int nb, void* stream);
+/* Same contract with a bf16 MULTIPLY (the perf mode of BASELINE.json configs[1]; not the parity mode): tensors
+ * stay fp32 in memory, the prologue runs in fp32, both operands are rounded to bf16 (nearest-even) on their way
+ * into LDS, v_mfma_f32_32x32x16_bf16 accumulates in fp32, bias / rowbias / statistics are fp32.  The result
+ * equals the fp32 product of the bf16-rounded operands up to summation order. */
+int usip_mlp_gemm_bf16(const float* At, int lda, const float* X, const float* X2, const float* coef,
+                       int pro, const float* bias, const float* rowbias, int rb_group,
+                       const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                       const float* epi_y, const float* epi_coef,
+                       float* Y, float* stats, int M, int K, int P, int nb, void* stream);
 
 /* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
  * coefficients coef[4][C] = (gamma*invstd, beta - mean*gamma*invstd, mean, invstd), and the running-statistics
@@ -193,6 +202,11 @@ int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int p
                        const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                        float* workspace, float* dW, int ldw, int coloff,
                        int M, int N, int P, int nb, void* stream);
+/* bf16-multiply variant (see usip_mlp_gemm_bf16); same workspace, same deterministic fp32 reduction. */
+int usip_mlp_wgrad_bf16(const float* G, const float* G2, const float* coef, int pro, const float* X,
+                        const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                        float* workspace, float* dW, int ldw, int coloff,
+                        int M, int N, int P, int nb, void* stream);
 
 /* ------------------------------------------------------------------ a-6 / a-7 / a-12  grouping, pooling
  * out[b][coff+c][m][k] = x[b][c][idx[b][m][k]] - (c < nsub ? sub[b][c][m] : 0), written into the

@@ -2,14 +2,16 @@
 # Run on the GPU box (through gpurun): kernel-trace stats + HBM traffic counters of the bench step.
 # Counters are collected in their OWN passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950,
 # MI355X_MICROARCH.md "rocprofv3 PMC slots") and never together with sys/runtime tracing.
-#   usage: tools/profile_roofline.sh <tag>      -> gpurun_out/prof_<tag>/{trace,fetch,write}/...
+#   usage: tools/profile_roofline.sh <tag> [extra bench.py flags]   -> gpurun_out/prof_<tag>/{trace,fetch,write}/...
 set -u
 TAG=${1:-r01}
+shift || true
+EXTRA="$*"
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1

@@ -32,6 +32,8 @@ SIGNATURES = {
     "usip_mlp_gemm_tiles": ([_int, _int, _int], _int),
     "usip_mlp_gemm_f32": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                            _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_gemm_bf16": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
+                            _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_backward_finalize_tiles_f32": ([_f32p, _int, _f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _f32p,
                                              _f32p, _stream], _int),
     "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p,
@@ -45,6 +47,8 @@ SIGNATURES = {
     "usip_mlp_wgrad_blocks": ([_int, _int, _int, _int], _int),
     "usip_mlp_wgrad_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int,
                             _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_wgrad_bf16": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int,
+                             _int, _int, _int, _int, _stream], _int),
     "usip_group_max_act_f32": ([_f32p, _f32p, _int, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_group_gather_f32": ([_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int,
                                _stream], _int),

@@ -1,0 +1,221 @@
+// usip_amd/csrc/mlp_common.h -- argument blocks, prologue math and the output epilogue shared by the
+// shared-MLP GEMM kernels (shared_mlp.hip: fp32 MFMA; shared_mlp_bf16.hip: bf16 multiply, fp32 accumulate).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace usip_mlp {
+
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2, PRO_BN_BWD_POOL = 3 };
+// PRO_BN_BWD_POOL: the layer's output went ONLY into a max over K neighbours, so its incoming gradient is
+// dZ[c][m][k] = (k == arg[c][m]) ? dpooled[c][m] : 0.  It is synthesised from the two small [C][M] arrays
+// instead of being written as a dense tensor by the pooling backward and read back three times.
+
+struct GemmArgs {
+    const float* At; int lda;          // [K][M], row stride lda
+    const float* X;                    // [nb][K][P]
+    const float* X2;                   // [nb][K][P]  (PRO_BN_BWD: the layer's pre-BN output Y)
+    const float* coef;                 // [4][K] prologue coefficients per input channel
+    const float* bias;                 // [M] or null
+    float* Y;                          // [nb][M][P]
+    float* stats;                      // [2][M][ntn] or null
+    int M, K, P, nb;
+    const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
+    const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
+    const float* epi_y; const float* epi_coef;   // EPI_BWD_STATS: Y is dZ of a layer whose pre-BN output is epi_y
+                                        // [nb][M][P] and whose (a1, a0, mean, invstd) are epi_coef [4][M]
+    int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
+    int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
+                                        // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
+};
+
+// prologue on one element of the streamed operand, channel coefficients c0..c3
+template <int PRO>
+__device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1, float c2, float c3)
+{
+    if (PRO == PRO_AFFINE_RELU) return fmaxf(__builtin_fmaf(x, c0, c1), 0.0f);
+    if (PRO == PRO_BN_BWD) {
+        // x = dZ, x2 = Y (pre-BN).  a1 = gamma*invstd, a0 = beta - mean*a1 reproduce the forward's
+        // z = relu(fma(y, a1, a0)) decision exactly; dY = a1*dYhat + q1*y + q0 (see bn_bwd_finalize).
+        const float dyh = (__builtin_fmaf(x2, c0, c1) > 0.0f) ? x : 0.0f;
+        return __builtin_fmaf(c0, dyh, __builtin_fmaf(c2, x2, c3));
+    }
+    return x;
+}
+
+// EPI: 0 none | 1 forward BatchNorm statistics of Y (sum, sum^2) | 2 BACKWARD statistics: Y is the gradient
+// dZ w.r.t. the activated output of the layer that produced this GEMM's input; with that layer's pre-BN
+// output y (epi_y) the epilogue accumulates sum(dYhat) and sum(dYhat * yhat), dYhat = dZ * [y*a1+a0 > 0],
+// so the producing layer's BatchNorm backward needs no separate pass over (dZ, y).
+enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BWD_STATS = 2 };
+
+// Epilogue shared by the fp32 and the bf16-multiply kernels (the 32x32 accumulator layout is the same for
+// every 32x32xK MFMA): + bias (+ row bias), store, BatchNorm partial statistics.  `scratch` is LDS the main
+// loop no longer needs (>= 2*WN*BM floats; what is left holds the tile's row bias when it fits).
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], float* scratch,
+                                              int scratch_floats, int b, int m0, int p0, int tn, int tpc)
+{
+    constexpr int BM = WM * 64, BN = WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    float* Yb = a.Y + (long long)b * a.M * a.P;
+    float* red = scratch;                                    // [2][WN][BM]
+    // the lane's two output columns and, for the pooled-concat layer, their neighbourhood index
+    // (ONE integer division per column instead of one per element)
+    int colj[2], grpj[2];
+    const int ngrp = a.rowbias ? a.P / a.rb_group : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        colj[j] = p0 + wn * 64 + j * 32 + c;
+        grpj[j] = a.rowbias ? min(colj[j], a.P - 1) / a.rb_group : 0;
+    }
+    // Row bias of this tile -> LDS once ([BM][G], G = neighbourhoods the tile's columns span) instead of one
+    // global load per output element.
+    float* rbs = red + 2 * WN * BM;
+    const int g0 = a.rowbias ? p0 / a.rb_group : 0;
+    const int G = a.rowbias ? (min(p0 + BN, a.P) - 1) / a.rb_group - g0 + 1 : 0;
+    const bool rb_lds = a.rowbias && BM * G <= scratch_floats - 2 * WN * BM;
+    if (rb_lds) {
+        for (int e = tid; e < BM * G; e += 256) {
+            const int rl = e / G, g = e % G;
+            rbs[e] = (m0 + rl < a.M) ? a.rowbias[((long long)b * a.M + m0 + rl) * ngrp + g0 + g] : 0.f;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // EPI_BWD_STATS: the 32 y values this lane needs for tile row-block i, as 32 independent loads from
+        // clamped addresses issued back to back (one load-use-wait per element would be 64 serial HBM trips)
+        float yv[EPI == EPI_BWD_STATS ? 16 : 1][2];
+        if (EPI == EPI_BWD_STATS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowc = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    yv[r][j] = a.epi_y[((long long)b * a.M + rowc) * a.P + min(colj[j], a.P - 1)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int row = m0 + row_l;
+            const int rowc = min(row, a.M - 1);
+            const float bv = a.bias ? a.bias[rowc] : 0.0f;
+            float e1 = 0.f, e0 = 0.f, emu = 0.f, eis = 0.f;
+            if (EPI == EPI_BWD_STATS) {
+                e1 = a.epi_coef[rowc]; e0 = a.epi_coef[a.M + rowc];
+                emu = a.epi_coef[2 * a.M + rowc]; eis = a.epi_coef[3 * a.M + rowc];
+            }
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v = acc[i][j][r] + bv;
+                if (a.rowbias)
+                    v += rb_lds ? rbs[row_l * G + grpj[j] - g0]
+                                : a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
+                if (row < a.M && colj[j] < a.P) {
+                    Yb[(long long)row * a.P + colj[j]] = v;
+                    if (EPI == EPI_STATS) { s += v; q = __builtin_fmaf(v, v, q); }
+                    if (EPI == EPI_BWD_STATS) {
+                        const float yy = yv[EPI == EPI_BWD_STATS ? r : 0][j];
+                        const float d = (__builtin_fmaf(yy, e1, e0) > 0.f) ? v : 0.f;
+                        s += d;
+                        q = __builtin_fmaf(d, (yy - emu) * eis, q);
+                    }
+                }
+            }
+            if (EPI != EPI_NONE) {
+                // 32-lane sum: four DPP steps inside each row of 16 lanes (VALU, no LDS crossbar), then one
+                // cross-row exchange
+                s = usip_row16_sum(s); q = usip_row16_sum(q);
+                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+                if (c == 0) {
+                    red[wn * BM + row_l] = s;
+                    red[WN * BM + wn * BM + row_l] = q;
+                }
+            }
+        }
+    }
+    if (EPI != EPI_NONE) {
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) { s += red[w * BM + tid]; q += red[WN * BM + w * BM + tid]; }
+            const long long ntn = (long long)a.nb * tpc;
+            // layout [2][M][tiles]: the finalisation kernels then read a channel's partials contiguously
+            a.stats[(long long)(m0 + tid) * ntn + tn] = s;
+            a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn] = q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[m=co][n=ci] = sum over positions of pro(G)[co][p] * X[ci][p]
+struct WgradArgs {
+    const float* G;  const float* G2; const float* coef;   // [nb][M][P] (+ Y and [4][M] for PRO_BN_BWD)
+    const float* X;                                         // [nb][N][P]
+    const float* xcoef;                                     // [2][N] or null: X := relu(X*xcoef[0][n] + xcoef[1][n])
+    const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][M][P/group] each
+    float* part;                                            // [slices][M][N]
+    int M, N, P, nb, seglen, segs;                          // segs position segments per cloud
+};
+
+// One stage of a [rows][32 positions] operand tile of the weight gradient: thread -> (row, 4
+// consecutive positions), 8 lanes cover one 128-B row segment.  Raw loads only; the BatchNorm-backward
+// prologue runs when the registers are written to LDS (after the MFMAs the loads overlap with).
+template <int N4, bool TWO, bool VEC>
+__device__ __forceinline__ void wgrad_load_rows(const float* __restrict__ base, const float* __restrict__ base2,
+                                                int rows, int P, int r0, int p, int pend, int tid,
+                                                float4 (&dst)[N4], float4 (&dst2)[TWO ? N4 : 1])
+{
+#pragma unroll
+    for (int i = 0; i < N4; ++i) {
+        const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+        if (VEC) {
+            // P % 4 == 0 and segments start at multiples of 32: a float4 is entirely inside or outside.
+            // Branch-free: clamped (valid) address, zeroed afterwards.
+            const long long off = (long long)min(r0 + row, rows - 1) * P + min(p + kq, P - 4);
+            v = *reinterpret_cast<const float4*>(base + off);           // masked at LDS-store time
+            if (TWO) w = *reinterpret_cast<const float4*>(base2 + off);
+        } else if (r0 + row < rows) {
+            const long long off = (long long)(r0 + row) * P + p + kq;
+            if (p + kq + 0 < pend) { v.x = base[off + 0]; if (TWO) w.x = base2[off + 0]; }
+            if (p + kq + 1 < pend) { v.y = base[off + 1]; if (TWO) w.y = base2[off + 1]; }
+            if (p + kq + 2 < pend) { v.z = base[off + 2]; if (TWO) w.z = base2[off + 2]; }
+            if (p + kq + 3 < pend) { v.w = base[off + 3]; if (TWO) w.w = base2[off + 3]; }
+        }
+        dst[i] = v;
+        if (TWO) dst2[i] = w;
+    }
+}
+
+// Accumulator tiles of one wave -> the slice's partial [M][N] tile in the workspace.
+template <int TM, int TN>
+__device__ __forceinline__ void wgrad_store_partial(const WgradArgs& a, f32x16 (&acc)[TM][TN], int slice,
+                                                    int m0, int n0, int wm, int wn, int lane)
+{
+    float* out = a.part + (long long)slice * a.M * a.N;
+    const int half = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int col = n0 + (wn * TN + j) * 32 + c;
+                if (row < a.M && col < a.N) out[(long long)row * a.N + col] = acc[i][j][r];
+            }
+}
+
+// bf16-multiply variants (shared_mlp_bf16.hip); same argument blocks, same outputs up to operand rounding
+int launch_gemm_bf16(const GemmArgs& a, int pro, hipStream_t st);
+int launch_wgrad_bf16(const WgradArgs& a, int pro, bool xpro, bool vec, int small, unsigned blocks, hipStream_t st);
+
+}  // namespace usip_mlp

@@ -23,55 +23,12 @@
 //
 // fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf
 // chain, so parity with the fp32 reference is a matter of summation order only (<= 1e-6).
-#include "common.h"
+#include "mlp_common.h"
 #include <cstdlib>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using namespace usip_mlp;
 
 namespace {
-
-enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2, PRO_BN_BWD_POOL = 3 };
-// PRO_BN_BWD_POOL: the layer's output went ONLY into a max over K neighbours, so its incoming gradient is
-// dZ[c][m][k] = (k == arg[c][m]) ? dpooled[c][m] : 0.  It is synthesised from the two small [C][M] arrays
-// instead of being written as a dense tensor by the pooling backward and read back three times.
-
-struct GemmArgs {
-    const float* At; int lda;          // [K][M], row stride lda
-    const float* X;                    // [nb][K][P]
-    const float* X2;                   // [nb][K][P]  (PRO_BN_BWD: the layer's pre-BN output Y)
-    const float* coef;                 // [4][K] prologue coefficients per input channel
-    const float* bias;                 // [M] or null
-    float* Y;                          // [nb][M][P]
-    float* stats;                      // [2][M][ntn] or null
-    int M, K, P, nb;
-    const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
-    const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
-    const float* epi_y; const float* epi_coef;   // EPI_BWD_STATS: Y is dZ of a layer whose pre-BN output is epi_y
-                                        // [nb][M][P] and whose (a1, a0, mean, invstd) are epi_coef [4][M]
-    int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
-    int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
-                                        // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
-};
-
-// prologue on one element of the streamed operand, channel coefficients c0..c3
-template <int PRO>
-__device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1, float c2, float c3)
-{
-    if (PRO == PRO_AFFINE_RELU) return fmaxf(__builtin_fmaf(x, c0, c1), 0.0f);
-    if (PRO == PRO_BN_BWD) {
-        // x = dZ, x2 = Y (pre-BN).  a1 = gamma*invstd, a0 = beta - mean*a1 reproduce the forward's
-        // z = relu(fma(y, a1, a0)) decision exactly; dY = a1*dYhat + q1*y + q0 (see bn_bwd_finalize).
-        const float dyh = (__builtin_fmaf(x2, c0, c1) > 0.0f) ? x : 0.0f;
-        return __builtin_fmaf(c0, dyh, __builtin_fmaf(c2, x2, c3));
-    }
-    return x;
-}
-
-// EPI: 0 none | 1 forward BatchNorm statistics of Y (sum, sum^2) | 2 BACKWARD statistics: Y is the gradient
-// dZ w.r.t. the activated output of the layer that produced this GEMM's input; with that layer's pre-BN
-// output y (epi_y) the epilogue accumulates sum(dYhat) and sum(dYhat * yhat), dYhat = dZ * [y*a1+a0 > 0],
-// so the producing layer's BatchNorm backward needs no separate pass over (dZ, y).
-enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BWD_STATS = 2 };
 
 template <int WM, int WN, int BK, int PRO, int EPI, bool VEC>
 __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
@@ -242,99 +199,7 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
         cur ^= 1;
     }
 
-    // ---- epilogue: + bias (+ row bias), store, BatchNorm partial statistics ------------------
-    float* Yb = a.Y + (long long)b * a.M * a.P;
-    float* red = &As[0][0][0];                               // [2][WN][BM] scratch (LDS is free now)
-    const int half = lane >> 5;
-    // the lane's two output columns and, for the pooled-concat layer, their neighbourhood index
-    // (ONE integer division per column instead of one per element)
-    int colj[2], grpj[2];
-    const int ngrp = a.rowbias ? a.P / a.rb_group : 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        colj[j] = p0 + wn * 64 + j * 32 + c;
-        grpj[j] = a.rowbias ? min(colj[j], a.P - 1) / a.rb_group : 0;
-    }
-    // Row bias of this tile -> LDS once ([BM][G], G = neighbourhoods the tile's columns span) instead of one
-    // global load per output element.
-    float* rbs = red + 2 * WN * BM;
-    const int g0 = a.rowbias ? p0 / a.rb_group : 0;
-    const int G = a.rowbias ? (min(p0 + BN, a.P) - 1) / a.rb_group - g0 + 1 : 0;
-    const bool rb_lds = a.rowbias && BM * G <= 2 * BK * BM - 2 * WN * BM;
-    if (rb_lds) {
-        for (int e = tid; e < BM * G; e += 256) {
-            const int rl = e / G, g = e % G;
-            rbs[e] = (m0 + rl < a.M) ? a.rowbias[((long long)b * a.M + m0 + rl) * ngrp + g0 + g] : 0.f;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        // EPI_BWD_STATS: the 32 y values this lane needs for tile row-block i, as 32 independent loads from
-        // clamped addresses issued back to back (one load-use-wait per element would be 64 serial HBM trips)
-        float yv[EPI == EPI_BWD_STATS ? 16 : 1][2];
-        if (EPI == EPI_BWD_STATS) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowc = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    yv[r][j] = a.epi_y[((long long)b * a.M + rowc) * a.P + min(colj[j], a.P - 1)];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int row = m0 + row_l;
-            const int rowc = min(row, a.M - 1);
-            const float bv = a.bias ? a.bias[rowc] : 0.0f;
-            float e1 = 0.f, e0 = 0.f, emu = 0.f, eis = 0.f;
-            if (EPI == EPI_BWD_STATS) {
-                e1 = a.epi_coef[rowc]; e0 = a.epi_coef[a.M + rowc];
-                emu = a.epi_coef[2 * a.M + rowc]; eis = a.epi_coef[3 * a.M + rowc];
-            }
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v = acc[i][j][r] + bv;
-                if (a.rowbias)
-                    v += rb_lds ? rbs[row_l * G + grpj[j] - g0]
-                                : a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
-                if (row < a.M && colj[j] < a.P) {
-                    Yb[(long long)row * a.P + colj[j]] = v;
-                    if (EPI == EPI_STATS) { s += v; q = __builtin_fmaf(v, v, q); }
-                    if (EPI == EPI_BWD_STATS) {
-                        const float yy = yv[EPI == EPI_BWD_STATS ? r : 0][j];
-                        const float d = (__builtin_fmaf(yy, e1, e0) > 0.f) ? v : 0.f;
-                        s += d;
-                        q = __builtin_fmaf(d, (yy - emu) * eis, q);
-                    }
-                }
-            }
-            if (EPI != EPI_NONE) {
-                // 32-lane sum: four DPP steps inside each row of 16 lanes (VALU, no LDS crossbar), then one
-                // cross-row exchange
-                s = usip_row16_sum(s); q = usip_row16_sum(q);
-                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-                if (c == 0) {
-                    red[wn * BM + row_l] = s;
-                    red[WN * BM + wn * BM + row_l] = q;
-                }
-            }
-        }
-    }
-    if (EPI != EPI_NONE) {
-        __syncthreads();
-        if (tid < BM && m0 + tid < a.M) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int w = 0; w < WN; ++w) { s += red[w * BM + tid]; q += red[WN * BM + w * BM + tid]; }
-            const long long ntn = (long long)a.nb * tpc;
-            // layout [2][M][tiles]: the finalisation kernels then read a channel's partials contiguously
-            a.stats[(long long)(m0 + tid) * ntn + tn] = s;
-            a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn] = q;
-        }
-    }
+    gemm_epilogue<WM, WN, EPI>(a, acc, &As[0][0][0], 2 * BK * BM, b, m0, p0, tn, tpc);   // LDS is free now
 }
 
 template <int WM, int WN, int BK>
@@ -372,47 +237,6 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_BWD_STATS, true)
 #undef USIP_GEMM_CASE
     return USIP_EINVAL;
-}
-
-// ------------------------------------------------------------------------------------------------
-// weight gradient: dW[m=co][n=ci] = sum over positions of pro(G)[co][p] * X[ci][p]
-struct WgradArgs {
-    const float* G;  const float* G2; const float* coef;   // [nb][M][P] (+ Y and [4][M] for PRO_BN_BWD)
-    const float* X;                                         // [nb][N][P]
-    const float* xcoef;                                     // [2][N] or null: X := relu(X*xcoef[0][n] + xcoef[1][n])
-    const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][M][P/group] each
-    float* part;                                            // [slices][M][N]
-    int M, N, P, nb, seglen, segs;                          // segs position segments per cloud
-};
-
-// One stage of a [rows][32 positions] operand tile of the weight gradient: thread -> (row, 4
-// consecutive positions), 8 lanes cover one 128-B row segment.  Raw loads only; the BatchNorm-backward
-// prologue runs when the registers are written to LDS (after the MFMAs the loads overlap with).
-template <int N4, bool TWO, bool VEC>
-__device__ __forceinline__ void wgrad_load_rows(const float* __restrict__ base, const float* __restrict__ base2,
-                                                int rows, int P, int r0, int p, int pend, int tid,
-                                                float4 (&dst)[N4], float4 (&dst2)[TWO ? N4 : 1])
-{
-#pragma unroll
-    for (int i = 0; i < N4; ++i) {
-        const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
-        if (VEC) {
-            // P % 4 == 0 and segments start at multiples of 32: a float4 is entirely inside or outside.
-            // Branch-free: clamped (valid) address, zeroed afterwards.
-            const long long off = (long long)min(r0 + row, rows - 1) * P + min(p + kq, P - 4);
-            v = *reinterpret_cast<const float4*>(base + off);           // masked at LDS-store time
-            if (TWO) w = *reinterpret_cast<const float4*>(base2 + off);
-        } else if (r0 + row < rows) {
-            const long long off = (long long)(r0 + row) * P + p + kq;
-            if (p + kq + 0 < pend) { v.x = base[off + 0]; if (TWO) w.x = base2[off + 0]; }
-            if (p + kq + 1 < pend) { v.y = base[off + 1]; if (TWO) w.y = base2[off + 1]; }
-            if (p + kq + 2 < pend) { v.z = base[off + 2]; if (TWO) w.z = base2[off + 2]; }
-            if (p + kq + 3 < pend) { v.w = base[off + 3]; if (TWO) w.w = base2[off + 3]; }
-        }
-        dst[i] = v;
-        if (TWO) dst2[i] = w;
-    }
 }
 
 template <int TM, int TN, int PRO, bool XPRO, bool VEC>
@@ -559,18 +383,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
         __syncthreads();
         cur ^= 1;
     }
-    float* out = a.part + (long long)slice * a.M * a.N;
-    const int half = lane >> 5;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int col = n0 + (wn * TN + j) * 32 + c;
-                if (row < a.M && col < a.N) out[(long long)row * a.N + col] = acc[i][j][r];
-            }
+    wgrad_store_partial<TM, TN>(a, acc, slice, m0, n0, wm, wn, lane);
 }
 
 // dW[e] = sum over slices, in a fixed order: 64 elements x 4 slice lanes per block, every lane sums
@@ -821,11 +634,11 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
     return nb * ((P + BN - 1) / BN);
 }
 
-extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
-                                 const float* coef, int pro, const float* bias, const float* rowbias,
-                                 int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                                 const float* epi_y, const float* epi_coef,
-                                 float* Y, float* stats, int M, int K, int P, int nb, void* stream)
+static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, const float* X2,
+                         const float* coef, int pro, const float* bias, const float* rowbias,
+                         int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                         const float* epi_y, const float* epi_coef,
+                         float* Y, float* stats, int M, int K, int P, int nb, void* stream)
 {
     // lda < 0 selects the transposed storage of the matrix operand: At is [M][K] with row stride -lda
     // (the forward product can then read W itself instead of a transposed copy made every step)
@@ -846,9 +659,23 @@ extern "C" int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
                epi_y, epi_coef, a_trans, ablate};
     hipStream_t st = (hipStream_t)stream;
+    if (bf16) return launch_gemm_bf16(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
     return (M <= 64) ? launch_gemm<1, 4, 16>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
 }
+
+#define USIP_GEMM_PARAMS                                                                                     \
+    const float *At, int lda, const float *X, const float *X2, const float *coef, int pro, const float *bias, \
+        const float *rowbias, int rb_group, const float *pool_dp, const int32_t *pool_arg, int pool_group,    \
+        const float *epi_y, const float *epi_coef, float *Y, float *stats, int M, int K, int P, int nb,       \
+        void *stream
+#define USIP_GEMM_ARGS \
+    At, lda, X, X2, coef, pro, bias, rowbias, rb_group, pool_dp, pool_arg, pool_group, epi_y, epi_coef, Y, stats, \
+        M, K, P, nb, stream
+extern "C" int usip_mlp_gemm_f32(USIP_GEMM_PARAMS) { return mlp_gemm_impl(false, USIP_GEMM_ARGS); }
+extern "C" int usip_mlp_gemm_bf16(USIP_GEMM_PARAMS) { return mlp_gemm_impl(true, USIP_GEMM_ARGS); }
+#undef USIP_GEMM_PARAMS
+#undef USIP_GEMM_ARGS
 
 // Workspace (floats) the weight-gradient needs, and the slicing it will use.
 static void wgrad_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* small, int* tiles)
@@ -884,10 +711,10 @@ extern "C" int usip_mlp_wgrad_blocks(int M, int N, int P, int nb)
     return tiles * nb * segs;
 }
 
-extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int pro,
-                                  const float* X, const float* xcoef, const float* pool_dp, const int32_t* pool_arg,
-                                  int pool_group, float* workspace, float* dW, int ldw,
-                                  int coloff, int M, int N, int P, int nb, void* stream)
+static int mlp_wgrad_impl(bool bf16, const float* G, const float* G2, const float* coef, int pro,
+                          const float* X, const float* xcoef, const float* pool_dp, const int32_t* pool_arg,
+                          int pool_group, float* workspace, float* dW, int ldw,
+                          int coloff, int M, int N, int P, int nb, void* stream)
 {
     if (M < 1 || N < 1 || P < 1 || nb < 1 || ldw < N + coloff || coloff < 0) return USIP_EINVAL;
     if (!dW) return USIP_EINVAL;
@@ -909,8 +736,12 @@ extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* 
     const long long blocks = (long long)tiles * nb * segs;
     if (blocks > 0x7fffffffLL) return USIP_EINVAL;
     dim3 grid((unsigned)blocks), block(256);
+    if (bf16) {
+        const int rc = launch_wgrad_bf16(a, pro, xpro, vec, small, (unsigned)blocks, st);
+        if (rc != USIP_OK) return rc;
+    }
 #define USIP_WGRAD_CASE(T_, P_, X_, V_)                                                        \
-    if (small == (T_ == 1) && pro == P_ && xpro == X_ && vec == V_) {                          \
+    if (!bf16 && small == (T_ == 1) && pro == P_ && xpro == X_ && vec == V_) {                \
         USIP_LAUNCH((wgrad_kernel<T_, T_, P_, X_, V_>), grid, block, 0, st, a);                \
         USIP_LAUNCH_CHECK();                                                                   \
     }
@@ -931,6 +762,17 @@ extern "C" int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* 
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
+
+#define USIP_WGRAD_PARAMS                                                                                      \
+    const float *G, const float *G2, const float *coef, int pro, const float *X, const float *xcoef,            \
+        const float *pool_dp, const int32_t *pool_arg, int pool_group, float *workspace, float *dW, int ldw,    \
+        int coloff, int M, int N, int P, int nb, void *stream
+#define USIP_WGRAD_ARGS \
+    G, G2, coef, pro, X, xcoef, pool_dp, pool_arg, pool_group, workspace, dW, ldw, coloff, M, N, P, nb, stream
+extern "C" int usip_mlp_wgrad_f32(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(false, USIP_WGRAD_ARGS); }
+extern "C" int usip_mlp_wgrad_bf16(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(true, USIP_WGRAD_ARGS); }
+#undef USIP_WGRAD_PARAMS
+#undef USIP_WGRAD_ARGS
 
 extern "C" int usip_bn_finalize_f32(const float* stats, int ntiles, int C, long long count,
                                     const float* gamma, const float* beta, float eps, float momentum,

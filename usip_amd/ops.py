@@ -151,6 +151,25 @@ def _opt(t):
     return _ptr(t) if t is not None else None
 
 
+# "f32": fp32 MFMA (the parity mode and the headline).  "bf16": operands rounded to bf16 inside the GEMM and
+# weight-gradient kernels, fp32 accumulate, everything else fp32 (BASELINE.json configs[1] perf mode).
+MATMUL_MODES = ("f32", "bf16")
+_matmul_mode = "f32"
+
+
+def set_matmul_mode(mode: str) -> str:
+    """Select the multiply precision of the shared-MLP kernels; returns the previous mode."""
+    global _matmul_mode
+    if mode not in MATMUL_MODES:
+        raise ValueError("matmul mode must be one of %s" % (MATMUL_MODES,))
+    prev, _matmul_mode = _matmul_mode, mode
+    return prev
+
+
+def matmul_mode() -> str:
+    return _matmul_mode
+
+
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
              M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, epi=None):
@@ -185,23 +204,27 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
     a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
+    bf16 = _matmul_mode == "bf16"
+    fn_name = "usip_mlp_gemm_bf16" if bf16 else "usip_mlp_gemm_f32"
+
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
-        vec = P % 4 == 0
-        return "gemm_kernel<%d, %d, 16, %d, %d, %s> |wg=%d" % (
-            wm, wn, pro, (2 if epi is not None else 1) if want_stats else 0, "true" if vec else "false",
-            tiles * ((M + wm * 64 - 1) // (wm * 64)))
+        e = (2 if epi is not None else 1) if want_stats else 0
+        wg = tiles * ((M + wm * 64 - 1) // (wm * 64))
+        if bf16:
+            return "gemm_bf16_kernel<%d, %d, 16, %d, %d> |wg=%d" % (wm, wn, pro, e, wg)
+        return "gemm_kernel<%d, %d, 16, %d, %d, %s> |wg=%d" % (wm, wn, pro, e, "true" if P % 4 == 0 else "false", wg)
 
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P, rocprof_key=_key):
-        _lib.check(_lib.lib().usip_mlp_gemm_f32(a_ptr, -lda if a_trans else lda,
+        _lib.check(getattr(_lib.lib(), fn_name)(a_ptr, -lda if a_trans else lda,
                                                 None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group),
                                                 _opt(epi_y), _opt(epi_coef),
-                                                _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), "usip_mlp_gemm_f32")
+                                                _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), fn_name)
     return Y, stats
 
 
@@ -303,18 +326,22 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     ws = torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev)
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     ldw = dW.shape[1]
+    bf16 = _matmul_mode == "bf16"
+    fn_name = "usip_mlp_wgrad_bf16" if bf16 else "usip_mlp_wgrad_f32"
+
     def _key():
         t = 1 if (M <= 64 and N <= 64) else 2
-        return "wgrad_kernel<%d, %d, %d, %s, %s> |wg=%d" % (t, t, pro, "true" if xcoef is not None else "false",
-                                                           "true" if P % 4 == 0 else "false",
-                                                           _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
+        return "%s<%d, %d, %d, %s, %s> |wg=%d" % ("wgrad_bf16_kernel" if bf16 else "wgrad_kernel", t, t, pro,
+                                                  "true" if xcoef is not None else "false",
+                                                  "true" if P % 4 == 0 else "false",
+                                                  _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
 
     with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
                                              4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
                                              rocprof_key=_key):
-        _lib.check(_lib.lib().usip_mlp_wgrad_f32(_opt(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _opt(xcoef),
-                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group), _ptr(ws), _ptr(dW),
-                                                 int(ldw), int(coloff), M, N, P, nb, _stream(X)), "usip_mlp_wgrad_f32")
+        _lib.check(getattr(_lib.lib(), fn_name)(_opt(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _opt(xcoef),
+                                                _opt(pool_dp), _opt(pool_arg), int(pool_group), _ptr(ws), _ptr(dW),
+                                                int(ldw), int(coloff), M, N, P, nb, _stream(X)), fn_name)
     return dW
 
 
