@@ -100,6 +100,21 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
 int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
                               const float* gd, float* ga, float* gb, int B, int C, int Ma, int Nb, void* stream);
 
+/* a-10: the sigma arithmetic of ChamferLoss_Brute after the two min / arg-min reductions
+ * (models/losses.py:82-99) as one launch.  a [B][M], J i32 [B][M] = row minima / arg-minima (src -> dst),
+ * c [B][N], I i32 [B][N] = column minima (dst -> src), sigma_src [B][M], sigma_dst [B][N].
+ * out3 = (forward_loss + backward_loss, chamfer_pure, chamfer_weighted); sums in double, fixed order. */
+int usip_chamfer_prob_f32(const float* a, const int32_t* J, const float* c, const int32_t* I,
+                          const float* sigma_src, const float* sigma_dst, float* out3,
+                          int B, int M, int N, void* stream);
+/* Its backward for an upstream gradient gloss[0] (device scalar) of out3[0]: da [B][M], dc [B][N],
+ * dsigma_src [B][M], dsigma_dst [B][N] (every element written; the gather's transpose is a deterministic
+ * segmented sum).  workspace: B*(M+N) floats. */
+int usip_chamfer_prob_backward_f32(const float* gloss, const float* a, const int32_t* J, const float* c,
+                                   const int32_t* I, const float* sigma_src, const float* sigma_dst,
+                                   float* da, float* dc, float* dsigma_src, float* dsigma_dst,
+                                   float* workspace, int B, int M, int N, void* stream);
+
 /* f-1 (descriptor head): the same minimum / first arg-minimum for C-dimensional points a [B][C][Ma],
  * b [B][C][Nb] (Nb <= 1024) -- the M x M descriptor-distance matrices of DescPairScanLoss
  * (models/losses.py:207-218: torch.norm over B x C x M x M, 268 MB at B=8) are never built. */
@@ -227,6 +242,11 @@ int usip_group_max_act_f32(const float* y, const float* coef, int relu, float* p
                            int B, int C, int M, int K, void* stream);
 int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float* dz,
                                 long long rows, int K, void* stream);
+/* The same gradient ADDED into an existing dense gradient: dz[row*K + arg[row]] += dpooled[row]
+ * (the tensor that was pooled also fed a layer directly: its two gradients are combined by touching
+ * `rows` elements instead of materialising and adding a second dense tensor). */
+int usip_group_max_backward_add_f32(const float* dpooled, const int32_t* arg, float* dz,
+                                    long long rows, int K, void* stream);
 
 /* ------------------------------------------------------------------ a-7  node KNN
  * idx[b][m][0..K) = the K database points nearest to query m, ascending distance (lower index first on

@@ -138,3 +138,46 @@ def test_layer_plus_max_fused_matches_reference(cfg):
     for name, a, t, f32 in zip(["pooled", "dx", "dw", "dgamma", "dbeta"], got, truth, aten):
         err, aten_err = _rel(a, t), _rel(f32, t)
         assert err <= max(1e-5, 4 * aten_err), (name, err, aten_err)
+
+
+@pytest.mark.parametrize("K", [16, 64, 5])
+def test_pool_fork_gradient_equals_separate_pool_and_pass(K):
+    """group_max_fork (pooling gradient added into the consumer's dense gradient in place) must give the
+    producing layer bit-for-bit the gradient that separate pooling + autograd's dense sum gives.  K = 5 takes
+    the non-fused fallback of the fork."""
+    from usip_amd import functional as Fh
+    B, Cin, C, M = 2, 9, 64, 40
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(B, Cin, M, K, generator=g).to(DEV)
+    w1 = (torch.randn(C, Cin, 1, 1, generator=g) * 0.3).to(DEV)
+    w2 = (torch.randn(32, 2 * C, 1, 1, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(B, 32, M, K, generator=g).to(DEV)
+
+    def run(fork):
+        a = w1.clone().requires_grad_(True)
+        b = w2.clone().requires_grad_(True)
+        bn1, bn2 = torch.nn.BatchNorm2d(C).to(DEV), torch.nn.BatchNorm2d(32).to(DEV)
+        xs = x.clone().requires_grad_(True)
+        h = Fh.conv1x1_bn_act(xs, a, None, bn1, True, defer=True)
+        if fork:
+            pooled, h2 = Fh.group_max_fork(h)
+        else:
+            pooled, h2 = Fh.group_max(h), h
+        y = Fh.conv1x1_bn_act_pooled(h2, pooled, b, None, bn2, True, pooled_first=False)
+        y.backward(gy)
+        return y.detach(), xs.grad, a.grad, b.grad, bn1.weight.grad
+
+    for got, want in zip(run(True), run(False)):
+        assert torch.equal(got, want)
+
+
+def test_group_max_backward_add_inplace():
+    from usip_amd import ops
+    B, C, M, K = 2, 3, 50, 12
+    g = torch.Generator().manual_seed(1)
+    dz = torch.randn(B, C, M, K, generator=g).to(DEV)
+    dp = torch.randn(B, C, M, generator=g).to(DEV)
+    arg = torch.randint(0, K, (B, C, M), generator=g, dtype=torch.int32).to(DEV)
+    want = dz + ops.group_max_backward(dp, arg, K)
+    out = ops.group_max_backward_add_(dz, dp, arg)
+    assert out.data_ptr() == dz.data_ptr() and torch.equal(dz, want)

@@ -217,3 +217,35 @@ def test_largest_supported_group_sizes():
     assert np.array_equal(got.cpu().numpy(), want)
     with pytest.raises(RuntimeError, match="USIP_EINVAL"):
         ops.ball_query(torch.from_numpy(dist).to(DEV), 0.9, 8193)
+
+
+def test_chamfer_prob_kernels_match_torch_float64():
+    """usip_chamfer_prob_f32 (+ backward) against the reference formulas (models/losses.py:82-99) evaluated
+    by autograd in float64, ragged M != N, repeated partners (many-to-one gather)."""
+    ops = _ops()
+    B, M, N = 3, 700, 1300                       # N > 1024: more than one LDS chunk in the segmented sums
+    g = torch.Generator().manual_seed(2)
+    a = torch.rand(B, M, generator=g).to(DEV)
+    c = torch.rand(B, N, generator=g).to(DEV)
+    J = torch.randint(0, N, (B, M), generator=g, dtype=torch.int32).to(DEV)
+    I = torch.randint(0, 40, (B, N), generator=g, dtype=torch.int32).to(DEV)      # heavy collisions
+    ss = (0.05 + torch.rand(B, M, generator=g)).to(DEV)
+    sd = (0.05 + torch.rand(B, N, generator=g)).to(DEV)
+    out = ops.chamfer_prob(a, J, c, I, ss, sd)
+    gl = torch.tensor(0.7, device=DEV)
+    da, dc, dss, dsd = ops.chamfer_prob_backward(gl, a, J, c, I, ss, sd)
+    A, C, SS, SD = (t.double().requires_grad_(True) for t in (a, c, ss, sd))
+    sf = (SS + torch.gather(SD, 1, J.long())) / 2
+    sb = (SD + torch.gather(SS, 1, I.long())) / 2
+    loss = (torch.log(sf) + A / sf).mean() + (torch.log(sb) + C / sb).mean()
+    pure = A.mean() + C.mean()
+    wf, wb = (1 / sf) / (1 / sf).mean(), (1 / sb) / (1 / sb).mean()
+    weighted = (wf * A).mean() + (wb * C).mean()
+    (0.7 * loss).backward()
+    for got, want in ((out[0], loss), (out[1], pure), (out[2], weighted)):
+        assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want))
+    for got, want, name in ((da, A.grad, "da"), (dc, C.grad, "dc"), (dss, SS.grad, "dss"), (dsd, SD.grad, "dsd")):
+        err = float((got.double() - want).abs().max() / want.abs().max())
+        assert err < 2e-6, (name, err)
+    # deterministic: bit-identical on a second run
+    assert torch.equal(ops.chamfer_prob_backward(gl, a, J, c, I, ss, sd)[3], dsd)

@@ -13,11 +13,13 @@ batch = batch_to_device(synth.make_pair_batch(1234, 8, 16384, 512, 4, "slab"), d
 for _ in range(3):
     st.step(batch)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     st.step(batch)
     torch.cuda.synchronize()
 names = sys.argv[1:] or ["aten::fill_", "aten::zero_", "aten::copy_", "aten::add"]
 for ev in prof.key_averages(group_by_stack_n=6):
     if ev.key in names:
-        src = [f for f in ev.stack if "site-packages/torch" not in f and "dist-packages/torch" not in f][:2]
-        print("%4d  %-14s %s" % (ev.count, ev.key, " <- ".join(s.split("/")[-1] for s in src) or str(ev.stack[:1])))
+        src = [f for f in ev.stack if "site-packages/torch" not in f and "dist-packages/torch" not in f
+               and not f.startswith("<built-in")][:3]
+        print("%4d  %-18s %s" % (ev.count, ev.key, " <- ".join(s.split("/")[-1] for s in src) or str(ev.stack[:2])))

@@ -27,6 +27,9 @@ SIGNATURES = {
     "usip_nearest_backward_f32": ([_f32p, _f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream],
                                   _int),
     "usip_nearest_nd_f32": ([_f32p, _f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
+    "usip_chamfer_prob_f32": ([_f32p, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_chamfer_prob_backward_f32": ([_f32p, _f32p, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
+                                        _f32p, _int, _int, _int, _stream], _int),
     "usip_nearest_workspace": ([_int, _int, _int], ctypes.c_longlong),
     "usip_nearest_f32": ([_f32p, _f32p, _f32p, _i32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_tiles": ([_int, _int, _int], _int),
@@ -55,6 +58,7 @@ SIGNATURES = {
     "usip_group_gather_backward_f32": ([_f32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _stream], _int),
     "usip_group_max_f32": ([_f32p, _f32p, _i32p, ctypes.c_longlong, _int, _stream], _int),
     "usip_group_max_backward_f32": ([_f32p, _i32p, _f32p, ctypes.c_longlong, _int, _stream], _int),
+    "usip_group_max_backward_add_f32": ([_f32p, _i32p, _f32p, ctypes.c_longlong, _int, _stream], _int),
     "usip_knn_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_fps_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_nms_f32": ([_f32p, _f32p, _flt, _i32p, _i32p, _int, _int, _stream], _int),

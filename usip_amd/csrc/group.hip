@@ -124,6 +124,17 @@ __global__ __launch_bounds__(256) void group_max_bwd4_kernel(
         make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f, a == 3 ? g : 0.f);
 }
 
+// dz[row][arg[row]] += dpooled[row]: the pooling gradient folded into a dense gradient that already exists
+// (the pooled tensor's source also fed a layer directly), touching rows elements instead of writing a dense
+// rows x K tensor and adding two dense tensors.
+__global__ __launch_bounds__(256) void group_max_bwd_add_kernel(
+    const float* __restrict__ dpooled, const int32_t* __restrict__ arg, float* __restrict__ dz, long long rows, int K)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    dz[row * K + arg[row]] += dpooled[row];
+}
+
 // Scatter-add through LDS: a workgroup owns CPB channels of one cloud, accumulates them in an
 // LDS table [CPB][N] with ds_add_f32 (neighbours of one neighbourhood are distinct points, so a wave
 // rarely hits one address twice) and writes the table out once.  N*CPB*4 B <= 64 KiB.
@@ -278,6 +289,20 @@ extern "C" int usip_group_max_backward_f32(const float* dpooled, const int32_t* 
     if (blocks > 0x7fffffffLL) return USIP_EINVAL;
     USIP_LAUNCH(group_max_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                 dpooled, arg, dz, total, K);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_group_max_backward_add_f32(const float* dpooled, const int32_t* arg, float* dz,
+                                               long long rows, int K, void* stream)
+{
+    if (rows < 0 || K < 1) return USIP_EINVAL;
+    if (rows == 0) return USIP_OK;
+    if (!dpooled || !arg || !dz) return USIP_EINVAL;
+    const long long blocks = (rows + 255) / 256;
+    if (blocks > 0x7fffffffLL) return USIP_EINVAL;
+    USIP_LAUNCH(group_max_bwd_add_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                dpooled, arg, dz, rows, K);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -49,11 +49,10 @@ class _NearestDistance(torch.autograd.Function):
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         d, arg32 = ops.nearest(a, b) if a.shape[1] == 3 else ops.nearest_nd(a, b)
-        arg = arg32.long()
         ctx.save_for_backward(a, b, d, arg32)
-        ctx.mark_non_differentiable(arg)
+        ctx.mark_non_differentiable(arg32)
         ctx.set_materialize_grads(False)
-        return d, arg
+        return d, arg32
 
     @staticmethod
     def backward(ctx, gd, _garg):
@@ -64,11 +63,45 @@ class _NearestDistance(torch.autograd.Function):
         return (ga if ctx.needs_input_grad[0] else None), gb
 
 
-def nearest_distance(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """a [B,C,Ma], b [B,C,Nb] -> (min distance [B,Ma], arg-min int64 [B,Ma]).  C == 3: coordinates (exact
-    oracle arithmetic); any other C: descriptors (Nb <= 1024)."""
+def nearest_distance_i32(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """As nearest_distance, arg-min as the kernels produce it (int32)."""
     require_device(a, "nearest_distance")
     return _NearestDistance.apply(a, b)
+
+
+class _ChamferProb(torch.autograd.Function):
+    """The sigma arithmetic of the probabilistic chamfer loss (models/losses.py:82-99) on the minima of the two
+    nearest-neighbour reductions: one forward and one backward launch instead of ~110 element-wise ones."""
+
+    @staticmethod
+    def forward(ctx, a, J, c, I, sigma_src, sigma_dst):
+        sigma_src, sigma_dst = sigma_src.contiguous(), sigma_dst.contiguous()
+        out = ops.chamfer_prob(a, J, c, I, sigma_src, sigma_dst)
+        ctx.save_for_backward(a, J, c, I, sigma_src, sigma_dst)
+        ctx.set_materialize_grads(False)
+        loss, pure, weighted = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(pure, weighted)
+        return loss, pure, weighted
+
+    @staticmethod
+    def backward(ctx, gloss, _gp, _gw):
+        if gloss is None:
+            return (None,) * 6
+        a, J, c, I, ss, sd = ctx.saved_tensors
+        da, dc, dss, dsd = ops.chamfer_prob_backward(gloss.contiguous(), a, J, c, I, ss, sd)
+        return da, None, dc, None, dss, dsd
+
+
+def chamfer_prob(a, J32, c, I32, sigma_src, sigma_dst):
+    """-> (loss, chamfer_pure, chamfer_weighted), 0-dim tensors; the last two carry no gradient."""
+    return _ChamferProb.apply(a, J32, c, I32, sigma_src, sigma_dst)
+
+
+def nearest_distance(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """a [B,C,Ma], b [B,C,Nb] -> (min distance [B,Ma], arg-min int64 [B,Ma] as torch.min returns it).  C == 3:
+    coordinates (exact oracle arithmetic); any other C: descriptors (Nb <= 1024)."""
+    d, arg32 = nearest_distance_i32(a, b)
+    return d, arg32.long()
 
 
 def knn_indices(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
@@ -194,6 +227,7 @@ class _SharedMLPLayer(torch.autograd.Function):
     def forward(ctx, x, xcoef, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
                 relu, defer, sink, link_in, link_out):
         ctx.sink, ctx.link_in, ctx.link_out = sink, link_in, link_out
+        ctx.set_materialize_grads(False)     # no zero-filled gradient for the (non-differentiable) coef output
         x = x.contiguous()
         # K-major copy of the weight [Cin][Cout]: the GEMM can also read W transposed in place (negative lda),
         # but the strided operand loads cost more (+0.3 ms/step measured) than these tiny copies
@@ -227,6 +261,8 @@ class _SharedMLPLayer(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, _dcoef):
+        if dz is None:
+            return (None,) * 16
         dz = dz.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
         tail = (None,) * 10
@@ -357,6 +393,7 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         B, Ch, M, K = dims
         Cp = pooled.shape[1]
         Cout = w2.shape[0]
+        ctx.set_materialize_grads(False)
         poff, hoff = (0, Cp) if pooled_first else (Ch, 0)
         h3 = h.contiguous().view(B, Ch, M * K)
         pooled = pooled.contiguous()
@@ -377,6 +414,8 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, _dcoef):
+        if dz is None:
+            return (None,) * 19
         h3, hcoef, pooled, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         B, Ch, Cp, Cout, M, K, poff, hoff = ctx.dims
         dz = dz.contiguous().view(B, Cout, M * K)
@@ -384,8 +423,8 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         # this layer needs the per-neighbourhood sums as well, which only the stand-alone pass produces
         dgamma, dbeta, coef4, gsum = _own_bn_backward(None, dz, y, coef, mean, invstd, gamma, ctx.relu, sink, group=K)
         # sum over the K neighbours of dY = a1*dYhat + q1*y + q0
-        sdy = (coef4[0].view(1, -1, 1) * gsum[0] + coef4[2].view(1, -1, 1) * gsum[1]
-               + float(K) * coef4[3].view(1, -1, 1)).contiguous()
+        sdy = torch.addcmul(torch.addcmul(float(K) * coef4[3].view(1, -1, 1), coef4[0].view(1, -1, 1), gsum[0]),
+                            coef4[2].view(1, -1, 1), gsum[1]).contiguous()
         w2c = w2.contiguous()
         dpooled = dh = dw = None
         if ctx.needs_input_grad[3]:
@@ -501,6 +540,42 @@ class _GroupMaxAct(torch.autograd.Function):
     def backward(ctx, dpooled):
         (arg,) = ctx.saved_tensors
         return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K), None, None
+
+
+class _GroupMaxActFork(torch.autograd.Function):
+    """max over K of a lazily activated layer output that ALSO feeds another layer directly
+    (networks.py:706-709, layers.py:433-436: the pooled feature is concatenated back onto its own source).
+    Returns (pooled, alias of y); in backward the sparse pooling gradient is added into the dense gradient
+    that arrives for the alias, in place, instead of being written as a second dense tensor and summed."""
+
+    @staticmethod
+    def forward(ctx, y4, coef, relu):
+        pooled, arg = ops.group_max_act(y4.contiguous(), coef, relu)
+        ctx.save_for_backward(arg)
+        ctx.K = y4.shape[3]
+        ctx.set_materialize_grads(False)
+        return pooled, y4.view_as(y4)
+
+    @staticmethod
+    def backward(ctx, dpooled, dy):
+        (arg,) = ctx.saved_tensors
+        if dpooled is None:
+            return dy, None, None
+        if dy is None:
+            return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K), None, None
+        # dy is the data gradient the consuming layer just produced for this node alone (contiguous() copies
+        # anything autograd may have expanded), so it can be updated in place
+        return ops.group_max_backward_add_(dy.contiguous(), dpooled.contiguous(), arg), None, None
+
+
+def group_max_fork(z):
+    """(max over K, z) for a tensor that is pooled AND passed on: for a LazyAct the returned z is an alias whose
+    gradient is combined with the pooling gradient in one sparse update (see _GroupMaxActFork)."""
+    if isinstance(z, LazyAct) and _group_sums_supported(z.shape[3]):
+        z.use(False)
+        pooled, y = _GroupMaxActFork.apply(z.y.view(z.shape), z.coef, z.relu)
+        return pooled, LazyAct(y.view(z.y.shape), z.coef, z.relu, z.shape, z.link)
+    return group_max(z), z
 
 
 def group_max(z) -> torch.Tensor:

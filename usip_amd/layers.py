@@ -184,7 +184,7 @@ class GeneralKNNFusionModule(nn.Module):
         h = Fh.knn_group(x, database.detach(), query.detach(), knn_I)    # :422-430
         for layer in self.layers_before:
             h = layer(h, epoch, defer=True)
-        pooled = Fh.group_max(h)                                         # :433 (BN+ReLU+max in one pass)
+        pooled, h = Fh.group_max_fork(h)                                 # :433 (BN+ReLU+max in one pass)
         first, rest = self.layers_after[0], list(self.layers_after)[1:]
         bn = getattr(first, "norm", None)
         if bn is not None:

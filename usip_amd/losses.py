@@ -17,20 +17,12 @@ class ChamferLoss_Brute(nn.Module):
         self.dimension = 3
 
     def forward(self, pc_src_input, pc_dst_input, sigma_src=None, sigma_dst=None):
-        a, J = Fh.nearest_distance(pc_src_input, pc_dst_input)          # row minima  (:81)
-        c, I = Fh.nearest_distance(pc_dst_input, pc_src_input)          # column minima (:86)
-        self.last_indices = (J, I)
+        a, J = Fh.nearest_distance_i32(pc_src_input, pc_dst_input)      # row minima  (:81)
+        c, I = Fh.nearest_distance_i32(pc_dst_input, pc_src_input)      # column minima (:86)
+        self.last_indices = (J, I)                                       # int32 (torch.min gives int64)
         if sigma_src is None or sigma_dst is None:                       # losses.py:68-78
             return a + c, a + c, a + c
-        s_fwd = (sigma_src + torch.gather(sigma_dst, 1, J)) / 2
-        forward_loss = (torch.log(s_fwd) + a / s_fwd).mean()
-        s_bwd = (sigma_dst + torch.gather(sigma_src, 1, I)) / 2
-        backward_loss = (torch.log(s_bwd) + c / s_bwd).mean()
-        chamfer_pure = (a.mean() + c.mean()).detach()
-        w_fwd = (1.0 / s_fwd) / torch.mean(1.0 / s_fwd)
-        w_bwd = (1.0 / s_bwd) / torch.mean(1.0 / s_bwd)
-        chamfer_weighted = ((w_fwd * a).mean() + (w_bwd * c).mean()).detach()
-        return forward_loss + backward_loss, chamfer_pure, chamfer_weighted
+        return Fh.chamfer_prob(a, J, c, I, sigma_src, sigma_dst)         # :82-99, one launch
 
 
 class SingleSideChamferLoss_Brute(nn.Module):
@@ -42,8 +34,7 @@ class SingleSideChamferLoss_Brute(nn.Module):
         self.dimension = 3
 
     def forward(self, pc_src_input, pc_dst_input):
-        return Fh.nearest_distance(pc_src_input, pc_dst_input.detach()
-                                   if not pc_dst_input.requires_grad else pc_dst_input)[0]
+        return Fh.nearest_distance_i32(pc_src_input, pc_dst_input)[0]
 
 
 class KeypointOnPCLoss(nn.Module):
@@ -73,8 +64,8 @@ class DescPairScanLoss(nn.Module):
         self.opt = opt
 
     def forward(self, anc_descriptors, pos_descriptors, neg_descriptors, anc_sigmas):
-        d_pos, _ = Fh.nearest_distance(anc_descriptors, pos_descriptors)
-        d_neg, _ = Fh.nearest_distance(anc_descriptors, neg_descriptors)
+        d_pos, _ = Fh.nearest_distance_i32(anc_descriptors, pos_descriptors)
+        d_neg, _ = Fh.nearest_distance_i32(anc_descriptors, neg_descriptors)
         before_clamp = d_pos - d_neg + self.opt.triple_loss_gamma
         active_percentage = torch.mean((before_clamp > 0).float(), dim=1)
         w = torch.clamp(self.opt.sigma_max - anc_sigmas, min=0)

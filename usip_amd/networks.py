@@ -121,7 +121,7 @@ class RPN_Detector_Ball(_DetectorTail):
         g = ops.group_gather(x_aug, ball_idx32, sub=node)                 # gather + decenter :699-703
         # activations stay lazy between the layers: BN+ReLU is applied by the consumer's prologue
         h = self.conv3(self.conv2(self.conv1(g, defer=True), defer=True), defer=True)   # no epoch: networks.py:705
-        pooled = Fh.group_max(h)                                          # :706
+        pooled, h = Fh.group_max_fork(h)                                  # :706
         h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
                                      getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
                                      pooled_first=False, defer=True)      # cat(h, expand(max)) :708-709
@@ -172,7 +172,7 @@ class DescriptorLiteOld(nn.Module):
         ball_idx32 = ops.ball_query_coords(keypoints, x, float(self.opt.ball_radius), K)      # :352-356 fused
         x_features = ops.group_gather(x_aug.contiguous(), ball_idx32, sub=keypoints)          # :358-370
         h = self.conv3(self.conv2(self.conv1(x_features, defer=True), defer=True), defer=True)   # :373
-        pooled = Fh.group_max(h)                                                               # :374
+        pooled, h = Fh.group_max_fork(h)                                                       # :374
         h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
                                      getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
                                      pooled_first=False, defer=True)                           # :375-377

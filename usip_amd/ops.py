@@ -146,6 +146,41 @@ def nearest(a: torch.Tensor, b: torch.Tensor):
     return d, arg
 
 
+def chamfer_prob(a, J, c, I, sigma_src, sigma_dst):
+    """(loss, chamfer_pure, chamfer_weighted) as a 3-vector from the nearest-neighbour minima a [B,M] / J i32
+    and c [B,N] / I i32 and the two sigma maps (models/losses.py:82-99)."""
+    for t, n in ((a, "a"), (c, "c"), (sigma_src, "sigma_src"), (sigma_dst, "sigma_dst")):
+        _need(t, n, torch.float32)
+    _need(J, "J", torch.int32)
+    _need(I, "I", torch.int32)
+    B, M = a.shape
+    N = c.shape[1]
+    if J.shape != a.shape or I.shape != c.shape or sigma_src.shape != a.shape or sigma_dst.shape != c.shape:
+        raise RuntimeError("chamfer_prob: shapes do not match")
+    out = torch.empty(3, dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), prof.kernel("chamfer_prob", 4.0 * 3 * B * (M + N), 0.0):
+        _lib.check(_lib.lib().usip_chamfer_prob_f32(_ptr(a), _ptr(J), _ptr(c), _ptr(I), _ptr(sigma_src),
+                                                    _ptr(sigma_dst), _ptr(out), B, M, N, _stream(a)),
+                   "usip_chamfer_prob_f32")
+    return out
+
+
+def chamfer_prob_backward(gloss, a, J, c, I, sigma_src, sigma_dst):
+    """-> (da, dc, dsigma_src, dsigma_dst) for the upstream gradient `gloss` (0-dim device tensor) of the loss."""
+    B, M = a.shape
+    N = c.shape[1]
+    _need(gloss, "gloss", torch.float32)
+    da, dc = torch.empty_like(a), torch.empty_like(c)
+    dss, dsd = torch.empty_like(sigma_src), torch.empty_like(sigma_dst)
+    ws = torch.empty(B * (M + N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device), prof.kernel("chamfer_prob_bwd", 4.0 * 7 * B * (M + N), 0.0):
+        _lib.check(_lib.lib().usip_chamfer_prob_backward_f32(_ptr(gloss), _ptr(a), _ptr(J), _ptr(c), _ptr(I),
+                                                             _ptr(sigma_src), _ptr(sigma_dst), _ptr(da), _ptr(dc),
+                                                             _ptr(dss), _ptr(dsd), _ptr(ws), B, M, N, _stream(a)),
+                   "usip_chamfer_prob_backward_f32")
+    return da, dc, dss, dsd
+
+
 # --------------------------------------------------------------------------- shared MLP
 def _opt(t):
     return _ptr(t) if t is not None else None
@@ -405,6 +440,20 @@ def group_max_backward(dpooled, arg, K: int):
     with torch.cuda.device(dpooled.device), prof.kernel("group_max_bwd", 4.0 * B * C * M * (K + 2)):
         _lib.check(_lib.lib().usip_group_max_backward_f32(_ptr(dpooled), _ptr(arg), _ptr(dz), B * C * M, int(K),
                                                           _stream(dpooled)), "usip_group_max_backward_f32")
+    return dz
+
+
+def group_max_backward_add_(dz, dpooled, arg):
+    """In place: dz[b,c,m,arg[b,c,m]] += dpooled[b,c,m]; returns dz."""
+    _need(dz, "dz", torch.float32)
+    _need(dpooled, "dpooled", torch.float32)
+    _need(arg, "arg", torch.int32)
+    B, C, M, K = dz.shape
+    if dpooled.shape != (B, C, M) or arg.shape != (B, C, M):
+        raise RuntimeError("group_max_backward_add_: shapes do not match")
+    with torch.cuda.device(dz.device), prof.kernel("group_max_bwd_add", 4.0 * B * C * M * 4):
+        _lib.check(_lib.lib().usip_group_max_backward_add_f32(_ptr(dpooled), _ptr(arg), _ptr(dz), B * C * M, int(K),
+                                                              _stream(dz)), "usip_group_max_backward_add_f32")
     return dz
 
 

@@ -65,20 +65,21 @@ class DetectorStep:
     def forward_losses(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None):
         B = batch["src_pc"].shape[0]
         self.detector.train()                                 # keypoint_detector.py:171
-        nodes, kp, sg, _ = self.detector(torch.cat((batch["src_pc"], batch["dst_pc"]), 0),
-                                         torch.cat((batch["src_sn"], batch["dst_sn"]), 0),
+        pc = torch.cat((batch["src_pc"], batch["dst_pc"]), 0)
+        nodes, kp, sg, _ = self.detector(pc, torch.cat((batch["src_sn"], batch["dst_sn"]), 0),
                                          torch.cat((batch["src_node"], batch["dst_node"]), 0),
                                          True, epoch)         # forward_siamese :141-156
         kp_src, kp_dst = torch.split(kp, B, dim=0)            # :147-149 (split: one backward node, no zero fills)
         sg_src, sg_dst = torch.split(sg, B, dim=0)
-        kp_t = torch.matmul(batch["R"], kp_src)               # :182
-        kp_t = kp_t * batch["scale"].unsqueeze(1).unsqueeze(2)   # :183
-        kp_t = kp_t + batch["shift"]                          # :184
+        # :182-184  R.kp*s + t  as one batched GEMM with the scale folded into R (inputs, no gradient)
+        kp_t = torch.baddbmm(batch["shift"], batch["R"] * batch["scale"].view(-1, 1, 1), kp_src)
         loss_chamfer, pure, weighted = self.chamfer_criteria(kp_t, kp_dst, sg_src, sg_dst)
         alpha = self.opt.keypoint_on_pc_alpha
-        on_src = torch.mean(self.keypoint_on_pc_criteria(kp_src, batch["src_pc"], None)) * alpha
-        on_dst = torch.mean(self.keypoint_on_pc_criteria(kp_dst, batch["dst_pc"], None)) * alpha
-        loss = loss_chamfer + on_src + on_dst                 # :204
+        # :196-203  keypoint-on-pc for src and dst: both clouds of every pair in ONE nearest-neighbour launch
+        # (rows [0,B) = src, [B,2B) = dst; every cloud is independent, so the values are the reference's)
+        on_pc = self.keypoint_on_pc_criteria(kp, pc, None).view(2, -1).mean(dim=1) * alpha
+        on_src, on_dst = on_pc[0], on_pc[1]
+        loss = loss_chamfer + on_pc.sum()                     # :204
         self.last = dict(node=nodes, keypoints=kp, sigmas=sg, loss=loss, loss_chamfer=loss_chamfer,
                          chamfer_pure=pure, chamfer_weighted=weighted, loss_on_pc_src=on_src,
                          loss_on_pc_dst=on_dst)
