@@ -276,3 +276,27 @@ def test_descriptor_step_matches_reference():
             continue
         gr = p.grad.detach().cpu().numpy().ravel().astype(np.float64)
         assert abs(np.sqrt((gr ** 2).sum()) - float(g["grad_norm/" + k])) <= 2e-2 * float(g["grad_norm/" + k]), k
+
+
+def test_adam_update_matches_reference_optimizer():
+    """a-11 ends with optimizer.step() (keypoint_detector.py:42-45, :207: Adam, lr, betas (0.9, 0.999)).
+    The step's multi-tensor Adam on gradients that live in the flat all-reduce bucket must move the parameters
+    exactly as torch.optim.Adam's plain single-tensor implementation does on the same gradients."""
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8)
+    torch.manual_seed(5)
+    st = DetectorStep("ball", opt, DEV, with_optimizer=True)
+    batch = batch_to_device(synth.make_pair_batch(7, 2, 1024, 32, 4, "sphere"), DEV)
+    names = [n for n, p in st.detector.named_parameters() if p.requires_grad]
+    ref = [p.detach().cpu().clone().requires_grad_(True) for p in st.bucket.params]
+    ref_opt = torch.optim.Adam(ref, lr=opt.lr, betas=(0.9, 0.999), foreach=False, fused=False)
+    for it in range(3):
+        st.step(batch)
+        for r, p in zip(ref, st.bucket.params):
+            assert p.grad.data_ptr() >= st.bucket.flat.data_ptr()           # still a view into the bucket
+            r.grad = p.grad.detach().cpu().clone()
+        ref_opt.step()
+        for n, r, p in zip(names, ref, st.bucket.params):
+            assert_close(p.detach().cpu().numpy(), r.detach().numpy(), rel=2e-6, name="%s after step %d" % (n, it + 1))

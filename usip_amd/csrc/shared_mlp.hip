@@ -422,20 +422,27 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-__global__ __launch_bounds__(64) void bn_finalize_kernel(
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ stats, int ntn, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
     float* __restrict__ running_var, float* __restrict__ mean_out, float* __restrict__ invstd_out,
     float* __restrict__ coef)
 {
-    const int ch = blockIdx.x, lane = threadIdx.x;
+    // one workgroup of four waves per channel (a single wave spent 26 us on the 4096 partials of the widest
+    // layers, latency bound); fixed partition and fixed combination order, so the result is deterministic
+    __shared__ double red[2][4];
+    const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
-    for (int t = lane; t < ntn; t += 64) {
+    for (int t = threadIdx.x; t < ntn; t += 256) {
         s += (double)stats[(long long)ch * ntn + t];
         q += (double)stats[(long long)ntn * C + (long long)ch * ntn + t];
     }
     s = wave_sum(s); q = wave_sum(q);
-    if (lane == 0) {
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
         const double mean = s / count;
         double var = q / count - mean * mean;                 // biased, as F.batch_norm normalises
         if (var < 0.0) var = 0.0;
@@ -781,7 +788,7 @@ extern "C" int usip_bn_finalize_f32(const float* stats, int ntiles, int C, long 
 {
     if (!stats || ntiles < 1 || C < 1 || count < 1 || !mean || !invstd || !coef) return USIP_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return USIP_EINVAL;
-    USIP_LAUNCH(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, ntiles, C, (double)count,
+    USIP_LAUNCH(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, stats, ntiles, C, (double)count,
                 gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, coef);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
