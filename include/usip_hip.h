@@ -109,11 +109,11 @@ int usip_chamfer_prob_f32(const float* a, const int32_t* J, const float* c, cons
                           int B, int M, int N, void* stream);
 /* Its backward for an upstream gradient gloss[0] (device scalar) of out3[0]: da [B][M], dc [B][N],
  * dsigma_src [B][M], dsigma_dst [B][N] (every element written; the gather's transpose is a deterministic
- * segmented sum).  workspace: B*(M+N) floats. */
+ * segmented sum). */
 int usip_chamfer_prob_backward_f32(const float* gloss, const float* a, const int32_t* J, const float* c,
                                    const int32_t* I, const float* sigma_src, const float* sigma_dst,
                                    float* da, float* dc, float* dsigma_src, float* dsigma_dst,
-                                   float* workspace, int B, int M, int N, void* stream);
+                                   int B, int M, int N, void* stream);
 
 /* f-1 (descriptor head): the same minimum / first arg-minimum for C-dimensional points a [B][C][Ma],
  * b [B][C][Nb] (Nb <= 1024) -- the M x M descriptor-distance matrices of DescPairScanLoss

@@ -19,7 +19,7 @@ with profile(activities=[ProfilerActivity.CPU], with_stack=True,
     torch.cuda.synchronize()
 names = sys.argv[1:] or ["aten::fill_", "aten::zero_", "aten::copy_", "aten::add"]
 for ev in prof.key_averages(group_by_stack_n=6):
-    if ev.key in names:
+    if ev.key in names or any(n.startswith("~") and n[1:] in ev.key for n in names):   # "~sub": substring match
         src = [f for f in ev.stack if "site-packages/torch" not in f and "dist-packages/torch" not in f
                and not f.startswith("<built-in")][:3]
         print("%4d  %-18s %s" % (ev.count, ev.key, " <- ".join(s.split("/")[-1] for s in src) or str(ev.stack[:2])))

@@ -29,7 +29,7 @@ SIGNATURES = {
     "usip_nearest_nd_f32": ([_f32p, _f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_chamfer_prob_f32": ([_f32p, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
     "usip_chamfer_prob_backward_f32": ([_f32p, _f32p, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
-                                        _f32p, _int, _int, _int, _stream], _int),
+                                        _int, _int, _int, _stream], _int),
     "usip_nearest_workspace": ([_int, _int, _int], ctypes.c_longlong),
     "usip_nearest_f32": ([_f32p, _f32p, _f32p, _i32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_tiles": ([_int, _int, _int], _int),

@@ -65,60 +65,69 @@ __global__ __launch_bounds__(1024) void chamfer_prob_fwd_kernel(
     }
 }
 
-// One workgroup per pair b.  ds_f[m] = dL/ds_f, ds_b[n] = dL/ds_b;
-//   d sigma_src[m] = ds_f[m]/2 + sum_{n: I[n]==m} ds_b[n]/2     d sigma_dst[n] = ds_b[n]/2 + sum_{m: J[m]==n} ds_f[m]/2
+// Backward.  With h_f[m] = (dL/ds_f[m]) / 2 and h_b[n] = (dL/ds_b[n]) / 2:
+//   d sigma_src[m] = h_f[m] + sum_{n: I[n]==m} h_b[n]          d sigma_dst[n] = h_b[n] + sum_{m: J[m]==n} h_f[m]
+// A workgroup owns 64 targets of one pair; its four waves each scan a quarter of the sources (staged in LDS,
+// read as 16-B vectors) and the quarters are combined in a fixed order: deterministic, no atomics, no
+// workspace (the halves are recomputed from (d, arg, sigma) where they are needed).
 constexpr int CHUNK = 1024;
 
-__device__ __forceinline__ void side_backward(const float* __restrict__ d, const int* __restrict__ arg,
-                                              const float* __restrict__ s_own, const float* __restrict__ s_other,
-                                              float scale, int M, float* __restrict__ dd,
-                                              float* __restrict__ ds_own_half)
-{
-    for (int m = threadIdx.x; m < M; m += blockDim.x) {
-        const float s = (s_own[m] + s_other[arg[m]]) / 2.0f;
+struct Side {                                  // one direction of the loss, row b
+    const float* d; const int* arg; const float* s_own; const float* s_other; float scale;
+    __device__ __forceinline__ float half(int i, float* dd) const
+    {
+        const float s = (s_own[i] + s_other[arg[i]]) / 2.0f;
         const float r = 1.0f / s;
-        dd[m] = scale * r;
-        ds_own_half[m] = 0.5f * (scale * (r - d[m] * r * r));
+        if (dd) dd[i] = scale * r;                                        // dL/dd
+        return 0.5f * (scale * (r - d[i] * r * r));
     }
-}
+};
 
 __global__ __launch_bounds__(256) void chamfer_prob_bwd_kernel(
     const float* __restrict__ gloss, const float* __restrict__ a, const int* __restrict__ J,
     const float* __restrict__ c, const int* __restrict__ I, const float* __restrict__ ss,
     const float* __restrict__ sd, float* __restrict__ da, float* __restrict__ dc, float* __restrict__ dss,
-    float* __restrict__ dsd, float* __restrict__ half_f, float* __restrict__ half_b, int B, int M, int N)
+    float* __restrict__ dsd, int B, int M, int N)
 {
-    __shared__ int s_arg[CHUNK];
-    __shared__ float s_val[CHUNK];
-    const int b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) int s_arg[CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_val[CHUNK];
+    __shared__ float part[4][64];
+    const int b = blockIdx.y, tl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;
     const float g = gloss[0];
-    a += (long long)b * M; J += (long long)b * M; ss += (long long)b * M; da += (long long)b * M;
-    dss += (long long)b * M; half_f += (long long)b * M;
-    c += (long long)b * N; I += (long long)b * N; sd += (long long)b * N; dc += (long long)b * N;
-    dsd += (long long)b * N; half_b += (long long)b * N;
-    side_backward(a, J, ss, sd, g / ((float)B * (float)M), M, da, half_f);
-    side_backward(c, I, sd, ss, g / ((float)B * (float)N), N, dc, half_b);
-    __syncthreads();
-    // segmented sums, sources in ascending index order (fixed summation order)
+    const long long om = (long long)b * M, on = (long long)b * N;
+    const Side fwd{a + om, J + om, ss + om, sd + on, g / ((float)B * (float)M)};
+    const Side bwd{c + on, I + on, sd + on, ss + om, g / ((float)B * (float)N)};
     for (int pass = 0; pass < 2; ++pass) {
-        const int* arg = pass == 0 ? J : I;                 // pass 0: forward halves land on sigma_dst[J[m]]
-        const float* src = pass == 0 ? half_f : half_b;
-        const float* own = pass == 0 ? half_b : half_f;
-        float* dst = pass == 0 ? dsd : dss;
+        const Side& src = pass == 0 ? fwd : bwd;          // pass 0: h_f[m] lands on sigma_dst[J[m]]
+        const Side& own = pass == 0 ? bwd : fwd;
         const int ns = pass == 0 ? M : N, nd = pass == 0 ? N : M;
-        for (int t0 = 0; t0 < nd; t0 += blockDim.x) {
-            const int t = t0 + threadIdx.x;
-            float accv = (t < nd) ? own[t] : 0.f;
-            for (int c0 = 0; c0 < ns; c0 += CHUNK) {
-                const int len = min(CHUNK, ns - c0);
-                __syncthreads();
-                for (int i = threadIdx.x; i < len; i += blockDim.x) { s_arg[i] = arg[c0 + i]; s_val[i] = src[c0 + i]; }
-                __syncthreads();
-                if (t < nd)
-                    for (int i = 0; i < len; ++i) accv += (s_arg[i] == t) ? s_val[i] : 0.f;
+        float* dd = (pass == 0 ? dc + on : da + om);       // the target side's distance gradient
+        float* dst = (pass == 0 ? dsd + on : dss + om);
+        float acc = 0.f;
+        for (int c0 = 0; c0 < ns; c0 += CHUNK) {
+            const int len = min(CHUNK, ns - c0);
+            const int len4 = ((len + 15) / 16) * 4;        // sources per wave, a multiple of 4
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4 * len4; i += 256) {
+                s_arg[i] = (i < len) ? src.arg[c0 + i] : -1;
+                s_val[i] = (i < len) ? src.half(c0 + i, nullptr) : 0.f;
             }
-            if (t < nd) dst[t] = accv;
+            __syncthreads();
+            for (int i = q * len4; i < (q + 1) * len4; i += 4) {
+                const int4 k = *reinterpret_cast<const int4*>(&s_arg[i]);
+                const float4 v = *reinterpret_cast<const float4*>(&s_val[i]);
+                acc += (k.x == t) ? v.x : 0.f;
+                acc += (k.y == t) ? v.y : 0.f;
+                acc += (k.z == t) ? v.z : 0.f;
+                acc += (k.w == t) ? v.w : 0.f;
+            }
         }
+        part[q][tl] = acc;
+        __syncthreads();
+        if (q == 0 && t < nd)
+            dst[t] = own.half(t, dd) + ((part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]));
+        __syncthreads();
     }
 }
 
@@ -138,13 +147,14 @@ extern "C" int usip_chamfer_prob_f32(const float* a, const int32_t* J, const flo
 extern "C" int usip_chamfer_prob_backward_f32(const float* gloss, const float* a, const int32_t* J, const float* c,
                                               const int32_t* I, const float* sigma_src, const float* sigma_dst,
                                               float* da, float* dc, float* dsigma_src, float* dsigma_dst,
-                                              float* workspace, int B, int M, int N, void* stream)
+                                              int B, int M, int N, void* stream)
 {
     if (B < 1 || M < 1 || N < 1 || !gloss || !a || !J || !c || !I || !sigma_src || !sigma_dst || !da || !dc ||
-        !dsigma_src || !dsigma_dst || !workspace)
+        !dsigma_src || !dsigma_dst || B > 65535)
         return USIP_EINVAL;
-    USIP_LAUNCH(chamfer_prob_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, gloss, a, J, c, I, sigma_src,
-                sigma_dst, da, dc, dsigma_src, dsigma_dst, workspace, workspace + (long long)B * M, B, M, N);
+    const int mx = M > N ? M : N;
+    USIP_LAUNCH(chamfer_prob_bwd_kernel, dim3(usip_ceil_div(mx, 64), B), dim3(256), 0, (hipStream_t)stream, gloss, a,
+                J, c, I, sigma_src, sigma_dst, da, dc, dsigma_src, dsigma_dst, B, M, N);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -172,11 +172,10 @@ def chamfer_prob_backward(gloss, a, J, c, I, sigma_src, sigma_dst):
     _need(gloss, "gloss", torch.float32)
     da, dc = torch.empty_like(a), torch.empty_like(c)
     dss, dsd = torch.empty_like(sigma_src), torch.empty_like(sigma_dst)
-    ws = torch.empty(B * (M + N), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device), prof.kernel("chamfer_prob_bwd", 4.0 * 7 * B * (M + N), 0.0):
         _lib.check(_lib.lib().usip_chamfer_prob_backward_f32(_ptr(gloss), _ptr(a), _ptr(J), _ptr(c), _ptr(I),
                                                              _ptr(sigma_src), _ptr(sigma_dst), _ptr(da), _ptr(dc),
-                                                             _ptr(dss), _ptr(dsd), _ptr(ws), B, M, N, _stream(a)),
+                                                             _ptr(dss), _ptr(dsd), B, M, N, _stream(a)),
                    "usip_chamfer_prob_backward_f32")
     return da, dc, dss, dsd
 
