@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="f32 = fp32 MFMA (parity mode, the headline); bf16 = bf16 multiply / fp32 accumulate in the "
                          "shared-MLP kernels, tensors stay fp32 (perf mode of BASELINE configs[1]; NOT the headline)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from the host instead of replaying the step from HIP graphs")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -132,8 +134,16 @@ def main():
                                      neg_idx=np.roll(np.arange(pairs), 1).astype(np.int64)), dev)
         args.pairs = pairs
     else:
-        st = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer)
+        st = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer, graph=not args.no_graph)
         batch = batch_to_device(synth.make_pair_batch(1234 + rank, args.pairs, args.n, args.m, 4, args.cloud), dev)
+        if not args.no_graph:
+            # set-up, not warm-up: two eager steps (allocator, rocBLAS handles) and the graph capture happen here,
+            # so that the W warm-up steps and the K timed steps below are all steady-state steps
+            for _ in range(3):
+                st.step(batch)
+            batch = st.static_batch(batch) or batch          # feed the captured input buffers directly
+
+    graphed = args.model != "descriptor" and not args.no_graph
 
     def barrier():
         if world > 1:
@@ -144,9 +154,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     # Per-kernel HIP events cost ~3 us of stream bubble each (~0.7 ms per step for ~220 of them): they are
-    # recorded on every 4th step of the timed region, which keeps the headline number within ~1.5 % of an
-    # uninstrumented run while the kernel durations still come from inside the timed region.
-    sample_every = 4
+    # recorded on every 4th (eager) / 10th (graph replay) step of the timed region, which keeps the headline
+    # number within ~1.5 % of an uninstrumented run while the kernel durations still come from inside the
+    # timed region.
+    # Sampled steps are launched eagerly (a graph replay cannot carry the events); the others replay the graphs.
+    sample_every = 10 if graphed else 4
     timed_steps_sampled = 0
     if not args.no_kernel_timing:
         prof.reset()
@@ -156,7 +168,10 @@ def main():
         sampled = (not args.no_kernel_timing) and (i % sample_every == 0)
         prof.enable(sampled)
         timed_steps_sampled += int(sampled)
-        st.step(batch)
+        if graphed:
+            st.step(batch, eager=sampled)
+        else:
+            st.step(batch)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -187,6 +202,8 @@ def main():
                        "ball_radius": 2, "ball_k": 64, "cloud": args.cloud,
                        "step": "fwd+losses+bwd" + ("+allreduce" if world > 1 else "") +
                                ("" if args.no_optimizer else "+adam"),
+                       "launch": "HIP graph replay (2 graphs per step, all-reduce between them)" if graphed
+                                 else "eager",
                        "parallelism": "dp%d" % world},
             "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,
         }

@@ -95,8 +95,9 @@ long long usip_nearest_workspace(int B, int Ma, int Nb);   /* elements of ws_d A
 int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
                      float* ws_d, int32_t* ws_j, int B, int Ma, int Nb, void* stream);
 /* Its backward (what autograd derives through torch.norm + torch.min + gather in the reference):
- * ga[b][:][i] = gd[b][i] * (a_i - b_J) / d, zero where d == 0; gb (may be NULL, else pre-zeroed)
- * receives the negative, scatter-added at J. */
+ * ga[b][:][i] = gd[b][i] * (a_i - b_J) / d, zero where d == 0; gb (may be NULL; every element is
+ * written) receives the negative summed over the queries that share a partner -- a deterministic segmented
+ * sum, not float atomics. */
 int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
                               const float* gd, float* ga, float* gb, int B, int C, int Ma, int Nb, void* stream);
 

@@ -300,3 +300,48 @@ def test_adam_update_matches_reference_optimizer():
         ref_opt.step()
         for n, r, p in zip(names, ref, st.bucket.params):
             assert_close(p.detach().cpu().numpy(), r.detach().numpy(), rel=2e-6, name="%s after step %d" % (n, it + 1))
+
+
+def test_graph_replay_equals_eager_steps():
+    """DetectorStep(graph=True): a step replayed from the captured HIP graphs is the eager step -- same kernels,
+    same order.  Without an optimizer the parameters stay put, so every call can be compared tightly (loss,
+    keypoints, every gradient, BatchNorm buffers); with Adam, whose first updates turn 1e-7 gradient noise (LDS
+    float atomics in the gather backward) into lr-sized differences, the replayed update is checked through its
+    step counter and through the loss trajectory at a loose tolerance."""
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8)
+    batches = [batch_to_device(synth.make_pair_batch(50 + i, 2, 2048, 64, 4, "sphere"), DEV) for i in range(5)]
+    torch.manual_seed(9)
+    eager = DetectorStep("ball", opt, DEV)
+    graph = DetectorStep("ball", opt, DEV, graph=True)
+    graph.detector.load_state_dict(eager.detector.state_dict())
+    for b in batches:                                  # calls 1-2 eager, call 3 captures + replays, 4-5 replay
+        le, lg = eager.step(b).detach(), graph.step(b).detach()
+        assert_close(lg.cpu().numpy(), le.cpu().numpy(), rel=1e-6, name="loss")
+        assert_close(graph.last["keypoints"].detach().cpu().numpy(), eager.last["keypoints"].detach().cpu().numpy(),
+                     rel=1e-6, name="keypoints")
+        ge, gg = eager.bucket.flat, graph.bucket.flat
+        assert float((ge - gg).norm() / ge.norm()) < 1e-5
+    assert len(graph._graphs) == 1
+    sg = graph.detector.state_dict()
+    for k, v in eager.detector.state_dict().items():   # BatchNorm running statistics and counters
+        if v.dtype.is_floating_point:
+            assert_close(sg[k].cpu().numpy(), v.cpu().numpy(), rel=1e-6, name=k)
+        else:
+            assert torch.equal(sg[k], v), k
+    # a batch of another shape captures its own graph (after running eagerly where needed)
+    other = batch_to_device(synth.make_pair_batch(77, 1, 1024, 32, 4, "sphere"), DEV)
+    assert_close(graph.step(other).detach().cpu().numpy(), eager.step(other).detach().cpu().numpy(), rel=1e-6, name="loss")
+    assert len(graph._graphs) == 2
+    # with Adam
+    torch.manual_seed(9)
+    eager = DetectorStep("ball", opt, DEV, with_optimizer=True)
+    graph = DetectorStep("ball", opt, DEV, with_optimizer=True, graph=True)
+    graph.detector.load_state_dict(eager.detector.state_dict())
+    for b in batches:
+        le, lg = float(eager.step(b).detach()), float(graph.step(b).detach())
+        assert abs(le - lg) <= 2e-2 * max(abs(le), 0.1), (le, lg)
+    steps = {int(s["step"]) for s in graph.optimizer.state.values()}
+    assert steps == {len(batches)}

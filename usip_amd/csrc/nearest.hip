@@ -141,12 +141,10 @@ __global__ __launch_bounds__(256) void nearest_nd_kernel(
 }
 
 // Backward of (min distance, arg-min): ga[b,:,i] = gd[b,i] * (a_i - b_J) / d (0 where d == 0, as the
-// sub-gradient of torch.norm at zero), and, when gb != null, gb[b,:,J] -= the same (float atomics: several
-// queries may share a partner).  gb must be zeroed by the caller.
+// sub-gradient of torch.norm at zero).
 __global__ __launch_bounds__(256) void nearest_bwd_kernel(
     const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ d,
-    const int32_t* __restrict__ arg, const float* __restrict__ gd, float* __restrict__ ga,
-    float* __restrict__ gb, int C, int Ma, int Nb)
+    const int32_t* __restrict__ arg, const float* __restrict__ gd, float* __restrict__ ga, int C, int Ma, int Nb)
 {
     const int bi = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -157,10 +155,49 @@ __global__ __launch_bounds__(256) void nearest_bwd_kernel(
     const float sc = dist > 0.f ? gd[q] / dist : 0.f;
     const float* ab = a + (long long)bi * C * Ma;
     const float* bb = b + (long long)bi * C * Nb;
+    for (int c = 0; c < C; ++c)
+        ga[((long long)bi * C + c) * Ma + i] = (ab[(long long)c * Ma + i] - bb[(long long)c * Nb + j]) * sc;
+}
+
+// gb[b,:,j] = - sum_{i: arg[b,i] == j} ga[b,:,i]: several queries may share a partner.  A deterministic
+// segmented sum instead of float atomics (training runs are reproducible bit for bit): a workgroup owns 64
+// partners j of one cloud, its four waves each scan a quarter of the queries (arg and ga staged in LDS, read as
+// 16-B vectors), quarters combined in a fixed order.  Every element of gb is written.
+constexpr int BWD_CHUNK = 1024;
+__global__ __launch_bounds__(256) void nearest_bwd_partner_kernel(
+    const int32_t* __restrict__ arg, const float* __restrict__ ga, float* __restrict__ gb, int C, int Ma, int Nb)
+{
+    __shared__ __attribute__((aligned(16))) int s_arg[BWD_CHUNK];
+    __shared__ __attribute__((aligned(16))) float s_val[BWD_CHUNK];
+    __shared__ float part[4][64];
+    const int bi = blockIdx.y, tl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tl;
+    const int32_t* ar = arg + (long long)bi * Ma;
     for (int c = 0; c < C; ++c) {
-        const float g = (ab[(long long)c * Ma + i] - bb[(long long)c * Nb + j]) * sc;
-        ga[((long long)bi * C + c) * Ma + i] = g;
-        if (gb) atomicAdd(&gb[((long long)bi * C + c) * Nb + j], -g);
+        const float* gr = ga + ((long long)bi * C + c) * Ma;
+        float acc = 0.f;
+        for (int c0 = 0; c0 < Ma; c0 += BWD_CHUNK) {
+            const int len = min(BWD_CHUNK, Ma - c0);
+            const int len4 = ((len + 15) / 16) * 4;
+            __syncthreads();
+            for (int i = threadIdx.x; i < 4 * len4; i += 256) {
+                s_arg[i] = (i < len) ? ar[c0 + i] : -1;
+                s_val[i] = (i < len) ? gr[c0 + i] : 0.f;
+            }
+            __syncthreads();
+            for (int i = q * len4; i < (q + 1) * len4; i += 4) {
+                const int4 k = *reinterpret_cast<const int4*>(&s_arg[i]);
+                const float4 v = *reinterpret_cast<const float4*>(&s_val[i]);
+                acc += (k.x == j) ? v.x : 0.f;
+                acc += (k.y == j) ? v.y : 0.f;
+                acc += (k.z == j) ? v.z : 0.f;
+                acc += (k.w == j) ? v.w : 0.f;
+            }
+        }
+        part[q][tl] = acc;
+        __syncthreads();
+        if (q == 0 && j < Nb)
+            gb[((long long)bi * C + c) * Nb + j] = -((part[0][tl] + part[1][tl]) + (part[2][tl] + part[3][tl]));
     }
 }
 
@@ -174,8 +211,13 @@ extern "C" int usip_nearest_backward_f32(const float* a, const float* b, const f
     if ((long long)B * Ma == 0) return USIP_OK;
     if (!a || !b || !d || !arg || !gd || !ga || B > 65535) return USIP_EINVAL;
     USIP_LAUNCH(nearest_bwd_kernel, dim3(usip_ceil_div(Ma, 256), B), dim3(256), 0, (hipStream_t)stream,
-                a, b, d, arg, gd, ga, gb, C, Ma, Nb);
+                a, b, d, arg, gd, ga, C, Ma, Nb);
     USIP_LAUNCH_CHECK();
+    if (gb) {
+        USIP_LAUNCH(nearest_bwd_partner_kernel, dim3(usip_ceil_div(Nb, 64), B), dim3(256), 0, (hipStream_t)stream,
+                    arg, ga, gb, C, Ma, Nb);
+        USIP_LAUNCH_CHECK();
+    }
     return USIP_OK;
 }
 

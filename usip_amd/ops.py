@@ -475,7 +475,7 @@ def nearest_backward(a, b, d, arg32, gd, need_gb: bool):
     B, C, Ma = a.shape
     Nb = b.shape[2]
     ga = torch.empty_like(a)
-    gb = torch.zeros_like(b) if need_gb else None
+    gb = torch.empty_like(b) if need_gb else None
     with torch.cuda.device(a.device), prof.kernel("nearest_bwd", 4.0 * B * Ma * 12):
         _lib.check(_lib.lib().usip_nearest_backward_f32(_ptr(a), _ptr(b), _ptr(d), _ptr(arg32), _ptr(gd), _ptr(ga),
                                                         _opt(gb), B, C, Ma, Nb, _stream(a)),
