@@ -52,6 +52,9 @@ def parse():
                          "shared-MLP kernels, tensors stay fp32 (perf mode of BASELINE configs[1]; NOT the headline)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host instead of replaying the step from HIP graphs")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay from HIP graphs at N > 1 as well (default there: eager launches -- capture next to "
+                         "an RCCL communicator cannot be exercised on the 1-GPU development boxes)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -94,6 +97,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not args.graph:
+        args.no_graph = True
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     # One process per GPU over RCCL ("nccl" IS RCCL on ROCm).  USIP_DIST_BACKEND=gloo + USIP_SHARE_DEVICE=1 is a

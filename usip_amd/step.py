@@ -143,15 +143,24 @@ class DetectorStep:
                 return self.step(batch, epoch, group, eager=True)
             static = {k: v.clone() for k, v in batch.items()}
             torch.cuda.synchronize(self.device)
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                loss = self._forward_backward(static, epoch)
-            last = dict(self.last)
-            gb = None
-            if self.optimizer is not None:
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb):
-                    self.optimizer.step()
+            try:
+                # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
+                # must not invalidate the capture
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    loss = self._forward_backward(static, epoch)
+                last = dict(self.last)
+                gb = None
+                if self.optimizer is not None:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                        self.optimizer.step()
+            except RuntimeError as err:                       # capture refused: keep training with plain launches
+                import warnings
+                warnings.warn("usip_amd: HIP graph capture failed (%s); continuing with eager launches" % err)
+                torch.cuda.synchronize(self.device)
+                self.use_graph = False
+                return self.step(batch, epoch, group, eager=True)
             entry = self._graphs[key] = (ga, gb, static, last, loss)   # capture launches nothing: replay below
         ga, gb, static, last, loss = entry
         for k, v in batch.items():
