@@ -130,7 +130,7 @@ def main():
         args.no_cpu_baseline = True
         kp = 256 if args.m == 512 else args.m
         pairs = 4 if args.pairs == 8 else args.pairs
-        st = DescriptorStep(opt, dev, with_optimizer=not args.no_optimizer)
+        st = DescriptorStep(opt, dev, with_optimizer=not args.no_optimizer, graph=not args.no_graph)
         b0 = synth.make_pair_batch(1234 + rank, pairs, args.n, kp, 4, args.cloud)
         rng = np.random.default_rng(99 + rank)
         batch = batch_to_device(dict(anc_pc=b0["src_pc"], pos_pc=b0["dst_pc"], anc_sn=b0["src_sn"], pos_sn=b0["dst_sn"],
@@ -141,14 +141,14 @@ def main():
     else:
         st = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer, graph=not args.no_graph)
         batch = batch_to_device(synth.make_pair_batch(1234 + rank, args.pairs, args.n, args.m, 4, args.cloud), dev)
-        if not args.no_graph:
-            # set-up, not warm-up: two eager steps (allocator, rocBLAS handles) and the graph capture happen here,
-            # so that the W warm-up steps and the K timed steps below are all steady-state steps
-            for _ in range(3):
-                st.step(batch)
-            batch = st.static_batch(batch) or batch          # feed the captured input buffers directly
+    if not args.no_graph:
+        # set-up, not warm-up: two eager steps (allocator, rocBLAS handles) and the graph capture happen here,
+        # so that the W warm-up steps and the K timed steps below are all steady-state steps
+        for _ in range(3):
+            st.step(batch)
+        batch = st.static_batch(batch) or batch              # feed the captured input buffers directly
 
-    graphed = args.model != "descriptor" and not args.no_graph
+    graphed = not args.no_graph
 
     def barrier():
         if world > 1:

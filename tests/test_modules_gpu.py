@@ -345,3 +345,31 @@ def test_graph_replay_equals_eager_steps():
         assert abs(le - lg) <= 2e-2 * max(abs(le), 0.1), (le, lg)
     steps = {int(s["step"]) for s in graph.optimizer.state.values()}
     assert steps == {len(batches)}
+
+
+def test_descriptor_graph_replay_equals_eager():
+    """DescriptorStep(graph=True): the point permutation is a device input of the captured graph, so replayed
+    steps with a caller-given permutation reproduce the eager steps."""
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DescriptorStep, batch_to_device
+    opt = DetectorOptions(surface_normal_len=4)
+    torch.manual_seed(4)
+    eager = DescriptorStep(opt, DEV)
+    graph = DescriptorStep(opt, DEV, graph=True)
+    graph.descriptor.load_state_dict(eager.descriptor.state_dict())
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        b0 = synth.make_pair_batch(30 + i, 2, 2048, 32, 4, "slab")
+        batch = batch_to_device(dict(anc_pc=b0["src_pc"], pos_pc=b0["dst_pc"], anc_sn=b0["src_sn"], pos_sn=b0["dst_sn"],
+                                     anc_kp=b0["src_node"], pos_kp=b0["dst_node"],
+                                     anc_sigmas=rng.uniform(0.1, 3.0, (2, 32)).astype(np.float32),
+                                     neg_idx=np.array([1, 0], dtype=np.int64),
+                                     perm=rng.permutation(2048).astype(np.int64)), DEV)
+        le, lg = eager.step(batch).detach(), graph.step(batch).detach()
+        assert_close(lg.cpu().numpy(), le.cpu().numpy(), rel=1e-6, name="loss %d" % i)
+        assert_close(graph.last["descriptors"].detach().cpu().numpy(), eager.last["descriptors"].detach().cpu().numpy(),
+                     rel=1e-6, name="descriptors %d" % i)
+        assert float((eager.bucket.flat - graph.bucket.flat).norm() / eager.bucket.flat.norm()) < 1e-5
+    assert len(graph._graphs) == 1
+

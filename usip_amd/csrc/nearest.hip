@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void nearest_bwd_kernel(
 // partners j of one cloud, its four waves each scan a quarter of the queries (arg and ga staged in LDS, read as
 // 16-B vectors), quarters combined in a fixed order.  Every element of gb is written.
 constexpr int BWD_CHUNK = 1024;
+constexpr int BWD_CPB = 4;                       // channels per workgroup (descriptors: C = 128 -> 32 z-slices)
 __global__ __launch_bounds__(256) void nearest_bwd_partner_kernel(
     const int32_t* __restrict__ arg, const float* __restrict__ ga, float* __restrict__ gb, int C, int Ma, int Nb)
 {
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(256) void nearest_bwd_partner_kernel(
     const int bi = blockIdx.y, tl = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tl;
     const int32_t* ar = arg + (long long)bi * Ma;
-    for (int c = 0; c < C; ++c) {
+    const int cend = min(C, (int)(blockIdx.z + 1) * BWD_CPB);
+    for (int c = blockIdx.z * BWD_CPB; c < cend; ++c) {
         const float* gr = ga + ((long long)bi * C + c) * Ma;
         float acc = 0.f;
         for (int c0 = 0; c0 < Ma; c0 += BWD_CHUNK) {
@@ -214,7 +216,8 @@ extern "C" int usip_nearest_backward_f32(const float* a, const float* b, const f
                 a, b, d, arg, gd, ga, C, Ma, Nb);
     USIP_LAUNCH_CHECK();
     if (gb) {
-        USIP_LAUNCH(nearest_bwd_partner_kernel, dim3(usip_ceil_div(Nb, 64), B), dim3(256), 0, (hipStream_t)stream,
+        USIP_LAUNCH(nearest_bwd_partner_kernel, dim3(usip_ceil_div(Nb, 64), B, usip_ceil_div(C, BWD_CPB)), dim3(256),
+                    0, (hipStream_t)stream,
                     arg, ga, gb, C, Ma, Nb);
         USIP_LAUNCH_CHECK();
     }

@@ -160,11 +160,14 @@ class DescriptorLiteOld(nn.Module):
                               activation=None, normalization=None)
         self.fixed_permutation = None
 
-    def forward(self, x, sn, keypoints, is_train=False, epoch=None):
+    def forward(self, x, sn, keypoints, is_train=False, epoch=None, perm=None):
+        """perm (optional, int64 [N], any device): the point permutation of networks.py:345-347; default: the
+        module's fixed_permutation (tests) or a fresh numpy permutation as in the reference."""
         Fh.require_device(x, "DescriptorLiteOld")
         import numpy as np
         N, K = x.shape[2], int(self.opt.ball_nsamples)
-        perm = self.fixed_permutation if self.fixed_permutation is not None else np.random.permutation(N)
+        if perm is None:
+            perm = self.fixed_permutation if self.fixed_permutation is not None else np.random.permutation(N)
         perm = torch.as_tensor(perm, dtype=torch.int64, device=x.device)       # networks.py:345-347
         x = x[:, :, perm].contiguous()
         x_aug = torch.cat((x, sn[:, :, perm]), dim=1) if self.opt.surface_normal_len > 0 else x

@@ -42,41 +42,142 @@ class FlatGradBucket:
             self.flat.div_(dist.get_world_size(group))
 
 
-class DetectorStep:
-    """Owns detector + criteria (+ optimizer) on one device and runs optimize()-equivalent steps.
+class _GraphedStep:
+    """What DetectorStep and DescriptorStep share: the gradient bucket, the optimizer, and the optional replay
+    of the step from HIP graphs.
 
-    graph=True replays the step from HIP graphs: the ~250 kernel launches of one step are captured once
-    (third call; the first two run eagerly and are ordinary training steps) into
+    graph=True: the kernel launches of one step are captured once (third call; the first two run eagerly and
+    are ordinary training steps) into
         graph A = zero the gradient bucket, forward, losses, backward, BatchNorm counters
         graph B = the Adam update
     with the gradient all-reduce issued eagerly between them when world > 1.  Every call copies the batch into
     the captured input buffers (skipped when the caller already passes those buffers) and replays; the kernels,
     their order and their results are those of the eager step -- only the per-launch host work and the gaps
-    between launches go away (9.9 -> 9.4 ms per step measured).  A batch of another shape, or another BatchNorm
-    momentum (epoch-dependent decay), captures a new graph."""
+    between launches go away (detector: 9.65 -> 9.44 ms per step).  A batch of another shape, or another
+    BatchNorm momentum (epoch-dependent decay), captures a new graph."""
 
-    def __init__(self, model: str, opt, device, with_optimizer: bool = False, graph: bool = False):
+    def _setup(self, module, opt, device, with_optimizer: bool, graph: bool):
         self.opt = opt
         self.device = torch.device(device)
-        self.detector = build_detector(model, opt).to(self.device)
-        self.chamfer_criteria = ChamferLoss_Brute(opt)
-        self.keypoint_on_pc_criteria = KeypointOnPCLoss(opt)
-        self.bucket = FlatGradBucket(self.detector)
-        self.optimizer = None
+        self.module = module
+        self.bucket = FlatGradBucket(module)
         self.use_graph = bool(graph) and self.device.type == "cuda"
-        if with_optimizer:                                    # keypoint_detector.py:42-45
-            # the multi-tensor ("fused") implementation: one or two launches for all 50 tensors instead of ~8;
+        self.optimizer = None
+        if with_optimizer:                                    # keypoint_detector.py:42-45, keypoint_descriptor.py:38-41
+            # the multi-tensor ("fused") implementation: one or two launches for all tensors instead of ~8;
             # capturable keeps its step counters on the device so that the update can live in a HIP graph
-            self.optimizer = torch.optim.Adam(self.detector.parameters(), lr=opt.lr, betas=(0.9, 0.999),
+            self.optimizer = torch.optim.Adam(module.parameters(), lr=opt.lr, betas=(0.9, 0.999),
                                               fused=self.device.type == "cuda", capturable=self.use_graph)
         self.last: Dict[str, torch.Tensor] = {}
         self._graphs: Dict = {}                               # key -> (graph A, graph B or None, static batch, last, loss)
         self._eager_calls = 0
+        self._bn_counters = [m.num_batches_tracked for m in module.modules()
+                             if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
+                             and m.num_batches_tracked is not None]
 
     def load_numpy_state(self, state: Dict):
-        sd = self.detector.state_dict()
-        self.detector.load_state_dict({k: torch.as_tensor(v).reshape(sd[k].shape) for k, v in state.items()})
+        sd = self.module.state_dict()
+        self.module.load_state_dict({k: torch.as_tensor(v).reshape(sd[k].shape) for k, v in state.items()})
         # load_state_dict copies in place, gradients keep pointing into the flat bucket
+
+    def _prepare(self, batch):
+        """Hook: host-side inputs the step adds to the batch (the descriptor's point permutation)."""
+        return batch
+
+    def forward_losses(self, batch, epoch=None):
+        raise NotImplementedError
+
+    def _forward_backward(self, batch, epoch):
+        from . import functional as Fh
+        self.bucket.zero()                                    # zero_grad()
+        Fh.GRAD_SINK = True       # every parameter is used once per step and the bucket was just zeroed:
+        Fh.DEFER_BN_COUNTERS = True   # the backward kernels write dW/dgamma/dbeta straight into the bucket
+        try:
+            loss = self.forward_losses(batch, epoch)
+            loss.backward()
+        finally:
+            Fh.GRAD_SINK = False
+            Fh.DEFER_BN_COUNTERS = False
+        if self._bn_counters:
+            torch._foreach_add_(self._bn_counters, 1)         # every BatchNorm ran exactly once
+        return loss
+
+    def step(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None, group=None, eager: bool = False):
+        """forward + losses + backward (+ gradient all-reduce) (+ Adam when constructed with it).
+        eager=True forces plain launches for this call (bench.py does so on the steps it instruments with
+        HIP events, which a graph replay cannot carry)."""
+        batch = self._prepare(batch)
+        if self.use_graph and not eager:
+            return self._step_graph(batch, epoch, group)
+        return self._step_eager(batch, epoch, group)
+
+    def _step_eager(self, batch, epoch, group):
+        loss = self._forward_backward(batch, epoch)
+        self.bucket.all_reduce_mean(group)
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss
+
+    def _step_graph(self, batch, epoch, group):
+        decays = getattr(self.opt, "bn_momentum_decay_step", None)
+        key = (tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())),
+               epoch if (decays is not None and decays > 0) else None)
+        entry = self._graphs.get(key)
+        if entry is None:
+            if self._eager_calls < 2:                         # allocator, rocBLAS handles, lazily built state
+                self._eager_calls += 1
+                return self._step_eager(batch, epoch, group)
+            static = {k: v.clone() for k, v in batch.items()}
+            torch.cuda.synchronize(self.device)
+            try:
+                # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
+                # must not invalidate the capture
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                    loss = self._forward_backward(static, epoch)
+                last = dict(self.last)
+                gb = None
+                if self.optimizer is not None:
+                    gb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                        self.optimizer.step()
+            except RuntimeError as err:                       # capture refused: keep training with plain launches
+                import warnings
+                warnings.warn("usip_amd: HIP graph capture failed (%s); continuing with eager launches" % err)
+                torch.cuda.synchronize(self.device)
+                self.use_graph = False
+                return self._step_eager(batch, epoch, group)
+            entry = self._graphs[key] = (ga, gb, static, last, loss)   # capture launches nothing: replay below
+        ga, gb, static, last, loss = entry
+        for k, v in batch.items():
+            if v.data_ptr() != static[k].data_ptr():
+                static[k].copy_(v, non_blocking=True)
+        ga.replay()
+        self.bucket.all_reduce_mean(group)
+        if gb is not None:
+            gb.replay()
+        self.last = last
+        return loss
+
+    def static_batch(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The captured input buffers for batches shaped like `batch` (None before capture): a loader that
+        writes into them saves the per-step device copies."""
+        for entry in self._graphs.values():
+            static = entry[2]
+            if all(k in static and static[k].shape == v.shape for k, v in batch.items()):
+                return {k: static[k] for k in batch}
+        return None
+
+
+class DetectorStep(_GraphedStep):
+    """ModelDetector.optimize (models/keypoint_detector.py:158-207) on one device: owns detector + criteria
+    (+ optimizer); see _GraphedStep for graph=True."""
+
+    def __init__(self, model: str, opt, device, with_optimizer: bool = False, graph: bool = False):
+        self.detector = build_detector(model, opt).to(torch.device(device))
+        self.chamfer_criteria = ChamferLoss_Brute(opt)
+        self.keypoint_on_pc_criteria = KeypointOnPCLoss(opt)
+        self._setup(self.detector, opt, device, with_optimizer, graph)
 
     def forward_losses(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None):
         B = batch["src_pc"].shape[0]
@@ -101,126 +202,40 @@ class DetectorStep:
                          loss_on_pc_dst=on_dst)
         return loss
 
-    def _forward_backward(self, batch, epoch):
-        from . import functional as Fh
-        self.bucket.zero()                                    # detector.zero_grad() :186
-        Fh.GRAD_SINK = True       # every parameter is used once per step and the bucket was just zeroed:
-        Fh.DEFER_BN_COUNTERS = True   # the backward kernels write dW/dgamma/dbeta straight into the bucket
-        try:
-            loss = self.forward_losses(batch, epoch)
-            loss.backward()                                   # :205
-        finally:
-            Fh.GRAD_SINK = False
-            Fh.DEFER_BN_COUNTERS = False
-        if getattr(self, "_bn_counters", None) is None:
-            self._bn_counters = [m.num_batches_tracked for m in self.detector.modules()
-                                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
-                                 and m.num_batches_tracked is not None]
-        if self._bn_counters:
-            torch._foreach_add_(self._bn_counters, 1)         # every BatchNorm ran exactly once
-        return loss
 
-    def step(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None, group=None, eager: bool = False):
-        """forward + losses + backward (+ gradient all-reduce) (+ Adam when constructed with it).
-        eager=True forces plain launches for this call (bench.py does so on the steps it instruments with
-        HIP events, which a graph replay cannot carry)."""
-        if self.use_graph and not eager:
-            return self._step_graph(batch, epoch, group)
-        loss = self._forward_backward(batch, epoch)
-        self.bucket.all_reduce_mean(group)
-        if self.optimizer is not None:
-            self.optimizer.step()                             # :207
-        return loss
-
-    def _step_graph(self, batch, epoch, group):
-        decays = getattr(self.opt, "bn_momentum_decay_step", None)
-        key = (tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())),
-               epoch if (decays is not None and decays > 0) else None)
-        entry = self._graphs.get(key)
-        if entry is None:
-            if self._eager_calls < 2:                         # allocator, rocBLAS handles, lazily built state
-                self._eager_calls += 1
-                return self.step(batch, epoch, group, eager=True)
-            static = {k: v.clone() for k, v in batch.items()}
-            torch.cuda.synchronize(self.device)
-            try:
-                # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
-                # must not invalidate the capture
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    loss = self._forward_backward(static, epoch)
-                last = dict(self.last)
-                gb = None
-                if self.optimizer is not None:
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                        self.optimizer.step()
-            except RuntimeError as err:                       # capture refused: keep training with plain launches
-                import warnings
-                warnings.warn("usip_amd: HIP graph capture failed (%s); continuing with eager launches" % err)
-                torch.cuda.synchronize(self.device)
-                self.use_graph = False
-                return self.step(batch, epoch, group, eager=True)
-            entry = self._graphs[key] = (ga, gb, static, last, loss)   # capture launches nothing: replay below
-        ga, gb, static, last, loss = entry
-        for k, v in batch.items():
-            if v.data_ptr() != static[k].data_ptr():
-                static[k].copy_(v, non_blocking=True)
-        ga.replay()
-        self.bucket.all_reduce_mean(group)
-        if gb is not None:
-            gb.replay()
-        self.last = last
-        return loss
-
-    def static_batch(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """The captured input buffers for batches shaped like `batch` (None before capture): a loader that
-        writes into them saves the per-step device copies."""
-        for key, entry in self._graphs.items():
-            if key[0] == tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())):
-                return entry[2]
-        return None
-
-
-class DescriptorStep:
+class DescriptorStep(_GraphedStep):
     """ModelDescriptor.optimize (models/keypoint_descriptor.py:126-159): siamese descriptor forward on
-    cat(anchor, positive), triplet loss with in-batch negatives, backward (+ all-reduce) (+ Adam)."""
+    cat(anchor, positive), triplet loss with in-batch negatives, backward (+ all-reduce) (+ Adam).
+    The random point permutation of the reference (networks.py:345-347) is drawn on the host every step and
+    handed to the model as a device tensor (batch["perm"]; given by the caller to fix it), which also keeps the
+    host-to-device copy out of a captured graph."""
 
-    def __init__(self, opt, device, with_optimizer: bool = False):
+    def __init__(self, opt, device, with_optimizer: bool = False, graph: bool = False):
         from .losses import DescPairScanLoss
         from .networks import DescriptorLiteOld
-        self.opt = opt
-        self.device = torch.device(device)
-        self.descriptor = DescriptorLiteOld(opt).to(self.device)
+        self.descriptor = DescriptorLiteOld(opt).to(torch.device(device))
         self.triplet_criteria = DescPairScanLoss(opt)
-        self.bucket = FlatGradBucket(self.descriptor)
-        self.optimizer = torch.optim.Adam(self.descriptor.parameters(), lr=opt.lr, betas=(0.9, 0.999),
-                                          fused=self.device.type == "cuda") if with_optimizer else None
-        self.last: Dict[str, torch.Tensor] = {}
+        self._setup(self.descriptor, opt, device, with_optimizer, graph)
 
-    def load_numpy_state(self, state: Dict):
-        sd = self.descriptor.state_dict()
-        self.descriptor.load_state_dict({k: torch.as_tensor(v).reshape(sd[k].shape) for k, v in state.items()})
+    def _prepare(self, batch):
+        if "perm" in batch:
+            return batch
+        import numpy as np
+        perm = self.descriptor.fixed_permutation
+        if perm is None:
+            perm = np.random.permutation(batch["anc_pc"].shape[2])
+        return dict(batch, perm=torch.as_tensor(perm, dtype=torch.int64).to(self.device))
 
-    def step(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None, group=None):
-        from . import functional as Fh
+    def forward_losses(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None):
         B = batch["anc_pc"].shape[0]
-        self.bucket.zero()
-        Fh.GRAD_SINK = True
-        try:
-            self.descriptor.train()
-            desc, x_feat = self.descriptor(torch.cat((batch["anc_pc"], batch["pos_pc"]), 0),
-                                           torch.cat((batch["anc_sn"], batch["pos_sn"]), 0),
-                                           torch.cat((batch["anc_kp"], batch["pos_kp"]), 0), True, epoch)
-            anc, pos = torch.split(desc, B, dim=0)
-            triplet, active = self.triplet_criteria(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"])
-            loss = torch.mean(triplet)
-            loss.backward()
-        finally:
-            Fh.GRAD_SINK = False
-        self.bucket.all_reduce_mean(group)
-        if self.optimizer is not None:
-            self.optimizer.step()
+        self.descriptor.train()
+        desc, x_feat = self.descriptor(torch.cat((batch["anc_pc"], batch["pos_pc"]), 0),
+                                       torch.cat((batch["anc_sn"], batch["pos_sn"]), 0),
+                                       torch.cat((batch["anc_kp"], batch["pos_kp"]), 0), True, epoch,
+                                       perm=batch.get("perm"))
+        anc, pos = torch.split(desc, B, dim=0)
+        triplet, active = self.triplet_criteria(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"])
+        loss = torch.mean(triplet)
         self.last = dict(descriptors=desc, x_features=x_feat, triplet=triplet, active=active, loss=loss)
         return loss
 
