@@ -90,32 +90,53 @@ __global__ __launch_bounds__(256) void nearest_merge_kernel(
 }
 
 // General-dimension variant for the descriptor loss (DescPairScanLoss, models/losses.py:207-218): points are
-// C-dimensional descriptors [B][C][M] (C = 128, M = 256 keypoints).  One wave per query; every lane keeps up
-// to TJ candidate partial sums in registers while the channel loop streams b[c][j] coalesced along j.
-constexpr int TJ = 16;               // candidates per lane -> Nb <= 1024
+// C-dimensional descriptors [B][C][M] (C = 128, M = 256 keypoints).  One wave per query; every lane keeps TJ
+// candidate partial sums in registers while the channel loop streams b[c][j] coalesced along j.  The problem is
+// tiny (B*M = 1024 queries), so the kernel is bound by load LATENCY, not bandwidth: CU channels are loaded
+// together before any of them is used (one exposed L2 round trip per CU channels instead of per channel;
+// 141 -> ~25 us at C = 128, Nb = 256).
+constexpr int TJ_MAX = 16;           // candidates per lane -> Nb <= 1024
 
+template <int TJ, int CU>
 __global__ __launch_bounds__(256) void nearest_nd_kernel(
     const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ min_d,
     int32_t* __restrict__ arg, int C, int Ma, int Nb)
 {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: a[c][i] is a scalar load
     const int bi = blockIdx.y;
     if (i >= Ma) return;
     const float* ab = a + (long long)bi * C * Ma;
     const float* bb = b + (long long)bi * C * Nb;
+    int jc[TJ];                                   // clamped candidate index: loads are branch-free
+#pragma unroll
+    for (int t = 0; t < TJ; ++t) jc[t] = min(t * 64 + lane, Nb - 1);
     float s[TJ];
 #pragma unroll
     for (int t = 0; t < TJ; ++t) s[t] = 0.f;
-    for (int c = 0; c < C; ++c) {
+    int c = 0;
+    for (; c + CU <= C; c += CU) {
+        float av[CU], bv[CU][TJ];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            av[u] = ab[(long long)(c + u) * Ma + i];
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) bv[u][t] = bb[(long long)(c + u) * Nb + jc[t]];
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u)              // channel order as in the plain loop: same sums bit for bit
+#pragma unroll
+            for (int t = 0; t < TJ; ++t) {
+                const float df = av[u] - bv[u][t];
+                s[t] = __builtin_fmaf(df, df, s[t]);
+            }
+    }
+    for (; c < C; ++c) {
         const float av = ab[(long long)c * Ma + i];
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {
-            const int j = t * 64 + lane;
-            if (j < Nb) {
-                const float df = av - bb[(long long)c * Nb + j];
-                s[t] = __builtin_fmaf(df, df, s[t]);
-            }
+            const float df = av - bb[(long long)c * Nb + jc[t]];
+            s[t] = __builtin_fmaf(df, df, s[t]);
         }
     }
     float best = __builtin_inff();
@@ -227,11 +248,14 @@ extern "C" int usip_nearest_backward_f32(const float* a, const float* b, const f
 extern "C" int usip_nearest_nd_f32(const float* a, const float* b, float* min_d, int32_t* arg,
                                    int B, int C, int Ma, int Nb, void* stream)
 {
-    if (B < 0 || C < 1 || Ma < 0 || Nb < 1 || Nb > 64 * TJ) return USIP_EINVAL;
+    if (B < 0 || C < 1 || Ma < 0 || Nb < 1 || Nb > 64 * TJ_MAX) return USIP_EINVAL;
     if ((long long)B * Ma == 0) return USIP_OK;
     if (!a || !b || !min_d || !arg || B > 65535) return USIP_EINVAL;
-    USIP_LAUNCH(nearest_nd_kernel, dim3(usip_ceil_div(Ma, 4), B), dim3(256), 0, (hipStream_t)stream,
-                a, b, min_d, arg, C, Ma, Nb);
+    const dim3 grid(usip_ceil_div(Ma, 4), B), block(256);
+    if (Nb <= 256)
+        USIP_LAUNCH((nearest_nd_kernel<4, 8>), grid, block, 0, (hipStream_t)stream, a, b, min_d, arg, C, Ma, Nb);
+    else
+        USIP_LAUNCH((nearest_nd_kernel<TJ_MAX, 2>), grid, block, 0, (hipStream_t)stream, a, b, min_d, arg, C, Ma, Nb);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
