@@ -57,6 +57,16 @@ __global__ __launch_bounds__(256) void ball_query_coords_kernel(
     }
     if (m0 < M) {
         constexpr int STEP = VEC ? 256 : 64;
+        // The scan is bound by load latency (one L2 round trip per 256 points if the loads are issued where
+        // they are used): the next block of points is fetched, from a clamped address, before the current one
+        // is tested.
+        float4 nx = make_float4(0, 0, 0, 0), ny = nx, nz = nx;
+        if (VEC) {
+            const int i = min(lane * 4, N - 4);
+            nx = *reinterpret_cast<const float4*>(xb + i);
+            ny = *reinterpret_cast<const float4*>(xb + N + i);
+            nz = *reinterpret_cast<const float4*>(xb + 2 * N + i);
+        }
         for (int base = 0; base < N; base += STEP) {
             bool done = true;
 #pragma unroll
@@ -66,12 +76,13 @@ __global__ __launch_bounds__(256) void ball_query_coords_kernel(
             unsigned any = 0;
             if (VEC) {
                 const int i = base + lane * 4;
-                float4 px = make_float4(0, 0, 0, 0), py = px, pz = px;
+                const float4 px = nx, py = ny, pz = nz;
                 const bool ok = i < N;
-                if (ok) {
-                    px = *reinterpret_cast<const float4*>(xb + i);
-                    py = *reinterpret_cast<const float4*>(xb + N + i);
-                    pz = *reinterpret_cast<const float4*>(xb + 2 * N + i);
+                {
+                    const int in = min(i + STEP, N - 4);
+                    nx = *reinterpret_cast<const float4*>(xb + in);
+                    ny = *reinterpret_cast<const float4*>(xb + N + in);
+                    nz = *reinterpret_cast<const float4*>(xb + 2 * N + in);
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -143,7 +154,7 @@ extern "C" int usip_ball_query_coords_f32(const float* node, const float* x, int
     if (K > 1024 || B > 65535) return USIP_EINVAL;           // LDS: 4*R*K*4 B = 64 KiB at K=1024
     const float T = sqrt_threshold(radius);
     hipStream_t st = (hipStream_t)stream;
-    const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    const bool vec = (N >= 4) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     dim3 grid(usip_ceil_div(M, 4 * R), B), block(256);
     const size_t lds = (size_t)4 * R * K * sizeof(int);
     if (vec)
