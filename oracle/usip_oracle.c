@@ -13,10 +13,16 @@
  *   ball_query : the reference ships no CPU implementation and no test vectors
  *                (models/ball_query_ext/ball_query.cpp:23-31 is a stub; only the
  *                CUDA kernel exists and there is no nvcc here).  The
- *                restatement below follows the CUDA kernel line by line and is
- *                cross-checked against the commented numba ancestor
- *                (models/operations.py:315-329), but it is "parity unpinned"
- *                by any executable reference artefact.
+ *                restatement below follows the CUDA kernel line by line
+ *                (ball_query_cuda.cu:22-46).  It is pinned as far as the
+ *                reference allows: tests/golden/ball_query_ancestor_cases.npz
+ *                holds rows produced by executing the reference's own earlier
+ *                statement of the kernel, the numba-CUDA function it keeps
+ *                commented out at models/operations.py:295-329 (un-commented
+ *                in memory and run through a thread-index shim by
+ *                tests/golden/make_golden.py).  That ancestor is undefined for
+ *                an empty ball; the all-zeros rule there comes from reading
+ *                the CUDA kernel only ("parity unpinned" for those rows).
  *
  * Build: make -C oracle   ->  oracle/libusip_oracle.so
  */

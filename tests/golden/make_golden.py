@@ -10,7 +10,8 @@ Fixtures are data (numbers); no reference source text is stored.
 Shims needed to import the reference here: an empty `torchvision`
 module (util/som.py:12 imports it, never uses it on this path); `index_max` = the
 reference's own CPU entry point; `ball_query` = oracle/usip_oracle.c (the reference has
-no CPU ball_query: that part of every fixture is "parity unpinned", flagged per file).
+no CPU ball_query; the oracle itself is pinned by ball_query_ancestor_cases.npz, rows
+produced by the reference's commented-out numba kernel, see gen_ball_query_ancestor).
 
     python tests/golden/make_golden.py
 """
@@ -127,6 +128,62 @@ def gen_dist_ball():
     assert (hits == 0).any() and ((hits > 0) & (hits < K)).any() and (hits >= K).any()
     save("dist_ball_cases.npz", x=x, node=node, dist=dist, radius=np.float32(2.0), K=np.int32(K),
          ball_idx_unpinned=out, prefix_len_unpinned=prefix)
+
+
+def _numba_ancestor_ball_query():
+    """The reference's only host-runnable statement of ball_query: the numba-CUDA kernel it replaced with the
+    C++/CUDA extension and left, commented out, at models/operations.py:295-329.  Its text is read from the
+    reference checkout, un-commented in memory and executed with a thread-index shim standing in for
+    numba.cuda (one Python call per (block m, thread b)); nothing of it is stored -- only the numbers it
+    produces.  It divides by the hit count (`i % unique_idx`), so it is undefined for an empty ball; those rows
+    are covered by the CUDA kernel's rule (ball_query_cuda.cu:40-45: all zeros) and flagged in the fixture."""
+    src = open("/root/reference/models/operations.py").read().split("\n")
+    start = next(i for i, ln in enumerate(src) if ln.startswith("# def ball_query("))
+    end = next(i for i, ln in enumerate(src) if ln.startswith("# def ball_query_wrapper("))
+    body = "\n".join(ln[2:] if ln.startswith("# ") else ln.lstrip("#") for ln in src[start:end])
+    cuda = types.SimpleNamespace(blockIdx=types.SimpleNamespace(x=0), threadIdx=types.SimpleNamespace(x=0),
+                                 shared=types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype)))
+    numba = types.SimpleNamespace(cuda=cuda, int32=np.int32, float32=np.float32)
+    scope = {"numba": numba}
+    exec(compile(body, "operations.py:ball_query (numba ancestor)", "exec"), scope)
+    kernel = scope["ball_query"]
+
+    def run(dist, radius, nsamples):
+        B, M, _ = dist.shape
+        assert B <= 32                                        # the kernel's shared array has 32 slots
+        out = np.zeros((B, M, nsamples), np.int32)
+        empty = np.zeros((B, M), bool)
+        for m in range(M):
+            for b in range(B):
+                if not (dist[b, m] <= np.float32(radius)).any():
+                    empty[b, m] = True                        # undefined in the ancestor (modulo by zero)
+                    continue
+                cuda.blockIdx.x, cuda.threadIdx.x = m, b
+                kernel(dist, out, np.float32(radius), nsamples)
+        return out, empty
+    return run
+
+
+def gen_ball_query_ancestor():
+    """ball_query rows produced by the reference's own (numba) kernel text on seeded distance matrices:
+    partially filled balls (cyclic padding), full balls (first K hits), ties at exactly the radius."""
+    run = _numba_ancestor_ball_query()
+    rng = np.random.default_rng(909)
+    cases = {}
+    seen = np.zeros(3, bool)                                  # empty / partially filled / full balls
+    for name, (B, M, N, K, r) in dict(a=(2, 40, 700, 16, 2.0), b=(3, 17, 333, 64, 2.5), c=(1, 9, 64, 5, 3.0)).items():
+        x = np.stack([synth.make_cloud(rng, N, "slab:10") for _ in range(B)])
+        node = np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)])
+        node[0, :, 0] = 500.0                                 # an empty ball
+        dist = torch.norm(torch.from_numpy(node).unsqueeze(3) - torch.from_numpy(x).unsqueeze(2), dim=1).numpy()
+        dist[0, 1, 7] = np.float32(r)                         # a hit exactly on the radius (<= is inclusive)
+        out, empty = run(dist, r, K)
+        hits = (dist <= np.float32(r)).sum(-1)
+        seen = seen | np.array([empty.any(), ((hits > 0) & (hits < K)).any(), (hits >= K).any()])
+        cases.update({name + "_dist": dist, name + "_radius": np.float32(r), name + "_K": np.int32(K),
+                      name + "_idx": out, name + "_empty": empty})
+    assert seen.all(), seen
+    save("ball_query_ancestor_cases.npz", **cases)
 
 
 def gen_som(som):
@@ -441,6 +498,9 @@ def gen_pre_post(networks):
 
 if __name__ == "__main__":
     ref_im, networks, losses, layers, som = import_reference()
+    if "--only-ball-ancestor" in sys.argv:
+        gen_ball_query_ancestor()
+        sys.exit(0)
     if "--only-prepost" in sys.argv:
         gen_pre_post(networks)
         sys.exit(0)

@@ -249,3 +249,17 @@ def test_chamfer_prob_kernels_match_torch_float64():
         assert err < 2e-6, (name, err)
     # deterministic: bit-identical on a second run
     assert torch.equal(ops.chamfer_prob_backward(gl, a, J, c, I, ss, sd)[3], dsd)
+
+
+def test_ball_query_kernels_match_reference_numba_ancestor():
+    """Both HIP entry points (dist-in, and coords-in on a matrix rebuilt from coordinates is covered elsewhere)
+    against the rows the reference's numba ancestor produced (tests/golden/ball_query_ancestor_cases.npz)."""
+    ops = _ops()
+    g = load_golden("ball_query_ancestor_cases.npz")
+    for n in "abc":
+        dist, K, r = g[n + "_dist"], int(g[n + "_K"]), float(g[n + "_radius"])
+        got = ops.ball_query(torch.from_numpy(dist).to(DEV), r, K).cpu().numpy()
+        empty = g[n + "_empty"]
+        assert np.array_equal(got[~empty], g[n + "_idx"][~empty]), n
+        assert not got[empty].any()
+

@@ -202,3 +202,19 @@ def test_checkpoint_prefix_fixup_and_bin_format(tmp_path):
     inference.write_keypoints_bin(path, kp)
     back = np.fromfile(path, dtype=np.float32).reshape(-1, 3)
     assert np.array_equal(back, kp.astype(np.float32))
+
+
+def test_ball_query_oracle_matches_reference_numba_ancestor():
+    """Pins the ball_query oracle to the reference's own statement of the algorithm: the numba-CUDA kernel it
+    keeps (commented out) at models/operations.py:295-329, executed by tests/golden/make_golden.py through a
+    thread-index shim.  The ancestor is undefined for an empty ball (modulo by the hit count); those rows follow
+    the CUDA kernel's rule, all zeros (ball_query_cuda.cu:40-45)."""
+    g = load_golden("ball_query_ancestor_cases.npz")
+    for n in "abc":
+        dist, K, r = g[n + "_dist"], int(g[n + "_K"]), float(g[n + "_radius"])
+        out = native.ball_query(dist, r, K)
+        empty = g[n + "_empty"]
+        assert np.array_equal(out[~empty], g[n + "_idx"][~empty]), n
+        assert not out[empty].any()
+        assert empty.any() and (~empty).any()
+
