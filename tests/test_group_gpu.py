@@ -181,3 +181,19 @@ def test_group_max_backward_add_inplace():
     want = dz + ops.group_max_backward(dp, arg, K)
     out = ops.group_max_backward_add_(dz, dp, arg)
     assert out.data_ptr() == dz.data_ptr() and torch.equal(dz, want)
+
+
+def test_gather_backward_is_reproducible_bit_for_bit():
+    """The scatter-add of the gather backward runs in single-wave workgroups: repeated launches on the same
+    input must give the same bits (heavy collisions: 16 neighbours drawn from 40 points)."""
+    from usip_amd import ops
+    B, C, N, M, K = 4, 33, 40, 512, 16
+    g = torch.Generator().manual_seed(3)
+    dout = torch.randn(B, C + 3, M, K, generator=g).to(DEV)
+    idx = torch.randint(0, N, (B, M, K), generator=g, dtype=torch.int32).to(DEV)
+    first = ops.group_gather_backward(dout, idx, C, N, coff=3)
+    want = torch.zeros(B, C, N, dtype=torch.float64, device=DEV).scatter_add_(
+        2, idx.long().view(B, 1, M * K).expand(B, C, M * K), dout[:, 3:].double().reshape(B, C, M * K))
+    assert _rel(first, want) < 1e-6
+    for _ in range(20):
+        assert torch.equal(ops.group_gather_backward(dout, idx, C, N, coff=3), first)

@@ -135,30 +135,69 @@ __global__ __launch_bounds__(256) void group_max_bwd_add_kernel(
     dz[row * K + arg[row]] += dpooled[row];
 }
 
-// Scatter-add through LDS: a workgroup owns CPB channels of one cloud, accumulates them in an
-// LDS table [CPB][N] with ds_add_f32 (neighbours of one neighbourhood are distinct points, so a wave
-// rarely hits one address twice) and writes the table out once.  N*CPB*4 B <= 64 KiB.
-template <int CPB>
+// Scatter-add through LDS, reproducible.  A workgroup owns CPB channels of one cloud; each of its four waves
+// accumulates ITS quarter of the positions into ITS OWN table [CPB][N] with ds_add_f32, and the four tables are
+// combined in a fixed order at the end.  No two waves ever add into the same cell, so the order of additions
+// into a cell is program order, and lanes of one instruction that hit the same cell are serialised by the LDS
+// unit in its fixed lane order: the same bits on every run (tests/test_group_gpu.py launches it repeatedly) --
+// the first version let four waves share one table, and their interleaving depended on timing.  Measured
+// bound: the LDS float-add rate (~0.35 lane-adds per clock per CU with random cells; 16.8 M adds = 89 us for the
+// KNN-feature gradient) -- neither prefetching the next batch of positions nor 1/2/4 channels per workgroup
+// nor one wave per workgroup moved it.  4*N*CPB*4 B <= 64 KiB.
+template <int CPB, bool VEC>
 __global__ __launch_bounds__(256) void group_gather_bwd_lds_kernel(
     const float* __restrict__ dout, const int32_t* __restrict__ idx, float* __restrict__ dx,
     int C, int N, int P, int Ctot, int coff)
 {
-    extern __shared__ __attribute__((aligned(16))) float table[];       // [CPB][N]
-    const int b = blockIdx.y, c0 = blockIdx.x * CPB;
-    for (int i = threadIdx.x; i < CPB * N; i += 256) table[i] = 0.f;
+    extern __shared__ __attribute__((aligned(16))) float tables[];      // [4 waves][CPB][N]
+    const int b = blockIdx.y, c0 = blockIdx.x * CPB, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 4 * CPB * N; i += 256) tables[i] = 0.f;
     __syncthreads();
+    float* table = tables + wave * CPB * N;
     const int32_t* ib = idx + (long long)b * P;
     const float* gb = dout + ((long long)b * Ctot + coff + c0) * P;
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const int n = ib[p];
+    // the wave's quarter of the positions, a multiple of 4 long (except the tail)
+    const int per = ((P + 15) / 16) * 4;
+    const int pbeg = min(P, wave * per), pend = min(P, pbeg + per);
+    if (VEC) {
+        auto fetch = [&](int p, int4& n, float4 (&g)[CPB]) {           // clamped address; masked by the loop bound
+            const int pc = min(p, P - 4);
+            n = *reinterpret_cast<const int4*>(ib + pc);
 #pragma unroll
-        for (int c = 0; c < CPB; ++c)
-            if (c0 + c < C) atomicAdd(&table[c * N + n], gb[(long long)c * P + p]);
+            for (int c = 0; c < CPB; ++c)
+                g[c] = *reinterpret_cast<const float4*>(gb + (long long)min(c, C - 1 - c0) * P + pc);
+        };
+        int4 n, nn;
+        float4 g[CPB], gn[CPB];
+        fetch(pbeg + lane * 4, n, g);
+        for (int p = pbeg + lane * 4; p < pend; p += 256) {
+            fetch(p + 256, nn, gn);
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) {                              // position order p, p+1, p+2, p+3
+                if (c0 + c >= C) break;
+                atomicAdd(&table[c * N + n.x], g[c].x);
+                atomicAdd(&table[c * N + n.y], g[c].y);
+                atomicAdd(&table[c * N + n.z], g[c].z);
+                atomicAdd(&table[c * N + n.w], g[c].w);
+            }
+            n = nn;
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) g[c] = gn[c];
+        }
+    } else {
+        for (int p = pbeg + lane; p < pend; p += 64) {
+            const int n = ib[p];
+#pragma unroll
+            for (int c = 0; c < CPB; ++c)
+                if (c0 + c < C) atomicAdd(&table[c * N + n], gb[(long long)c * P + p]);
+        }
     }
     __syncthreads();
     float* xb = dx + ((long long)b * C + c0) * N;
-    for (int i = threadIdx.x; i < CPB * N; i += 256)
-        if (c0 + i / N < C) xb[i] = table[i];
+    const int sz = CPB * N;
+    for (int i = threadIdx.x; i < sz; i += 256)
+        if (c0 + i / N < C) xb[i] = (tables[i] + tables[sz + i]) + (tables[2 * sz + i] + tables[3 * sz + i]);
 }
 
 __global__ __launch_bounds__(256) void group_max_bwd_kernel(
@@ -195,10 +234,17 @@ extern "C" int usip_group_gather_backward_f32(const float* dout, const int32_t* 
     if (B < 0 || C < 1 || N < 1 || M < 0 || K < 0 || coff < 0 || coff + C > Ctot) return USIP_EINVAL;
     if (!dx) return USIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if ((long long)B * M * K > 0 && dout && idx && B <= 65535 && (long long)N * 8 * 4 <= 65536) {
-        // LDS path: 8 channels per workgroup, every dx element written exactly once (no memset)
-        USIP_LAUNCH((group_gather_bwd_lds_kernel<8>), dim3(usip_ceil_div(C, 8), B), dim3(256),
-                    (size_t)8 * N * sizeof(float), st, dout, idx, dx, C, N, M * K, Ctot, coff);
+    if ((long long)B * M * K > 0 && dout && idx && B <= 65535 && (long long)N * 4 * 2 * 4 <= 65536) {
+        // LDS path: 2 channels per workgroup, every dx element written exactly once (no memset)
+        const long long P = (long long)M * K;
+        const bool vec = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(dout) & 15u) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(idx) & 15u) == 0);
+        const dim3 grid(usip_ceil_div(C, 2), B), block(256);
+        const size_t lds = (size_t)4 * 2 * N * sizeof(float);
+        if (vec)
+            USIP_LAUNCH((group_gather_bwd_lds_kernel<2, true>), grid, block, lds, st, dout, idx, dx, C, N, M * K, Ctot, coff);
+        else
+            USIP_LAUNCH((group_gather_bwd_lds_kernel<2, false>), grid, block, lds, st, dout, idx, dx, C, N, M * K, Ctot, coff);
         USIP_LAUNCH_CHECK();
         return USIP_OK;
     }
