@@ -612,6 +612,33 @@ class _KnnGroup(torch.autograd.Function):
         return ops.group_gather_backward(dout.contiguous(), idx32, C, N, coff=3), None, None, None
 
 
+class _ClusterBroadcast(torch.autograd.Function):
+    """out[b,c,n] = x[b,c,idx[b,n]]: every point receives its SOM node's feature (models/networks.py:119-125,
+    torch.gather on an index expanded over the channels).  Backward = the sum over each node's member points,
+    through the reproducible LDS scatter of csrc/group.hip instead of ATen's float atomics."""
+
+    @staticmethod
+    def forward(ctx, x, idx32):
+        B, C, M = x.shape
+        N = idx32.shape[1]
+        ctx.save_for_backward(idx32)
+        ctx.dims = (C, M)
+        return ops.group_gather(x.contiguous(), idx32.view(B, N, 1)).view(B, C, N)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx32,) = ctx.saved_tensors
+        C, M = ctx.dims
+        B, _, N = dout.shape
+        return ops.group_gather_backward(dout.contiguous().view(B, C, N, 1), idx32.view(B, N, 1), C, M), None
+
+
+def cluster_broadcast(x, idx32):
+    """x [B,C,M] node features, idx32 i32 [B,N] node of every point -> [B,C,N]."""
+    require_device(x, "cluster_broadcast")
+    return _ClusterBroadcast.apply(x, idx32)
+
+
 def knn_group(feat, database, query, idx32):
     require_device(feat, "knn_group")
     return _KnnGroup.apply(feat, database, query, idx32)

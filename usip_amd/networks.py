@@ -75,13 +75,12 @@ class RPN_Detector(_DetectorTail):
         min_idx32 = ops.som_assign(x, node.contiguous())                  # som.py:31-39
         cluster_mean, count, x_dec = ops.som_cluster(x, min_idx32, M)     # networks.py:87-107
         has_pts = (count > 0).to(x.dtype).unsqueeze(1)                    # mask_row_max
-        min_idx = min_idx32.long()
         self.last_indices = dict(min_idx=min_idx32)
         feat_in = torch.cat((x_dec, sn), dim=1) if self.opt.surface_normal_len >= 1 else x_dec
         first = self.first_pointnet(feat_in, epoch)
         first_idx = ops.index_max(first.detach().contiguous(), min_idx32, M).long()   # networks.py:117-118
         first_max = first.gather(2, first_idx) * has_pts
-        scattered = torch.gather(first_max, 2, min_idx.unsqueeze(1).expand(B, first.shape[1], N))
+        scattered = Fh.cluster_broadcast(first_max, min_idx32)             # networks.py:119-125
         second = self.second_pointnet(torch.cat((first, scattered), dim=1), epoch)
         second_idx = ops.index_max(second.detach().contiguous(), min_idx32, M).long()  # networks.py:130-131
         second_max = second.gather(2, second_idx) * has_pts
