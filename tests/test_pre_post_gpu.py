@@ -1,6 +1,7 @@
 """GPU parity of the steps either side of the detector path: farthest-point sampling,
 eval-mode forward, sigma-ordered NMS + top-k export -- against outputs of the reference's own functions
 (tests/golden/pre_post_cases.npz) and against the numpy oracle at larger sizes."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -84,3 +85,26 @@ def test_eval_mode_forward_matches_reference_run_model():
                                   torch.from_numpy(g["eval_node"]).to(DEV))
     assert_close(kp.cpu().numpy(), g["eval_keypoints"], name="keypoints")
     assert_close(sig.cpu().numpy(), g["eval_sigmas"], name="sigmas")
+
+
+def test_example_scripts_train_then_extract(tmp_path):
+    """examples/: a few training steps on synthetic pairs -> checkpoint with the reference's keys -> keypoint
+    .bin files in the reference's wire format (float32 M x 3)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ck = str(tmp_path / "det.pth")
+    out = str(tmp_path / "kp")
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "train_detector_synthetic.py"), "--model", "ball",
+                        "--steps", "4", "--pairs", "2", "--n", "2048", "--m", "64", "--out", ck],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    sd = torch.load(ck, map_location="cpu")
+    assert "conv1.conv.weight" in sd and "knnlayer_1.layers_before.0.conv.weight" in sd and "mlp3.conv.bias" in sd
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "extract_keypoints.py"), "--model", "ball",
+                        "--checkpoint", ck, "--frames", "2", "--n", "2048", "--m", "64", "--top", "20", "--out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i in range(2):
+        kp = np.fromfile(os.path.join(out, "%06d.bin" % i), dtype=np.float32)
+        assert kp.size % 3 == 0 and 0 < kp.size // 3 <= 20 and np.isfinite(kp).all()
