@@ -698,7 +698,15 @@ static void wgrad_plan(int M, int N, int P, int nb, int* seglen, int* segs, int*
     if (per_cloud < 1) per_cloud = 1;
     long long sl = (P + per_cloud - 1) / per_cloud;
     sl = ((sl + 31) / 32) * 32;
-    if (sl < 512) sl = 512;
+    if (sl < 512) {
+        // Long segments keep the partial tiles small next to what a workgroup streams -- but only while they
+        // still fill the chip: the M-sized products of the pooled-concat layers and the head (P = 512 per
+        // cloud) ran as 16-128 workgroups of 16 serial stages each (45-70 us for < 60 MB).  Take the longest
+        // segment in {512, 256, 128, 64} that still gives >= 256 workgroups.
+        long long floor_sl = 512;
+        while (floor_sl > 64 && (long long)(*tiles) * nb * ((P + floor_sl - 1) / floor_sl) < 256) floor_sl /= 2;
+        if (sl < floor_sl) sl = floor_sl;
+    }
     *seglen = (int)sl;
     *segs = (int)((P + sl - 1) / sl);
 }
