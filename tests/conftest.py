@@ -15,6 +15,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build what is MISSING before the first
+    test -- the HIP library (hipcc cross-compiles gfx950 without a GPU) and the C oracle.  Nothing that exists is
+    rebuilt, and the product still refuses to run without its library (usip_amd/_lib.py)."""
+    try:
+        from usip_amd import build as hip_build
+        if not os.path.exists(hip_build.LIB):
+            hip_build.build()
+        from oracle import native
+        native.build()                                   # no-op when oracle/libusip_oracle.so is up to date
+    except Exception as err:                             # the tests that need the artefact will say so
+        print("conftest: could not build prerequisites: %s" % err, file=sys.stderr)
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name), allow_pickle=False))
 
