@@ -142,18 +142,12 @@ int usip_nearest_nd_f32(const float* a, const float* b, float* min_d, int32_t* a
  *   the contribution of input channels that are constant inside a neighbourhood of rb_group
  *   positions (the max-pooled feature the reference expands and concatenates, networks.py:706-709,
  *   layers.py:433-435) -- computed once per neighbourhood instead of once per neighbour.
- *   epi_y / epi_coef (may be NULL): when this GEMM is the data gradient w.r.t. the ACTIVATED output of a
- *   BatchNorm layer (Y = dZ of that layer, M = its channels), epi_y is that layer's pre-BN output [nb][M][P] and
- *   epi_coef its [4][M] coefficients from usip_bn_finalize_f32; `stats` then receives the per-tile BACKWARD sums
- *   (sum dYhat, sum dYhat*yhat), finalised by usip_bn_backward_finalize_tiles_f32 -- the layer's BatchNorm
- *   backward needs no pass of its own over (dZ, y).
  *   stats (may be NULL): [2][M][tiles] per-tile (sum, sum of squares) of Y over valid positions,
  *   tiles = usip_mlp_gemm_tiles(M, P, nb); summed in fixed order by usip_bn_finalize_f32. */
 int usip_mlp_gemm_tiles(int M, int P, int nb);
 int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2, const float* coef,
                       int pro, const float* bias, const float* rowbias, int rb_group,
                       const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                      const float* epi_y, const float* epi_coef,
                       float* Y, float* stats, int M, int K, int P, int nb, void* stream);
 /* Same contract with a bf16 MULTIPLY (the perf mode of BASELINE.json configs[1]; not the parity mode): tensors
  * stay fp32 in memory, the prologue runs in fp32, both operands are rounded to bf16 (nearest-even) on their way
@@ -162,8 +156,7 @@ int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
 int usip_mlp_gemm_bf16(const float* At, int lda, const float* X, const float* X2, const float* coef,
                        int pro, const float* bias, const float* rowbias, int rb_group,
                        const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                       const float* epi_y, const float* epi_coef,
-                       float* Y, float* stats, int M, int K, int P, int nb, void* stream);
+                        float* Y, float* stats, int M, int K, int P, int nb, void* stream);
 
 /* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
  * coefficients coef[4][C] = (gamma*invstd, beta - mean*gamma*invstd, mean, invstd), and the running-statistics
@@ -191,12 +184,6 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
                                 float* partial, float* dgamma, float* dbeta, float* coef4,
                                 float* gsum, int group, int nb, int C, int P, void* stream);
 
-/* Finalisation of backward sums that arrived as GEMM-epilogue tiles (stats [2][C][tiles], see epi_y above), plus,
- * optionally, the per-(cloud, channel) partial sums of a pooled consumer (pool_partial [2][pool_nb*C], as written by
- * usip_bn_pool_backward_reduce_f32 with dgamma = dbeta = coef4 = NULL).  coef_fwd4 is the layer's [4][C] array. */
-int usip_bn_backward_finalize_tiles_f32(const float* stats, int tiles, const float* pool_partial, int pool_nb,
-                                        int C, long long count, const float* coef_fwd4,
-                                        float* dgamma, float* dbeta, float* coef4, void* stream);
 
 /* usip_bn_backward_reduce_f32 for a layer whose output fed ONLY a max over K neighbours: the incoming
  * gradient is (k == arg) ? dpooled : 0, so the sums run over B*C*M arg-max elements instead of B*C*M*K.

@@ -23,8 +23,6 @@ struct GemmArgs {
     int M, K, P, nb;
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
-    const float* epi_y; const float* epi_coef;   // EPI_BWD_STATS: Y is dZ of a layer whose pre-BN output is epi_y
-                                        // [nb][M][P] and whose (a1, a0, mean, invstd) are epi_coef [4][M]
     int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
     int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
                                         // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
@@ -44,11 +42,8 @@ __device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1
     return x;
 }
 
-// EPI: 0 none | 1 forward BatchNorm statistics of Y (sum, sum^2) | 2 BACKWARD statistics: Y is the gradient
-// dZ w.r.t. the activated output of the layer that produced this GEMM's input; with that layer's pre-BN
-// output y (epi_y) the epilogue accumulates sum(dYhat) and sum(dYhat * yhat), dYhat = dZ * [y*a1+a0 > 0],
-// so the producing layer's BatchNorm backward needs no separate pass over (dZ, y).
-enum { EPI_NONE = 0, EPI_STATS = 1, EPI_BWD_STATS = 2 };
+// EPI: 0 none | 1 BatchNorm statistics of Y: per-tile (sum, sum^2) partials
+enum { EPI_NONE = 0, EPI_STATS = 1 };
 
 // Epilogue shared by the fp32 and the bf16-multiply kernels (the 32x32 accumulator layout is the same for
 // every 32x32xK MFMA): + bias (+ row bias), store, BatchNorm partial statistics.  `scratch` is LDS the main
@@ -87,29 +82,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        // EPI_BWD_STATS: the 32 y values this lane needs for tile row-block i, as 32 independent loads from
-        // clamped addresses issued back to back (one load-use-wait per element would be 64 serial HBM trips)
-        float yv[EPI == EPI_BWD_STATS ? 16 : 1][2];
-        if (EPI == EPI_BWD_STATS) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowc = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, a.M - 1);
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    yv[r][j] = a.epi_y[((long long)b * a.M + rowc) * a.P + min(colj[j], a.P - 1)];
-            }
-        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int row = m0 + row_l;
             const int rowc = min(row, a.M - 1);
             const float bv = a.bias ? a.bias[rowc] : 0.0f;
-            float e1 = 0.f, e0 = 0.f, emu = 0.f, eis = 0.f;
-            if (EPI == EPI_BWD_STATS) {
-                e1 = a.epi_coef[rowc]; e0 = a.epi_coef[a.M + rowc];
-                emu = a.epi_coef[2 * a.M + rowc]; eis = a.epi_coef[3 * a.M + rowc];
-            }
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -120,12 +98,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
                 if (row < a.M && colj[j] < a.P) {
                     Yb[(long long)row * a.P + colj[j]] = v;
                     if (EPI == EPI_STATS) { s += v; q = __builtin_fmaf(v, v, q); }
-                    if (EPI == EPI_BWD_STATS) {
-                        const float yy = yv[EPI == EPI_BWD_STATS ? r : 0][j];
-                        const float d = (__builtin_fmaf(yy, e1, e0) > 0.f) ? v : 0.f;
-                        s += d;
-                        q = __builtin_fmaf(d, (yy - emu) * eis, q);
-                    }
                 }
             }
             if (EPI != EPI_NONE) {

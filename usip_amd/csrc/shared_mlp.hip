@@ -211,7 +211,7 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     if (total > 0x7fffffffLL) return USIP_EINVAL;
     const bool vec = (a.P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(a.X) & 15u) == 0) &&
                      ((pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) || (reinterpret_cast<uintptr_t>(a.X2) & 15u) == 0);
-    const int epi = a.stats == nullptr ? EPI_NONE : (a.epi_y ? EPI_BWD_STATS : EPI_STATS);
+    const int epi = a.stats == nullptr ? EPI_NONE : EPI_STATS;
     dim3 grid((unsigned)total), block(256);
 #define USIP_GEMM_CASE(P_, E_, V_)                                                              \
     if (pro == P_ && epi == E_ && vec == V_) {                                                  \
@@ -230,11 +230,6 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     USIP_GEMM_CASE(PRO_BN_BWD, EPI_NONE, true)
     USIP_GEMM_CASE(PRO_BN_BWD, EPI_NONE, false)
     USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_NONE, true)
-    USIP_GEMM_CASE(PRO_NONE, EPI_BWD_STATS, true)
-    USIP_GEMM_CASE(PRO_NONE, EPI_BWD_STATS, false)
-    USIP_GEMM_CASE(PRO_BN_BWD, EPI_BWD_STATS, true)
-    USIP_GEMM_CASE(PRO_BN_BWD, EPI_BWD_STATS, false)
-    USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_BWD_STATS, true)
 #undef USIP_GEMM_CASE
     return USIP_EINVAL;
 }
@@ -644,7 +639,6 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, const float* X2,
                          const float* coef, int pro, const float* bias, const float* rowbias,
                          int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                         const float* epi_y, const float* epi_coef,
                          float* Y, float* stats, int M, int K, int P, int nb, void* stream)
 {
     // lda < 0 selects the transposed storage of the matrix operand: At is [M][K] with row stride -lda
@@ -656,15 +650,14 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
     if (!At || !Y || pro < 0 || pro > 3) return USIP_EINVAL;
     if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
     if (pro != PRO_NONE && !coef) return USIP_EINVAL;
-    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || (stats && !epi_y))) return USIP_EINVAL;
-    if (epi_y && (!epi_coef || !stats)) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || stats)) return USIP_EINVAL;
     if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 4 || pool_group % 4 != 0 ||
                                    P % pool_group != 0 || P % 4 != 0)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
-               epi_y, epi_coef, a_trans, ablate};
+               a_trans, ablate};
     hipStream_t st = (hipStream_t)stream;
     if (bf16) return launch_gemm_bf16(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
@@ -674,10 +667,10 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
 #define USIP_GEMM_PARAMS                                                                                     \
     const float *At, int lda, const float *X, const float *X2, const float *coef, int pro, const float *bias, \
         const float *rowbias, int rb_group, const float *pool_dp, const int32_t *pool_arg, int pool_group,    \
-        const float *epi_y, const float *epi_coef, float *Y, float *stats, int M, int K, int P, int nb,       \
+        float *Y, float *stats, int M, int K, int P, int nb,                                                  \
         void *stream
 #define USIP_GEMM_ARGS \
-    At, lda, X, X2, coef, pro, bias, rowbias, rb_group, pool_dp, pool_arg, pool_group, epi_y, epi_coef, Y, stats, \
+    At, lda, X, X2, coef, pro, bias, rowbias, rb_group, pool_dp, pool_arg, pool_group, Y, stats, \
         M, K, P, nb, stream
 extern "C" int usip_mlp_gemm_f32(USIP_GEMM_PARAMS) { return mlp_gemm_impl(false, USIP_GEMM_ARGS); }
 extern "C" int usip_mlp_gemm_bf16(USIP_GEMM_PARAMS) { return mlp_gemm_impl(true, USIP_GEMM_ARGS); }
@@ -882,50 +875,6 @@ extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int3
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
                 (double)nb * (double)M * (double)K, gamma, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
-    USIP_LAUNCH_CHECK();
-    return USIP_OK;
-}
-
-namespace {
-__global__ __launch_bounds__(64) void bn_bwd_finalize_tiles_kernel(
-    const float* __restrict__ stats, int ntn, const float* __restrict__ pool_partial, int pool_rows_nb,
-    int C, double count, const float* __restrict__ coef_fwd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ coef4)
-{
-    const int ch = blockIdx.x, lane = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = lane; t < ntn; t += 64) {
-        s1 += (double)stats[(long long)ch * ntn + t];
-        s2 += (double)stats[(long long)ntn * C + (long long)ch * ntn + t];
-    }
-    if (pool_partial) {
-        const long long nrows = (long long)pool_rows_nb * C;
-        for (int b = lane; b < pool_rows_nb; b += 64) {
-            s1 += (double)pool_partial[(long long)b * C + ch];
-            s2 += (double)pool_partial[nrows + (long long)b * C + ch];
-        }
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) {
-        if (dbeta) dbeta[ch] = (float)s1;
-        if (dgamma) dgamma[ch] = (float)s2;
-        const float a1 = coef_fwd[ch], a0 = coef_fwd[C + ch], mu = coef_fwd[2 * C + ch], is = coef_fwd[3 * C + ch];
-        const float c1m = (float)(s1 / count), c2m = (float)(s2 / count);
-        coef4[ch] = a1;
-        coef4[C + ch] = a0;
-        coef4[2 * C + ch] = -a1 * c2m * is;
-        coef4[3 * C + ch] = a1 * (c2m * is * mu - c1m);
-    }
-}
-}  // namespace
-
-extern "C" int usip_bn_backward_finalize_tiles_f32(const float* stats, int tiles, const float* pool_partial,
-                                                   int pool_nb, int C, long long count, const float* coef_fwd4,
-                                                   float* dgamma, float* dbeta, float* coef4, void* stream)
-{
-    if (!stats || tiles < 1 || C < 1 || count < 1 || !coef_fwd4 || !coef4) return USIP_EINVAL;
-    USIP_LAUNCH(bn_bwd_finalize_tiles_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, stats, tiles, pool_partial,
-                pool_partial ? pool_nb : 0, C, (double)count, coef_fwd4, dgamma, dbeta, coef4);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -182,7 +182,7 @@ int launch_gemm_bf16_t(const GemmArgs& a, int pro, hipStream_t st)
     const int tpc = (a.P + BN - 1) / BN, nmt = (a.M + BM - 1) / BM;
     const long long total = (long long)a.nb * tpc * nmt;
     if (total > 0x7fffffffLL) return USIP_EINVAL;
-    const int epi = a.stats == nullptr ? EPI_NONE : (a.epi_y ? EPI_BWD_STATS : EPI_STATS);
+    const int epi = a.stats == nullptr ? EPI_NONE : EPI_STATS;
     dim3 grid((unsigned)total), block(256);
 #define USIP_GEMM_CASE(P_, E_)                                                                  \
     if (pro == P_ && epi == E_) {                                                               \
@@ -196,9 +196,6 @@ int launch_gemm_bf16_t(const GemmArgs& a, int pro, hipStream_t st)
     USIP_GEMM_CASE(PRO_AFFINE_RELU, EPI_NONE)
     USIP_GEMM_CASE(PRO_BN_BWD, EPI_NONE)
     USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_NONE)
-    USIP_GEMM_CASE(PRO_NONE, EPI_BWD_STATS)
-    USIP_GEMM_CASE(PRO_BN_BWD, EPI_BWD_STATS)
-    USIP_GEMM_CASE(PRO_BN_BWD_POOL, EPI_BWD_STATS)
 #undef USIP_GEMM_CASE
     return USIP_EINVAL;
 }

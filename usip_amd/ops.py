@@ -206,7 +206,7 @@ def matmul_mode() -> str:
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
-             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, epi=None):
+             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
     (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,M,tiles] when want_stats)."""
@@ -230,10 +230,6 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                            % (tuple(At.shape), tuple(X.shape), M, a_offset))
     Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
     stats = None
-    epi_y = epi_coef = None
-    if epi is not None:                       # (y, coef[4,M]) of the layer that produced this GEMM's output rows
-        epi_y, epi_coef = epi
-        want_stats = True
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
@@ -244,7 +240,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
-        e = (2 if epi is not None else 1) if want_stats else 0
+        e = 1 if want_stats else 0
         wg = tiles * ((M + wm * 64 - 1) // (wm * 64))
         if bf16:
             return "gemm_bf16_kernel<%d, %d, 16, %d, %d> |wg=%d" % (wm, wn, pro, e, wg)
@@ -257,7 +253,6 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                 None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group),
-                                                _opt(epi_y), _opt(epi_coef),
                                                 _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), fn_name)
     return Y, stats
 
@@ -308,22 +303,6 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
                                                           nb, C, P, _stream(dZ)),
                    "usip_bn_backward_reduce_f32")
     return dgamma, dbeta, coef4, gsum
-
-
-def bn_backward_finalize_tiles(stats, count, coef_fwd4, dgamma_out=None, dbeta_out=None, pool_partial=None,
-                               pool_nb: int = 0):
-    """Backward BN sums that arrived as GEMM-epilogue tiles -> (dgamma, dbeta, coef4)."""
-    _, C, tiles = stats.shape
-    dev = stats.device
-    dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
-    coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), prof.kernel("bn_backward_finalize", 8.0 * tiles * C):
-        _lib.check(_lib.lib().usip_bn_backward_finalize_tiles_f32(_ptr(stats), tiles, _opt(pool_partial), int(pool_nb), C,
-                                                                  int(count), _ptr(coef_fwd4), _ptr(dgamma), _ptr(dbeta),
-                                                                  _ptr(coef4), _stream(stats)),
-                   "usip_bn_backward_finalize_tiles_f32")
-    return dgamma, dbeta, coef4
 
 
 def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, relu: bool,
