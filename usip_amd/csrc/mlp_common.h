@@ -24,8 +24,6 @@ struct GemmArgs {
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
     int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
-    int ablate;                         // tuning aid (USIP_GEMM_ABLATE): 1 = no global loads after stage 0,
-                                        // 2 = additionally no LDS refill (pure MFMA + LDS-read loop). WRONG RESULTS.
 };
 
 // prologue on one element of the streamed operand, channel coefficients c0..c3

@@ -24,7 +24,6 @@
 // fp32 in, fp32 accumulate on the matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf
 // chain, so parity with the fp32 reference is a matter of summation order only (<= 1e-6).
 #include "mlp_common.h"
-#include <cstdlib>
 
 using namespace usip_mlp;
 
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     int cur = 0;
     const int kr = lane >> 5, c = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk && a.ablate == 0) load_stage((kt + 1) * BK);   // in flight under the MFMAs below
+        if (kt + 1 < nk) load_stage((kt + 1) * BK);         // in flight under the MFMAs below
         // fragments of step kk+2 are read from LDS while the four MFMAs of step kk run
         float fa0 = As[cur][kr][wm * 64 + c], fa1 = As[cur][kr][wm * 64 + 32 + c];
         float fb0 = Bs[cur][kr][wn * 64 + c], fb1 = Bs[cur][kr][wn * 64 + 32 + c];
@@ -194,8 +193,8 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        if (kt + 1 < nk && a.ablate < 2) store_stage(cur ^ 1, (kt + 1) * BK);
-        if (a.ablate < 2) __syncthreads();
+        if (kt + 1 < nk) store_stage(cur ^ 1, (kt + 1) * BK);
+        __syncthreads();
         cur ^= 1;
     }
 
@@ -654,10 +653,8 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
     if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 4 || pool_group % 4 != 0 ||
                                    P % pool_group != 0 || P % 4 != 0)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("USIP_GEMM_ABLATE"); ablate = e ? atoi(e) : 0; }
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
-               a_trans, ablate};
+               a_trans};
     hipStream_t st = (hipStream_t)stream;
     if (bf16) return launch_gemm_bf16(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
