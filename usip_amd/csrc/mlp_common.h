@@ -46,11 +46,11 @@ enum { EPI_NONE = 0, EPI_STATS = 1 };
 // Epilogue shared by the fp32 and the bf16-multiply kernels (the 32x32 accumulator layout is the same for
 // every 32x32xK MFMA): + bias (+ row bias), store, BatchNorm partial statistics.  `scratch` is LDS the main
 // loop no longer needs (>= 2*WN*BM floats; what is left holds the tile's row bias when it fits).
-template <int WM, int WN, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2][2], float* scratch,
+template <int WM, int WN, int EPI, int TM = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], float* scratch,
                                               int scratch_floats, int b, int m0, int p0, int tn, int tpc)
 {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * 32 * TM, BN = WN * 64;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -79,10 +79,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[2
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row_l = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int row_l = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int row = m0 + row_l;
             const int rowc = min(row, a.M - 1);
             const float bv = a.bias ? a.bias[rowc] : 0.0f;

@@ -29,10 +29,13 @@ using namespace usip_mlp;
 
 namespace {
 
-template <int WM, int WN, int BK, int PRO, int EPI, bool VEC>
+// TM = 32-row MFMA tiles per wave: 2 (64 x 64 per wave, the default) or 1 (32 x 64 per wave, block 64 x 128) for
+// launches whose 128-row tiling would leave most CUs idle -- a workgroup's time is its waves' K-loop, so the only
+// way to shorten an under-filled launch is less work per wave (tools/small_gemm_bench.py).
+template <int WM, int WN, int BK, int PRO, int EPI, bool VEC, int TM>
 __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
 {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * 32 * TM, BN = WN * 64;
     constexpr int NA = BM * BK / 256;           // A elements per thread per stage
     constexpr int NB4 = BK * BN / 4 / 256;      // X float4 per thread per stage (VEC)
     constexpr int NBS = BK * BN / 256;          // X scalars per thread per stage (!VEC)
@@ -60,9 +63,9 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     const float* pdp = POOL ? a.pool_dp + (long long)b * a.K * pgrp : nullptr;
     const int* parg = POOL ? a.pool_arg + (long long)b * a.K * pgrp : nullptr;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -174,37 +177,42 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_stage((kt + 1) * BK);         // in flight under the MFMAs below
         // fragments of step kk+2 are read from LDS while the four MFMAs of step kk run
-        float fa0 = As[cur][kr][wm * 64 + c], fa1 = As[cur][kr][wm * 64 + 32 + c];
-        float fb0 = Bs[cur][kr][wn * 64 + c], fb1 = Bs[cur][kr][wn * 64 + 32 + c];
+        float fa[TM], fb0 = Bs[cur][kr][wn * 64 + c], fb1 = Bs[cur][kr][wn * 64 + 32 + c];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = As[cur][kr][(wm * TM + i) * 32 + c];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = fa0, a1 = fa1, b0 = fb0, b1 = fb1;
+            float av[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = fa[i];
+            const float b0 = fb0, b1 = fb1;
             if (kk + 2 < BK) {
-                fa0 = As[cur][kk + 2 + kr][wm * 64 + c];
-                fa1 = As[cur][kk + 2 + kr][wm * 64 + 32 + c];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = As[cur][kk + 2 + kr][(wm * TM + i) * 32 + c];
                 fb0 = Bs[cur][kk + 2 + kr][wn * 64 + c];
                 fb1 = Bs[cur][kk + 2 + kr][wn * 64 + 32 + c];
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            // pin the order: next step's LDS reads first, then this step's four MFMAs cover them
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc[i][1], 0, 0, 0);
+            }
+            // pin the order: next step's LDS reads first, then this step's MFMAs cover them
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM, 0);
         }
         if (kt + 1 < nk) store_stage(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
         cur ^= 1;
     }
 
-    gemm_epilogue<WM, WN, EPI>(a, acc, &As[0][0][0], 2 * BK * BM, b, m0, p0, tn, tpc);   // LDS is free now
+    gemm_epilogue<WM, WN, EPI, TM>(a, acc, &As[0][0][0], 2 * BK * BM, b, m0, p0, tn, tpc);   // LDS is free now
 }
 
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, int TM>
 int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
 {
-    constexpr int BM = WM * 64, BN = WN * 64;
+    constexpr int BM = WM * 32 * TM, BN = WN * 64;
     const int tpc = (a.P + BN - 1) / BN, nmt = (a.M + BM - 1) / BM;
     const long long total = (long long)a.nb * tpc * nmt;
     if (total > 0x7fffffffLL) return USIP_EINVAL;
@@ -214,7 +222,7 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
     dim3 grid((unsigned)total), block(256);
 #define USIP_GEMM_CASE(P_, E_, V_)                                                              \
     if (pro == P_ && epi == E_ && vec == V_) {                                                  \
-        USIP_LAUNCH((gemm_kernel<WM, WN, BK, P_, E_, V_>), grid, block, 0, st, a);              \
+        USIP_LAUNCH((gemm_kernel<WM, WN, BK, P_, E_, V_, TM>), grid, block, 0, st, a);          \
         USIP_LAUNCH_CHECK();                                                                    \
         return USIP_OK;                                                                         \
     }
@@ -658,7 +666,12 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
     hipStream_t st = (hipStream_t)stream;
     if (bf16) return launch_gemm_bf16(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
-    return (M <= 64) ? launch_gemm<1, 4, 16>(a, pro, st) : launch_gemm<2, 2, 16>(a, pro, st);
+    // fewer than two workgroups per CU: halve the rows per wave (32 x 256 resp. 64 x 128 workgroups)
+    if (M <= 64)
+        return ((long long)nb * ((P + 255) / 256) < 512 && M <= 32) ? launch_gemm<1, 4, 16, 1>(a, pro, st)
+                                                                    : launch_gemm<1, 4, 16, 2>(a, pro, st);
+    if ((long long)nb * ((P + 127) / 128) * ((M + 127) / 128) < 512) return launch_gemm<2, 2, 16, 1>(a, pro, st);
+    return launch_gemm<2, 2, 16, 2>(a, pro, st);
 }
 
 #define USIP_GEMM_PARAMS                                                                                     \

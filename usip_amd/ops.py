@@ -241,10 +241,14 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         wm, wn = (1, 4) if M <= 64 else (2, 2)
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         e = 1 if want_stats else 0
-        wg = tiles * ((M + wm * 64 - 1) // (wm * 64))
         if bf16:
-            return "gemm_bf16_kernel<%d, %d, 16, %d, %d> |wg=%d" % (wm, wn, pro, e, wg)
-        return "gemm_kernel<%d, %d, 16, %d, %d, %s> |wg=%d" % (wm, wn, pro, e, "true" if P % 4 == 0 else "false", wg)
+            return "gemm_bf16_kernel<%d, %d, 16, %d, %d> |wg=%d" % (wm, wn, pro, e, tiles * ((M + wm * 64 - 1) // (wm * 64)))
+        # csrc/shared_mlp.hip mlp_gemm_impl: 32 rows per wave when 128-row tiles would not fill the chip
+        tm = 1 if ((M > 64 and nb * ((P + 127) // 128) * ((M + 127) // 128) < 512)
+                   or (M <= 32 and nb * ((P + 255) // 256) < 512)) else 2
+        bm = wm * 32 * tm
+        return "gemm_kernel<%d, %d, 16, %d, %d, %s, %d> |wg=%d" % (wm, wn, pro, e, "true" if P % 4 == 0 else "false", tm,
+                                                                   tiles * ((M + bm - 1) // bm))
 
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
