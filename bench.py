@@ -159,16 +159,19 @@ def main():
     torch.cuda.synchronize()
     barrier()
     # Per-kernel HIP events cost ~3 us of stream bubble each (~0.7 ms per step for ~220 of them): they are
-    # recorded on every 4th (eager) / 10th (graph replay) step of the timed region, which keeps the headline
+    # recorded on every 4th step (eager) or on the first step only (graph replay) of the timed region, which keeps the headline
     # number within ~1.5 % of an uninstrumented run while the kernel durations still come from inside the
     # timed region.
     # Sampled steps are launched eagerly (a graph replay cannot carry the events); the others replay the graphs.
-    sample_every = 10 if graphed else 4
+    sample_every = max(10, args.steps) if graphed else 4      # graph replay: only the first timed step is instrumented
     timed_steps_sampled = 0
     if not args.no_kernel_timing:
         prof.reset()
+    # one HIP event per step boundary (median and p10/p90 of the step time); 3 us each
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         sampled = (not args.no_kernel_timing) and (i % sample_every == 0)
         prof.enable(sampled)
@@ -177,6 +180,7 @@ def main():
             st.step(batch, eager=sampled)
         else:
             st.step(batch)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -212,6 +216,10 @@ def main():
                        "parallelism": "dp%d" % world},
             "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,
         }
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        if per_step:
+            pick = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
+            out["step_ms_rank0"] = {"p10": round(pick(0.1), 4), "median": round(pick(0.5), 4), "p90": round(pick(0.9), 4)}
         if not args.no_kernel_timing:
             summ = prof.summary()
             # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/profile_roofline.sh:
