@@ -24,6 +24,7 @@ struct GemmArgs {
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
     int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
+    int y_vec;                          // 1: P % 4 == 0 and Y 16-B aligned: runs of 4 positions are stored as one float4
 };
 
 // prologue on one element of the streamed operand, channel coefficients c0..c3
@@ -43,9 +44,16 @@ __device__ __forceinline__ float pro_apply(float x, float x2, float c0, float c1
 // EPI: 0 none | 1 BatchNorm statistics of Y: per-tile (sum, sum^2) partials
 enum { EPI_NONE = 0, EPI_STATS = 1 };
 
-// Epilogue shared by the fp32 and the bf16-multiply kernels (the 32x32 accumulator layout is the same for
-// every 32x32xK MFMA): + bias (+ row bias), store, BatchNorm partial statistics.  `scratch` is LDS the main
-// loop no longer needs (>= 2*WN*BM floats; what is left holds the tile's row bias when it fits).
+// Epilogue shared by the fp32 and the bf16-multiply kernels: + bias (+ row bias), store, BatchNorm partial
+// statistics.  The kernels issue their MFMAs with the operands SWAPPED (streamed operand as A, matrix operand as
+// B), so an accumulator tile is D'[position][channel]: lane l holds ONE channel (l & 31) and, per 32 x 32 tile,
+// four runs of four consecutive positions (r = 4g + e  ->  position 8g + 4(l >> 5) + e).  Hence
+//   * a run is one 16-B store (16 stores per thread instead of 64 scalar ones: the store tail of the short-K
+//     layers was issue-bound -- 17 % of a 128x64 forward GEMM);
+//   * bias and the channel's statistics are lane-local: plain adds plus ONE cross-half exchange per channel
+//     instead of a 32-lane reduction per accumulator register.
+// `scratch` is LDS the main loop no longer needs (>= 2*WN*BM floats; what is left holds the tile's row bias when
+// it fits).
 template <int WM, int WN, int EPI, int TM = 2>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], float* scratch,
                                               int scratch_floats, int b, int m0, int p0, int tn, int tpc)
@@ -56,16 +64,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
     const int wm = wave / WN, wn = wave % WN;
     float* Yb = a.Y + (long long)b * a.M * a.P;
     float* red = scratch;                                    // [2][WN][BM]
-    // the lane's two output columns and, for the pooled-concat layer, their neighbourhood index
-    // (ONE integer division per column instead of one per element)
-    int colj[2], grpj[2];
     const int ngrp = a.rowbias ? a.P / a.rb_group : 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        colj[j] = p0 + wn * 64 + j * 32 + c;
-        grpj[j] = a.rowbias ? min(colj[j], a.P - 1) / a.rb_group : 0;
-    }
-    // Row bias of this tile -> LDS once ([BM][G], G = neighbourhoods the tile's columns span) instead of one
+    // Row bias of this tile -> LDS once ([BM][G], G = neighbourhoods the tile's positions span) instead of one
     // global load per output element.
     float* rbs = red + 2 * WN * BM;
     const int g0 = a.rowbias ? p0 / a.rb_group : 0;
@@ -78,35 +78,63 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
         }
         __syncthreads();
     }
+    const bool run_one_group = a.rowbias && (a.rb_group % 4 == 0);   // a run of 4 positions never straddles a group
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int row_l = (wm * TM + i) * 32 + c;            // the lane's channel in this tile row
+        const int row = m0 + row_l;
+        const int rowc = min(row, a.M - 1);
+        const bool rok = row < a.M;
+        const float bv = a.bias ? a.bias[rowc] : 0.0f;
+        float* yrow = Yb + (long long)rowc * a.P;
+        float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row_l = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int row = m0 + row_l;
-            const int rowc = min(row, a.M - 1);
-            const float bv = a.bias ? a.bias[rowc] : 0.0f;
-            float s = 0.f, q = 0.f;
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v = acc[i][j][r] + bv;
-                if (a.rowbias)
-                    v += rb_lds ? rbs[row_l * G + grpj[j] - g0]
-                                : a.rowbias[((long long)b * a.M + rowc) * ngrp + grpj[j]];
-                if (row < a.M && colj[j] < a.P) {
-                    Yb[(long long)row * a.P + colj[j]] = v;
-                    if (EPI == EPI_STATS) { s += v; q = __builtin_fmaf(v, v, q); }
+            for (int g = 0; g < 4; ++g) {
+                const int pb = p0 + wn * 64 + j * 32 + 8 * g + 4 * half;   // first position of the run
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv;
+                if (a.rowbias) {
+                    if (run_one_group) {
+                        const int grp = min(pb, a.P - 1) / a.rb_group;
+                        const float rb = rb_lds ? rbs[row_l * G + grp - g0]
+                                                : a.rowbias[((long long)b * a.M + rowc) * ngrp + grp];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rb;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int grp = min(pb + e, a.P - 1) / a.rb_group;
+                            v[e] += rb_lds ? rbs[row_l * G + grp - g0]
+                                           : a.rowbias[((long long)b * a.M + rowc) * ngrp + grp];
+                        }
+                    }
+                }
+                if (rok) {
+                    if (a.y_vec && pb + 3 < a.P) {
+                        *reinterpret_cast<float4*>(yrow + pb) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (EPI == EPI_STATS) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { s += v[e]; q = __builtin_fmaf(v[e], v[e], q); }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (pb + e < a.P) {
+                                yrow[pb + e] = v[e];
+                                if (EPI == EPI_STATS) { s += v[e]; q = __builtin_fmaf(v[e], v[e], q); }
+                            }
+                    }
                 }
             }
-            if (EPI != EPI_NONE) {
-                // 32-lane sum: four DPP steps inside each row of 16 lanes (VALU, no LDS crossbar), then one
-                // cross-row exchange
-                s = usip_row16_sum(s); q = usip_row16_sum(q);
-                s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-                if (c == 0) {
-                    red[wn * BM + row_l] = s;
-                    red[WN * BM + wn * BM + row_l] = q;
-                }
+        }
+        if (EPI != EPI_NONE) {
+            s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);  // the other half-wave holds the channel's other positions
+            if (half == 0) {
+                red[wn * BM + row_l] = s;
+                red[WN * BM + wn * BM + row_l] = q;
             }
         }
     }

@@ -194,8 +194,9 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc[i][1], 0, 0, 0);
+                // operands swapped: D'[position][channel], see gemm_epilogue
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, av[i], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, av[i], acc[i][1], 0, 0, 0);
             }
             // pin the order: next step's LDS reads first, then this step's MFMAs cover them
             __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
@@ -662,7 +663,7 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
                                    P % pool_group != 0 || P % 4 != 0)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
-               a_trans};
+               a_trans, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     if (bf16) return launch_gemm_bf16(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)

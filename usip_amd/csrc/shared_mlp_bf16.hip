@@ -163,10 +163,11 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
                 fb0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + c][kk + 16 + kh]);
                 fb1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + 32 + c][kk + 16 + kh]);
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            // operands swapped: D'[position][channel], see gemm_epilogue
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
         }
         if (kt + 1 < nk) store_stage(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
