@@ -75,6 +75,12 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     // first touched (prologue math + ds_write) after them, so their latency hides under the MFMAs.
     float ra[NA];
     float4 rx[VEC ? NB4 : 1], ry[(VEC && TWO) ? NB4 : 1];
+    // BN+ReLU prologue: the float4's channel coefficients are fetched WITH the operand, a stage ahead (loaded
+    // where they are used they put a vector-load round trip between the MFMAs and the LDS refill of every
+    // stage).  Not for the BatchNorm-backward prologues: their four coefficients per float4 push the kernel over
+    // the 128-VGPR budget (24-180 B of scratch, the narrow data-gradient GEMMs 2x slower).
+    constexpr bool RC = VEC && (PRO == PRO_AFFINE_RELU);
+    float rc[RC ? NB4 : 1][2];
     float rxs[VEC ? 1 : NBS], rys[(!VEC && TWO) ? NBS : 1];
 
     auto load_stage = [&](int k0) {
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
                     rx[i] = *reinterpret_cast<const float4*>(Xb + off);
                 }
                 if (TWO) ry[i] = *reinterpret_cast<const float4*>(X2b + off);
+                if (RC) { rc[i][0] = a.coef[kc]; rc[i][1] = a.coef[a.K + kc]; }
             }
         } else {
 #pragma unroll
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
                     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     const int kc = min(k0 + k, a.K - 1);
-                    const float c0 = a.coef[kc], c1 = a.coef[a.K + kc];
+                    const float c0 = RC ? rc[RC ? i : 0][0] : a.coef[kc], c1 = RC ? rc[RC ? i : 0][1] : a.coef[a.K + kc];
                     float c2 = 0.f, c3 = 0.f;
                     float4 w = v;
                     if (TWO) { c2 = a.coef[2 * a.K + kc]; c3 = a.coef[3 * a.K + kc]; w = ry[i]; }
