@@ -81,6 +81,13 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
     // the 128-VGPR budget (24-180 B of scratch, the narrow data-gradient GEMMs 2x slower).
     constexpr bool RC = VEC && (PRO == PRO_AFFINE_RELU);
     float rc[RC ? NB4 : 1][2];
+    // BatchNorm-backward prologues (four coefficients per channel): a wave's 64 float4 cover KW = 256 / BN
+    // consecutive K rows (lanes [32h', ...) of a 128-wide tile, one row of a 256-wide tile), so the coefficients
+    // are fetched with SCALAR loads -- a stage ahead like the operands, in SGPRs, at no VGPR cost -- and picked
+    // per lane with one select each.
+    constexpr int KW = (64 * 4) / BN;                        // K rows per wave per float4 index: 2 or 1
+    constexpr bool SC = VEC && TWO;
+    float sc[SC ? NB4 : 1][4][KW];
     float rxs[VEC ? 1 : NBS], rys[(!VEC && TWO) ? NBS : 1];
 
     auto load_stage = [&](int k0) {
@@ -108,6 +115,15 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
                 }
                 if (TWO) ry[i] = *reinterpret_cast<const float4*>(X2b + off);
                 if (RC) { rc[i][0] = a.coef[kc]; rc[i][1] = a.coef[a.K + kc]; }
+                if (SC) {
+                    const int kw = __builtin_amdgcn_readfirstlane(k);     // the wave's first K row for this i
+#pragma unroll
+                    for (int h = 0; h < KW; ++h) {
+                        const int ks = min(k0 + kw + h, a.K - 1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sc[i][j][h] = a.coef[j * a.K + ks];
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -140,10 +156,20 @@ __global__ __launch_bounds__(256, 4) void gemm_kernel(const GemmArgs a)
                     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
                     const int kc = min(k0 + k, a.K - 1);
-                    const float c0 = RC ? rc[RC ? i : 0][0] : a.coef[kc], c1 = RC ? rc[RC ? i : 0][1] : a.coef[a.K + kc];
-                    float c2 = 0.f, c3 = 0.f;
+                    float c0, c1, c2 = 0.f, c3 = 0.f;
                     float4 w = v;
-                    if (TWO) { c2 = a.coef[2 * a.K + kc]; c3 = a.coef[3 * a.K + kc]; w = ry[i]; }
+                    if (SC) {
+                        const bool hi = KW > 1 && (lane >= 32);          // second K row of the wave
+                        c0 = hi ? sc[SC ? i : 0][0][KW - 1] : sc[SC ? i : 0][0][0];
+                        c1 = hi ? sc[SC ? i : 0][1][KW - 1] : sc[SC ? i : 0][1][0];
+                        c2 = hi ? sc[SC ? i : 0][2][KW - 1] : sc[SC ? i : 0][2][0];
+                        c3 = hi ? sc[SC ? i : 0][3][KW - 1] : sc[SC ? i : 0][3][0];
+                        w = ry[i];
+                    } else {
+                        c0 = RC ? rc[RC ? i : 0][0] : a.coef[kc];
+                        c1 = RC ? rc[RC ? i : 0][1] : a.coef[a.K + kc];
+                        if (TWO) { c2 = a.coef[2 * a.K + kc]; c3 = a.coef[3 * a.K + kc]; w = ry[i]; }
+                    }
                     if (POOL) {
                         const int hit = __float_as_int(v.y) - __float_as_int(v.z);   // arg - (first k of the float4)
                         const float g = v.x;
