@@ -254,6 +254,23 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
         pk[0] = (__bf16)v.x; pk[1] = (__bf16)v.y; pk[2] = (__bf16)v.z; pk[3] = (__bf16)v.w;
         *reinterpret_cast<bf16x4*>(dst) = pk;
     };
+    // per-row prologue coefficients, loaded once (a thread's rows are the same in every stage)
+    float gc[TWO ? NG4 : 1][4], xc[XPRO ? NX4 : 1][2];
+    if (TWO) {
+#pragma unroll
+        for (int i = 0; i < NG4; ++i) {
+            const int ch = min(m0 + (tid + i * 256) / (BKP / 4), a.M - 1);
+            gc[i][0] = a.coef[ch]; gc[i][1] = a.coef[a.M + ch];
+            gc[i][2] = a.coef[2 * a.M + ch]; gc[i][3] = a.coef[3 * a.M + ch];
+        }
+    }
+    if (XPRO) {
+#pragma unroll
+        for (int i = 0; i < NX4; ++i) {
+            const int ch = min(n0 + (tid + i * 256) / (BKP / 4), a.N - 1);
+            xc[i][0] = a.xcoef[ch]; xc[i][1] = a.xcoef[a.N + ch];
+        }
+    }
     auto store_stage = [&](int buf, int p) {
 #pragma unroll
         for (int i = 0; i < NG4; ++i) {
@@ -261,10 +278,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
             float4 v = rg[i];
             if (!TWO && VEC && !(m0 + row < a.M && p + kq < pend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (TWO) {
-                const int ch = min(m0 + row, a.M - 1);
                 const bool rok = m0 + row < a.M;
-                const float c0 = a.coef[ch], c1 = a.coef[a.M + ch], c2 = a.coef[2 * a.M + ch],
-                            c3 = a.coef[3 * a.M + ch];
+                const float c0 = gc[TWO ? i : 0][0], c1 = gc[TWO ? i : 0][1], c2 = gc[TWO ? i : 0][2],
+                            c3 = gc[TWO ? i : 0][3];
                 const float4 w = rg2[i];
                 if (POOL) {
                     const int hit = __float_as_int(v.y) - __float_as_int(v.z);
@@ -283,8 +299,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
             const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
             float4 v = rx[i];
             if (XPRO) {
-                const int ch = min(n0 + row, a.N - 1);
-                const float s0 = a.xcoef[ch], s1 = a.xcoef[a.N + ch];
+                const float s0 = xc[XPRO ? i : 0][0], s1 = xc[XPRO ? i : 0][1];
                 v.x = fmaxf(__builtin_fmaf(v.x, s0, s1), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, s0, s1), 0.f);
                 v.z = fmaxf(__builtin_fmaf(v.z, s0, s1), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, s0, s1), 0.f);
                 if (!VEC) {
