@@ -166,14 +166,14 @@ struct WgradArgs {
 // One stage of a [rows][32 positions] operand tile of the weight gradient: thread -> (row, 4
 // consecutive positions), 8 lanes cover one 128-B row segment.  Raw loads only; the BatchNorm-backward
 // prologue runs when the registers are written to LDS (after the MFMAs the loads overlap with).
-template <int N4, bool TWO, bool VEC>
+template <int N4, bool TWO, bool VEC, int Q4 = 8>
 __device__ __forceinline__ void wgrad_load_rows(const float* __restrict__ base, const float* __restrict__ base2,
                                                 int rows, int P, int r0, int p, int pend, int tid,
                                                 float4 (&dst)[N4], float4 (&dst2)[TWO ? N4 : 1])
 {
 #pragma unroll
     for (int i = 0; i < N4; ++i) {
-        const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
+        const int f = tid + i * 256, row = f / Q4, kq = (f % Q4) * 4;         // Q4 float4 per row and stage
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
         if (VEC) {
             // P % 4 == 0 and segments start at multiples of 32: a float4 is entirely inside or outside.

@@ -276,10 +276,10 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
 }
 
 template <int TM, int TN, int PRO, bool XPRO, bool VEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradArgs a)
 {
     // 2 x 2 waves, each TM x TN MFMA tiles of 32 x 32: block tile 128 x 128 (TM = TN = 2) or 64 x 64
-    constexpr int WN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32, BKP = 32;
+    constexpr int WN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32, BKP = 16;
     constexpr int LDM = BM + 2, LDN = BN + 2;
     __shared__ float Gs[2][BKP][LDM];
     __shared__ float Xs[2][BKP][LDN];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     auto load_pool = [&](int p) {
 #pragma unroll
         for (int i = 0; i < NG4; ++i) {
-            const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
+            const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
             const int rc = min(m0 + row, a.M - 1), pc = min(p + kq, a.P - 4);
             const long long g = ((long long)b * a.M + rc) * pgrp + pc / a.pool_group;
             rg[i] = make_float4(a.pool_dp[g], __int_as_float(a.pool_arg[g]), __int_as_float(pc % a.pool_group), 0.f);
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const int nst = (pend - pbeg + BKP - 1) / BKP;
     if (nst > 0) {
         if (POOL) load_pool(pbeg);
-        else wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
-        wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx, rdummy);
+        else wgrad_load_rows<NG4, TWO, VEC, BKP / 4>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
+        wgrad_load_rows<NX4, false, VEC, BKP / 4>(Xb, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx, rdummy);
         store_stage(0, pbeg);
     }
     __syncthreads();
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     for (int s = 0; s < nst; ++s) {
         if (s + 1 < nst) {
             if (POOL) load_pool(pbeg + (s + 1) * BKP);
-            else wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
-            wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx, rdummy);
+            else wgrad_load_rows<NG4, TWO, VEC, BKP / 4>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
+            wgrad_load_rows<NX4, false, VEC, BKP / 4>(Xb, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx, rdummy);
         }
         float fa[TM], fb[TN];
 #pragma unroll
