@@ -276,7 +276,7 @@ int launch_gemm(const GemmArgs& a, int pro, hipStream_t st)
 }
 
 template <int TM, int TN, int PRO, bool XPRO, bool VEC>
-__global__ __launch_bounds__(256, 3) void wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradArgs a)
 {
     // 2 x 2 waves, each TM x TN MFMA tiles of 32 x 32: block tile 128 x 128 (TM = TN = 2) or 64 x 64
     constexpr int WN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32, BKP = 16;
