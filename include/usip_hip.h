@@ -142,13 +142,15 @@ int usip_nearest_nd_f32(const float* a, const float* b, float* min_d, int32_t* a
  *   the contribution of input channels that are constant inside a neighbourhood of rb_group
  *   positions (the max-pooled feature the reference expands and concatenates, networks.py:706-709,
  *   layers.py:433-435) -- computed once per neighbourhood instead of once per neighbour.
+ *   y_rows: 0, or the number of rows per cloud of the tensor Y points into when the M output rows are a
+ *   channel slice of a wider [nb][y_rows][P] tensor (Y then points at the slice's first row of cloud 0).
  *   stats (may be NULL): [2][M][tiles] per-tile (sum, sum of squares) of Y over valid positions,
  *   tiles = usip_mlp_gemm_tiles(M, P, nb); summed in fixed order by usip_bn_finalize_f32. */
 int usip_mlp_gemm_tiles(int M, int P, int nb);
 int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2, const float* coef,
                       int pro, const float* bias, const float* rowbias, int rb_group,
                       const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                      float* Y, float* stats, int M, int K, int P, int nb, void* stream);
+                      float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
 /* Same contract with a bf16 MULTIPLY (the perf mode of BASELINE.json configs[1]; not the parity mode): tensors
  * stay fp32 in memory, the prologue runs in fp32, both operands are rounded to bf16 (nearest-even) on their way
  * into LDS, v_mfma_f32_32x32x16_bf16 accumulates in fp32, bias / rowbias / statistics are fp32.  The result
@@ -156,7 +158,7 @@ int usip_mlp_gemm_f32(const float* At, int lda, const float* X, const float* X2,
 int usip_mlp_gemm_bf16(const float* At, int lda, const float* X, const float* X2, const float* coef,
                        int pro, const float* bias, const float* rowbias, int rb_group,
                        const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                        float* Y, float* stats, int M, int K, int P, int nb, void* stream);
+                        float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
 
 /* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
  * coefficients coef[4][C] = (gamma*invstd, beta - mean*gamma*invstd, mean, invstd), and the running-statistics

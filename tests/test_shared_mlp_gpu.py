@@ -140,3 +140,45 @@ def test_gemm_reads_transposed_operand_in_place():
     y1, _ = ops.mlp_gemm(W.t().contiguous(), X)
     y2, _ = ops.mlp_gemm(W, X, a_trans=True)
     assert torch.equal(y1, y2)
+
+
+def test_nograd_prefix_skips_rows_of_the_data_gradient():
+    """conv1x1_bn_act(..., nograd_prefix=3): the data gradient of the remaining channels is computed straight
+    into its slice of the full tensor (GEMM with a destination row offset) and equals the full computation; the
+    prefix rows are zeros; parameter gradients do not change."""
+    from usip_amd import functional as Fh
+    B, Cin, Cout, M, K = 2, 3 + 128, 64, 24, 16
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, Cin, M, K, generator=g).to(DEV)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1).to(DEV)
+    gy = torch.randn(B, Cout, M, K, generator=g).to(DEV)
+
+    def run(prefix):
+        xs = x.clone().requires_grad_(True)
+        ws = w.clone().requires_grad_(True)
+        bn = torch.nn.BatchNorm2d(Cout).to(DEV)
+        y = Fh.conv1x1_bn_act(xs, ws, None, bn, True, nograd_prefix=prefix)
+        y.backward(gy)
+        return y.detach(), xs.grad, ws.grad, bn.weight.grad, bn.bias.grad
+
+    y0, gx0, gw0, gg0, gb0 = run(0)
+    y1, gx1, gw1, gg1, gb1 = run(3)
+    assert torch.equal(y0, y1) and torch.equal(gw0, gw1) and torch.equal(gg0, gg1) and torch.equal(gb0, gb1)
+    assert float(gx1[:, :3].abs().max()) == 0.0 and float(gx0[:, :3].abs().max()) > 0.0
+    assert _rel(gx1[:, 3:], gx0[:, 3:]) < 1e-6              # different tile split: summation order only
+
+
+def test_gemm_writes_a_channel_slice_of_a_wider_tensor():
+    """C ABI: y_rows / a destination row offset (ops.mlp_gemm(out=, out_row_offset=))."""
+    from usip_amd import ops
+    nb, K, M, P = 3, 40, 70, 260
+    g = torch.Generator().manual_seed(9)
+    At = torch.randn(K, M, generator=g).to(DEV)
+    X = torch.randn(nb, K, P, generator=g).to(DEV)
+    want, _ = ops.mlp_gemm(At, X)
+    out = torch.full((nb, M + 9, P), 7.0, device=DEV)
+    ops.mlp_gemm(At, X, out=out, out_row_offset=5)
+    assert torch.equal(out[:, 5:5 + M], want)
+    assert bool((out[:, :5] == 7.0).all()) and bool((out[:, 5 + M:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        ops.mlp_gemm(At, X, out=out, out_row_offset=10)

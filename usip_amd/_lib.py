@@ -34,9 +34,9 @@ SIGNATURES = {
     "usip_nearest_f32": ([_f32p, _f32p, _f32p, _i32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_tiles": ([_int, _int, _int], _int),
     "usip_mlp_gemm_f32": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
-                           _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
+                           _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_bf16": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
-                            _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
+                            _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p,
                                           _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _flt, _flt, _f32p, _f32p, _f32p,

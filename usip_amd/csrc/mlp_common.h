@@ -24,6 +24,7 @@ struct GemmArgs {
     const float* rowbias; int rb_group; // Y += rowbias[b][m][p / rb_group]  ([nb][M][P/rb_group]) or null
     const float* pool_dp; const int* pool_arg; int pool_group;   // PRO_BN_BWD_POOL: [nb][K][P/group] each
     int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
+    int y_rows;                         // rows per cloud of the tensor Y points into (>= M): Y[b] = Y + b*y_rows*P
     int y_vec;                          // 1: P % 4 == 0 and Y 16-B aligned: runs of 4 positions are stored as one float4
 };
 
@@ -62,7 +63,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    float* Yb = a.Y + (long long)b * a.M * a.P;
+    float* Yb = a.Y + (long long)b * a.y_rows * a.P;
     float* red = scratch;                                    // [2][WN][BM]
     const int ngrp = a.rowbias ? a.P / a.rb_group : 0;
     // Row bias of this tile -> LDS once ([BM][G], G = neighbourhoods the tile's positions span) instead of one

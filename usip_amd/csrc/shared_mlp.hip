@@ -697,7 +697,7 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, const float* X2,
                          const float* coef, int pro, const float* bias, const float* rowbias,
                          int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                         float* Y, float* stats, int M, int K, int P, int nb, void* stream)
+                         float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream)
 {
     // lda < 0 selects the transposed storage of the matrix operand: At is [M][K] with row stride -lda
     // (the forward product can then read W itself instead of a transposed copy made every step)
@@ -712,8 +712,10 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
     if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 4 || pool_group % 4 != 0 ||
                                    P % pool_group != 0 || P % 4 != 0)) return USIP_EINVAL;
     if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
+    if (y_rows == 0) y_rows = M;                           // Y is a dense [nb][M][P] tensor
+    if (y_rows < M) return USIP_EINVAL;
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
-               a_trans, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
+               a_trans, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     if (bf16) return launch_gemm_bf16(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
@@ -728,10 +730,10 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
 #define USIP_GEMM_PARAMS                                                                                     \
     const float *At, int lda, const float *X, const float *X2, const float *coef, int pro, const float *bias, \
         const float *rowbias, int rb_group, const float *pool_dp, const int32_t *pool_arg, int pool_group,    \
-        float *Y, float *stats, int M, int K, int P, int nb,                                                  \
+        float *Y, int y_rows, float *stats, int M, int K, int P, int nb,                                      \
         void *stream
 #define USIP_GEMM_ARGS \
-    At, lda, X, X2, coef, pro, bias, rowbias, rb_group, pool_dp, pool_arg, pool_group, Y, stats, \
+    At, lda, X, X2, coef, pro, bias, rowbias, rb_group, pool_dp, pool_arg, pool_group, Y, y_rows, stats, \
         M, K, P, nb, stream
 extern "C" int usip_mlp_gemm_f32(USIP_GEMM_PARAMS) { return mlp_gemm_impl(false, USIP_GEMM_ARGS); }
 extern "C" int usip_mlp_gemm_bf16(USIP_GEMM_PARAMS) { return mlp_gemm_impl(true, USIP_GEMM_ARGS); }

@@ -186,8 +186,9 @@ class _SharedMLPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, xcoef, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-                relu, defer, sink):
+                relu, defer, sink, nograd_prefix=0):
         ctx.sink = sink
+        ctx.nograd_prefix = int(nograd_prefix)
         ctx.set_materialize_grads(False)     # no zero-filled gradient for the (non-differentiable) coef output
         x = x.contiguous()
         # K-major copy of the weight [Cin][Cout]: the GEMM can also read W transposed in place (negative lda),
@@ -223,10 +224,10 @@ class _SharedMLPLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, _dcoef):
         if dz is None:
-            return (None,) * 14
+            return (None,) * 15
         dz = dz.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
-        tail = (None,) * 8
+        tail = (None,) * 9
         sink = ctx.sink                      # (w.grad, b.grad[, gamma.grad, beta.grad]) or None
         if not ctx.has_bn:
             x, xcoef, w2 = ctx.saved_tensors
@@ -248,7 +249,17 @@ class _SharedMLPLayer(torch.autograd.Function):
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
         dx = None
         if need_x:
-            dx = _dgrad(x, w2.contiguous(), dz, pro=2, X2=y, coef=coef4)
+            pre = ctx.nograd_prefix
+            if pre > 0:
+                # the first `pre` input channels carry no gradient (neighbour coordinates, layers.py:422-430):
+                # only the remaining rows of dX are computed, straight into their slice of the full tensor --
+                # for 3 + 128 channels that is one 128-row tile instead of two
+                dx = torch.empty_like(x)
+                dx[:, :pre].zero_()
+                ops.mlp_gemm(w2.contiguous(), dz, pro=2, X2=y, coef=coef4, tag="dgrad", M=x.shape[1] - pre,
+                             a_offset=pre, out=dx, out_row_offset=pre)
+            else:
+                dx = _dgrad(x, w2.contiguous(), dz, pro=2, X2=y, coef=coef4)
         dw = None
         if need_w:
             dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef,
@@ -429,11 +440,13 @@ def conv1x1_bn_act_pooled(h, pooled: torch.Tensor, weight: torch.Tensor, bias: O
 
 
 def conv1x1_bn_act(x, weight: torch.Tensor, bias: Optional[torch.Tensor],
-                   bn: Optional[torch.nn.modules.batchnorm._BatchNorm], relu: bool, defer: bool = False):
+                   bn: Optional[torch.nn.modules.batchnorm._BatchNorm], relu: bool, defer: bool = False,
+                   nograd_prefix: int = 0):
     """One shared-MLP layer: 1x1 convolution (+bias) -> BatchNorm (batch statistics when the
     module is in training mode) -> ReLU  (models/layers.py:208-216, :293-303).
     x [B,Cin,*positions] (tensor or LazyAct), weight [Cout,Cin,1(,1)] -> [B,Cout,*positions];
-    defer=True (BatchNorm layers only) returns a LazyAct instead of the activated tensor."""
+    defer=True (BatchNorm layers only) returns a LazyAct instead of the activated tensor.
+    nograd_prefix: the first so many input channels need no gradient (their rows of dX are zeros, not computed)."""
     shape = x.shape
     xcoef = None
     if isinstance(x, LazyAct):
@@ -454,7 +467,7 @@ def conv1x1_bn_act(x, weight: torch.Tensor, bias: Optional[torch.Tensor],
         bn.num_batches_tracked.add_(1)
     y, coef = _SharedMLPLayer.apply(x3, xcoef, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     training, bn.momentum, bn.eps, relu, defer,
-                                    _sink(weight, bias, bn.weight, bn.bias) if training else None)
+                                    _sink(weight, bias, bn.weight, bn.bias) if training else None, nograd_prefix)
     return LazyAct(y, coef, relu, oshape) if defer else y.view(oshape)
 
 

@@ -92,13 +92,15 @@ class MyConv2d(nn.Module):
             self.act = nn.ReLU()
         _init_conv(self.conv, in_channels)
 
-    def forward(self, x, epoch=None, defer=False):
-        """defer=True (internal use by the fused networks): return a functional.LazyAct."""
+    def forward(self, x, epoch=None, defer=False, nograd_prefix=0):
+        """defer=True (internal use by the fused networks): return a functional.LazyAct.
+        nograd_prefix: leading input channels that need no gradient (see functional.conv1x1_bn_act)."""
         bn = getattr(self, "norm", None)
         if bn is not None:
             bn.decay_momentum(epoch)
         return Fh.conv1x1_bn_act(x, self.conv.weight, self.conv.bias, bn, self.activation == "relu",
-                                 defer=defer and bn is not None and self.activation == "relu")
+                                 defer=defer and bn is not None and self.activation == "relu",
+                                 nograd_prefix=nograd_prefix)
 
 
 class EquivariantLayer(nn.Module):
@@ -182,8 +184,9 @@ class GeneralKNNFusionModule(nn.Module):
         knn_I = Fh.knn_indices(query, database, K)                       # layers.py:417-421
         self.last_knn_I = knn_I
         h = Fh.knn_group(x, database.detach(), query.detach(), knn_I)    # :422-430
-        for layer in self.layers_before:
-            h = layer(h, epoch, defer=True)
+        for n, layer in enumerate(self.layers_before):
+            # the three decentered coordinates in front of the features are inputs without a gradient
+            h = layer(h, epoch, defer=True, nograd_prefix=3 if n == 0 else 0)
         pooled, h = Fh.group_max_fork(h)                                 # :433 (BN+ReLU+max in one pass)
         first, rest = self.layers_after[0], list(self.layers_after)[1:]
         bn = getattr(first, "norm", None)

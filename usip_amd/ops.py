@@ -206,7 +206,8 @@ def matmul_mode() -> str:
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
-             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False):
+             M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, out=None,
+             out_row_offset: int = 0):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
     (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,M,tiles] when want_stats)."""
@@ -228,7 +229,18 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     if Kx != K or a_offset < 0 or a_offset + (K if a_trans else M) > lda:
         raise RuntimeError("mlp_gemm: operand shapes do not match (At %s, X %s, M %d, offset %d)"
                            % (tuple(At.shape), tuple(X.shape), M, a_offset))
-    Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
+    y_rows = 0
+    if out is None:
+        Y = torch.empty((nb, M, P), dtype=torch.float32, device=X.device)
+        y_ptr = _ptr(Y)
+    else:                                     # rows [out_row_offset, out_row_offset + M) of a wider [nb, rows, P] tensor
+        _need(out, "out", torch.float32)
+        if out.dim() != 3 or out.shape[0] != nb or out.shape[2] != P or out_row_offset < 0 \
+                or out_row_offset + M > out.shape[1]:
+            raise RuntimeError("mlp_gemm: out %s does not hold rows [%d, %d) of [%d, *, %d]"
+                               % (tuple(out.shape), out_row_offset, out_row_offset + M, nb, P))
+        Y, y_rows = out, out.shape[1]
+        y_ptr = ctypes.c_void_p(out.data_ptr() + 4 * int(out_row_offset) * P)
     stats = None
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
@@ -257,7 +269,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                 None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group),
-                                                _ptr(Y), _opt(stats), M, K, P, nb, _stream(X)), fn_name)
+                                                y_ptr, int(y_rows), _opt(stats), M, K, P, nb, _stream(X)), fn_name)
     return Y, stats
 
 
