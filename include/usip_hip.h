@@ -160,6 +160,13 @@ int usip_mlp_gemm_bf16(const float* At, int lda, const float* X, const float* X2
                        const float* pool_dp, const int32_t* pool_arg, int pool_group,
                         float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
 
+/* K-major copies of many weight matrices in one launch: for every t < ntensors, table[5t..5t+4] =
+ * (source offset, rows, cols, destination offset, index of its first 32 x 32 tile), offsets in floats into src / dst;
+ * dst[dof + c*rows + r] = src[sof + r*cols + c].  The reference stores Conv weights [Cout][Cin][1(,1)]
+ * (models/layers.py:186-205); the GEMMs want [Cin][Cout].  total_tiles = sum of ceil(rows/32)*ceil(cols/32). */
+int usip_multi_transpose_f32(const float* src, float* dst, const int32_t* table, int ntensors, int total_tiles,
+                             void* stream);
+
 /* Batch statistics -> mean[C], invstd[C] (biased variance, eps inside the sqrt), forward
  * coefficients coef[4][C] = (gamma*invstd, beta - mean*gamma*invstd, mean, invstd), and the running-statistics
  * update running = (1-momentum)*running + momentum*batch (unbiased variance), as F.batch_norm does

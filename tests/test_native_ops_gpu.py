@@ -263,3 +263,20 @@ def test_ball_query_kernels_match_reference_numba_ancestor():
         assert np.array_equal(got[~empty], g[n + "_idx"][~empty]), n
         assert not got[empty].any()
 
+
+
+def test_multi_transpose_matches_per_tensor_transposes():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 7), (64, 64), (131, 256), (4, 256), (33, 1), (512, 640)]
+    src = torch.randn(sum(r * c for r, c in shapes) + 11, generator=g).to(DEV)
+    rows, off, dof, tiles = [], 5, 0, 0
+    for r, c in shapes:
+        rows.append((off, r, c, dof, tiles))
+        off += r * c
+        dof += r * c
+        tiles += ((r + 31) // 32) * ((c + 31) // 32)
+    dst = torch.full((dof,), float("nan"), device=DEV)
+    ops.multi_transpose(src, dst, torch.tensor(rows, dtype=torch.int32, device=DEV), tiles)
+    for (so, r, c, do, _), _s in zip(rows, shapes):
+        assert torch.equal(dst[do:do + r * c].view(c, r), src[so:so + r * c].view(r, c).t())

@@ -22,6 +22,18 @@ GRAD_SINK = False
 DEFER_BN_COUNTERS = False
 
 
+# Set by the training step for the duration of forward + backward: {weight.data_ptr(): K-major copy [Cin, Cout]}
+# made for ALL layers by one launch (ops.multi_transpose) after the last parameter update.  None: every layer
+# transposes its own weight (any caller outside the step).
+WT_CACHE = None
+
+
+def _kmajor(w2):
+    """[Cin, Cout] copy of the weight matrix w2 [Cout, Cin]."""
+    cached = WT_CACHE.get(w2.data_ptr()) if WT_CACHE is not None else None
+    return cached if cached is not None else w2.detach().t().contiguous()
+
+
 def _sink(*params):
     if not GRAD_SINK:
         return None
@@ -193,7 +205,7 @@ class _SharedMLPLayer(torch.autograd.Function):
         x = x.contiguous()
         # K-major copy of the weight [Cin][Cout]: the GEMM can also read W transposed in place (negative lda),
         # but the strided operand loads cost more (+0.3 ms/step measured) than these tiny copies
-        wt = w2.detach().t().contiguous()
+        wt = _kmajor(w2)
         nb, _, P = x.shape
         ctx.has_bn = gamma is not None
         ctx.relu = bool(relu)
@@ -283,7 +295,7 @@ class _SharedMLPLayerMax(torch.autograd.Function):
         B, Cin, M, K = dims
         x3 = x.contiguous().view(B, Cin, M * K)
         Cout = w2.shape[0]
-        y, stats = ops.mlp_gemm(w2.detach().t().contiguous(), x3, bias, want_stats=True,
+        y, stats = ops.mlp_gemm(_kmajor(w2), x3, bias, want_stats=True,
                                 pro=0 if xcoef is None else 1, coef=xcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum, running_mean, running_var)
         pooled, arg = ops.group_max_act(y.view(B, Cout, M, K), coef, True)
@@ -365,7 +377,7 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         poff, hoff = (0, Cp) if pooled_first else (Ch, 0)
         h3 = h.contiguous().view(B, Ch, M * K)
         pooled = pooled.contiguous()
-        wt = w2.detach().t().contiguous()                                   # [Ctot][Cout]
+        wt = _kmajor(w2)                                                    # [Ctot][Cout]
         r, _ = ops.mlp_gemm(wt[poff:poff + Cp], pooled, tag="fwd_pooled")   # [B,Cout,M]
         y, stats = ops.mlp_gemm(wt[hoff:hoff + Ch], h3, bias, want_stats=True, rowbias=r, rb_group=K,
                                 pro=0 if hcoef is None else 1, coef=hcoef)

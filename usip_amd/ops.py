@@ -451,6 +451,18 @@ def group_max_backward_add_(dz, dpooled, arg):
     return dz
 
 
+def multi_transpose(src_flat, dst_flat, table, total_tiles: int):
+    """K-major copies of all weight matrices described by `table` (int32 [n,5]: source offset, rows, cols,
+    destination offset, first tile) from src_flat into dst_flat, one launch."""
+    _need(src_flat, "src", torch.float32)
+    _need(dst_flat, "dst", torch.float32)
+    _need(table, "table", torch.int32)
+    with torch.cuda.device(src_flat.device), prof.kernel("weight_transposes", 8.0 * dst_flat.numel()):
+        _lib.check(_lib.lib().usip_multi_transpose_f32(_ptr(src_flat), _ptr(dst_flat), _ptr(table), int(table.shape[0]),
+                                                       int(total_tiles), _stream(src_flat)), "usip_multi_transpose_f32")
+    return dst_flat
+
+
 def nearest_nd(a: torch.Tensor, b: torch.Tensor):
     """f-1: (min_j |a_i - b_j| [B,Ma], first arg-min i32 [B,Ma]) for C-dimensional a [B,C,Ma], b [B,C,Nb<=1024]."""
     _need(a, "a", torch.float32)

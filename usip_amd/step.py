@@ -38,7 +38,9 @@ class FlatGradBucket:
             self.flat_param = torch.nn.Parameter(store)
             self.flat_param.grad = self.flat
         off = 0
+        self.offsets = {}                                     # id(parameter) -> offset of its values in the flat buffers
         for p in self.params:
+            self.offsets[id(p)] = off
             if self.flat_param is not None:
                 view = self.flat_param.data[off:off + p.numel()].view_as(p)
                 view.copy_(p.data)
@@ -84,6 +86,22 @@ class _GraphedStep:
             params = [self.bucket.flat_param] if self.bucket.flat_param is not None else module.parameters()
             self.optimizer = torch.optim.Adam(params, lr=opt.lr, betas=(0.9, 0.999), fused=on_gpu,
                                               capturable=self.use_graph)
+        # K-major copies of all convolution weights ([Cout, Cin, 1(, 1)] -> [Cin, Cout]) by ONE launch per step
+        self._wt = None
+        if self.bucket.flat_param is not None:
+            rows, views, dof, tiles = [], {}, 0, 0
+            for p in self.bucket.params:
+                if p.dim() >= 3 and p.numel() == p.shape[0] * p.shape[1]:
+                    co, ci = int(p.shape[0]), int(p.shape[1])
+                    rows.append((self.bucket.offsets[id(p)], co, ci, dof, tiles))
+                    views[p.data_ptr()] = (dof, ci, co)
+                    dof += co * ci
+                    tiles += ((co + 31) // 32) * ((ci + 31) // 32)
+            if rows:
+                flat_wt = torch.empty(dof, dtype=torch.float32, device=self.device)
+                table = torch.tensor(rows, dtype=torch.int32, device=self.device)
+                self._wt = (flat_wt, table, tiles,
+                            {ptr: flat_wt[o:o + ci * co].view(ci, co) for ptr, (o, ci, co) in views.items()})
         self.last: Dict[str, torch.Tensor] = {}
         self._graphs: Dict = {}                               # key -> (graph A, graph B or None, static batch, last, loss)
         self._eager_calls = 0
@@ -105,15 +123,21 @@ class _GraphedStep:
 
     def _forward_backward(self, batch, epoch):
         from . import functional as Fh
+        from . import ops
         self.bucket.zero()                                    # zero_grad()
         Fh.GRAD_SINK = True       # every parameter is used once per step and the bucket was just zeroed:
         Fh.DEFER_BN_COUNTERS = True   # the backward kernels write dW/dgamma/dbeta straight into the bucket
         try:
+            if self._wt is not None:                          # fresh K-major weights for every layer, one launch
+                flat_wt, table, tiles, views = self._wt
+                ops.multi_transpose(self.bucket.flat_param.data, flat_wt, table, tiles)
+                Fh.WT_CACHE = views
             loss = self.forward_losses(batch, epoch)
             loss.backward()
         finally:
             Fh.GRAD_SINK = False
             Fh.DEFER_BN_COUNTERS = False
+            Fh.WT_CACHE = None
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)         # every BatchNorm ran exactly once
         return loss
