@@ -159,11 +159,14 @@ def main():
     torch.cuda.synchronize()
     barrier()
     # Per-kernel HIP events cost ~3 us of stream bubble each (~0.7 ms per step for ~220 of them): they are
-    # recorded on every 4th step (eager) or on the first step only (graph replay) of the timed region, which keeps the headline
+    # recorded on every 4th step (1-GPU eager runs) or on one middle step only (graph replay, multi-GPU), which keeps the headline
     # number within ~1.5 % of an uninstrumented run while the kernel durations still come from inside the
     # timed region.
     # Sampled steps are launched eagerly (a graph replay cannot carry the events); the others replay the graphs.
-    sample_every = max(10, args.steps) if graphed else 4      # graph replay: only the first timed step is instrumented
+    # light instrumentation (graph replay, and every multi-GPU run so that all N are measured alike): ONE step of
+    # the timed region carries events, and only around the shared-MLP launches
+    light = graphed or world > 1
+    sample_every = 4
     timed_steps_sampled = 0
     if not args.no_kernel_timing:
         prof.reset()
@@ -175,10 +178,10 @@ def main():
     for i in range(args.steps):
         # graph replay: instrument the MIDDLE step -- the host is then a few replays ahead of the GPU, so the ~8 ms it
         # needs to launch an eager step never leave the GPU waiting (at step 0 they do: the queue starts empty)
-        sampled = (not args.no_kernel_timing) and ((i == args.steps // 2) if graphed else (i % sample_every == 0))
+        sampled = (not args.no_kernel_timing) and ((i == args.steps // 2) if light else (i % sample_every == 0))
         # graph replay: the one instrumented step brackets only the shared-MLP launches (the roofline kernel's
         # family); the other operators are timed in an extra step after the timed region (see below)
-        prof.enable(sampled, only="shared_mlp" if graphed else None)
+        prof.enable(sampled, only="shared_mlp" if light else None)
         timed_steps_sampled += int(sampled)
         if graphed:
             st.step(batch, eager=sampled)
@@ -194,6 +197,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(st.last["loss"].item())
+    summ = None
+    if not args.no_kernel_timing:
+        summ = prof.summary()
+        if light:
+            # the remaining operators: one fully instrumented eager step AFTER the timed region (not part of
+            # `value`; on every rank, it contains the gradient all-reduce); shared-MLP entries keep their in-region
+            # timings
+            prof.reset()
+            prof.enable(True)
+            if graphed:
+                st.step(batch, eager=True)
+            else:
+                st.step(batch)
+            prof.enable(False)
+            for name, r in prof.summary().items():
+                if name not in summ:
+                    r = dict(r)
+                    r["calls"] = r["calls"] * timed_steps_sampled         # normalised per sampled step below
+                    r["total_ms"] = r["total_ms"] * timed_steps_sampled
+                    summ[name] = r
 
     if rank == 0:
         clouds = world * 2 * args.pairs * args.steps
@@ -227,20 +250,6 @@ def main():
             out["step_ms_rank0"] = {"p10": round(pick(0.1), 4), "median": round(pick(0.5), 4), "p90": round(pick(0.9), 4),
                                     "max": round(per_step[-1], 4), "first": round(raw_steps[0], 4)}
         if not args.no_kernel_timing:
-            summ = prof.summary()
-            if graphed:
-                # the remaining operators: one fully instrumented eager step AFTER the timed region (not part of
-                # `value`); shared-MLP entries keep their in-region timings
-                prof.reset()
-                prof.enable(True)
-                st.step(batch, eager=True)
-                prof.enable(False)
-                for name, r in prof.summary().items():
-                    if name not in summ:
-                        r = dict(r)
-                        r["calls"] = r["calls"] * timed_steps_sampled     # normalised per sampled step below
-                        r["total_ms"] = r["total_ms"] * timed_steps_sampled
-                        summ[name] = r
             # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/profile_roofline.sh:
             # separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per
             # MI355X_MICROARCH.md).  Keyed by kernel template + workgroup count; a key shared by several
@@ -300,15 +309,16 @@ def main():
                     if top["mfma"] else top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
                     "avg_us": round(avg_s * 1e6, 2),
                     "share_of_step": round(top["ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
-                    "timing": "HIP events on the launch stream, every %d-th step of the timed region (%d steps)"
-                              % (sample_every, timed_steps_sampled),
+                    "timing": ("HIP events on the launch stream, one eager step in the middle of the timed region"
+                               if light else "HIP events on the launch stream, every %d-th step of the timed region "
+                               "(%d steps)" % (sample_every, timed_steps_sampled)),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
                     "traffic_source": traffic_src,
                     "attainable_peak_note": "a pure fp32-MFMA loop (tools/mfma_peak.hip) sustains 121-141 TFLOP/s with "
                                             "random operands on this chip (clock 1.85-2.15 GHz under load), see "
                                             "profiles/r01_mfma_attainable_peak.txt" if (top["mfma"] and args.precision == "f32") else None}
                 out["kernels"] = kernels
-                if graphed:
+                if light:
                     out["kernels_note"] = ("shared_mlp_* rows: HIP events inside the timed region (one eager step); the "
                                            "other rows: one instrumented eager step run after the timed region")
         if world == 1 and not args.no_cpu_baseline:
