@@ -48,10 +48,37 @@ __global__ __launch_bounds__(256) void som_cluster_kernel(
     if (m >= M) return;
     const float* xb = x + (long long)b * 3 * N;
     const int32_t* ib = min_idx + (long long)b * N;
-    float sx = 0.f, sy = 0.f, sz = 0.f;
+    // sums in double: the mean is then the correctly rounded exact mean, whatever the order of the scan
+    double sx = 0.0, sy = 0.0, sz = 0.0;
     int c = 0;
-    for (int n = lane; n < N; n += 64) {
-        if (ib[n] == m) { sx += xb[n]; sy += xb[N + n]; sz += xb[2 * N + n]; c += 1; }
+    if ((N & 3) == 0 && (reinterpret_cast<uintptr_t>(ib) & 15u) == 0) {
+        // the scan is bound by the latency of the index loads (one in flight per wave otherwise): 16-B loads,
+        // four of them issued before the first compare; the coordinate loads happen for ~N/M hits only
+        int n0 = lane * 4;
+        for (; n0 + 3 * 256 < N; n0 += 4 * 256) {
+            int4 id[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) id[u] = *reinterpret_cast<const int4*>(ib + n0 + u * 256);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = n0 + u * 256;
+                if (id[u].x == m) { sx += xb[n]; sy += xb[N + n]; sz += xb[2 * N + n]; c += 1; }
+                if (id[u].y == m) { sx += xb[n + 1]; sy += xb[N + n + 1]; sz += xb[2 * N + n + 1]; c += 1; }
+                if (id[u].z == m) { sx += xb[n + 2]; sy += xb[N + n + 2]; sz += xb[2 * N + n + 2]; c += 1; }
+                if (id[u].w == m) { sx += xb[n + 3]; sy += xb[N + n + 3]; sz += xb[2 * N + n + 3]; c += 1; }
+            }
+        }
+        for (; n0 < N; n0 += 256) {
+            const int4 id = *reinterpret_cast<const int4*>(ib + n0);
+            if (id.x == m) { sx += xb[n0]; sy += xb[N + n0]; sz += xb[2 * N + n0]; c += 1; }
+            if (id.y == m) { sx += xb[n0 + 1]; sy += xb[N + n0 + 1]; sz += xb[2 * N + n0 + 1]; c += 1; }
+            if (id.z == m) { sx += xb[n0 + 2]; sy += xb[N + n0 + 2]; sz += xb[2 * N + n0 + 2]; c += 1; }
+            if (id.w == m) { sx += xb[n0 + 3]; sy += xb[N + n0 + 3]; sz += xb[2 * N + n0 + 3]; c += 1; }
+        }
+    } else {
+        for (int n = lane; n < N; n += 64) {
+            if (ib[n] == m) { sx += xb[n]; sy += xb[N + n]; sz += xb[2 * N + n]; c += 1; }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -63,7 +90,7 @@ __global__ __launch_bounds__(256) void som_cluster_kernel(
     if (lane == 0) {
         const float denom = (float)c + 1e-5f;                            // networks.py:95-96
         float* cm = cluster_mean + (long long)b * 3 * M;
-        cm[m] = sx / denom; cm[M + m] = sy / denom; cm[2 * M + m] = sz / denom;
+        cm[m] = (float)sx / denom; cm[M + m] = (float)sy / denom; cm[2 * M + m] = (float)sz / denom;
         count[(long long)b * M + m] = c;
     }
 }
