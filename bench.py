@@ -38,8 +38,8 @@ PEAK_BF16_TFLOPS = 2500.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # warm-up 10, >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="ball", choices=["ball", "som", "descriptor"],
                     help="ball = RPN_Detector_Ball (the K=64 headline model), som = RPN_Detector, "
                          "descriptor = DescriptorLiteOld step (BASELINE configs[4], SURVEY 8 f-1)")
@@ -53,43 +53,138 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host instead of replaying the step from HIP graphs")
     ap.add_argument("--graph", action="store_true",
-                    help="replay from HIP graphs at N > 1 as well (default there: eager launches -- capture next to "
-                         "an RCCL communicator cannot be exercised on the 1-GPU development boxes)")
+                    help="(default since round 2, kept for old command lines) replay from HIP graphs at every N: graph A "
+                         "(forward+backward) / eager RCCL all-reduce / graph B (Adam); a refused capture falls back "
+                         "to eager launches with a warning")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-kernel-leg", action="store_true",
+                    help="skip the stand-alone roofline leg of the two HBM-bound integer kernels the north star names "
+                         "(dist-in ball_query, index_max), which runs after the timed region at N=1")
+    ap.add_argument("--only-kernels", action="store_true",
+                    help="run ONLY that leg and print its rows (what tools/profile_roofline.sh puts under rocprofv3)")
     return ap.parse_args()
 
 
+def load_traffic_db(precision):
+    """HBM traffic per launch from the committed rocprofv3 PMC passes (tools/profile_roofline.sh: separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    Keyed by kernel template + workgroup count; a key shared by several layer shapes carries their average."""
+    import glob
+    db, src = {}, []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
+        if ("bf16" in os.path.basename(f)) != (precision == "bf16"):
+            continue                               # each precision mode has its own kernels and PMC passes
+        try:
+            db.update(json.load(open(f)))          # later rounds override earlier ones key by key
+            src.append(os.path.basename(f))
+        except (OSError, ValueError):
+            pass
+    return db, (src[-1] if src else None)
+
+
+def kernel_leg(dev, traffic_db, iters=12):
+    """The two HBM-bound integer kernels of the path on their own, at BASELINE configs[2] sizes (B'=16 clouds,
+    N=16384, M=512): dist-in ball_query on "cube" clouds (every row is a full scan: the defining case of SURVEY 8d)
+    and index_max at C=64 / C=128.  Every launch reads a DIFFERENT buffer of a ring whose total size exceeds the
+    256 MB Infinity Cache, so the bytes come from HBM, not from the cache the previous launch (or the producer)
+    left them in.  HIP events on the launch stream around every launch; median."""
+    import numpy as np
+    from usip_amd import ops, synth
+    B, N, M, K = 16, 16384, 512, 64
+    rows = []
+
+    def timed(fn_of_i, n_ring):
+        for i in range(3):
+            fn_of_i(i % n_ring)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for i, (s, e) in enumerate(evs):
+            s.record()
+            fn_of_i(i % n_ring)
+            e.record()
+        torch.cuda.synchronize()
+        t = sorted(s.elapsed_time(e) for s, e in evs)
+        return t[len(t) // 2] * 1e-3, t[0] * 1e-3, t[-1] * 1e-3
+
+    def row(name, alg, t, key, note):
+        med, lo, hi = t
+        tr = traffic_db.get(key, {})
+        rows.append({"kernel": name, "calls_per_step": 0, "avg_us": round(med * 1e6, 2), "min_us": round(lo * 1e6, 2),
+                     "max_us": round(hi * 1e6, 2), "share_of_step": 0.0, "bound": "hbm",
+                     "achieved": round(alg / med / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": round(alg / med / 1e9 / PEAK_HBM_GBPS, 4), "algorithmic_bytes": alg,
+                     "traffic": tr.get("hbm_bytes_per_launch"), "rocprof_key": key, "rocprof_avg_us": tr.get("avg_us"),
+                     "note": note})
+
+    rng = np.random.default_rng(0)
+    ring = []
+    for _ in range(3):                                         # 3 x 537 MB distance matrices
+        x = torch.from_numpy(np.stack([synth.make_cloud(rng, N, "cube") for _ in range(B)])).to(dev)
+        ring.append(ops.pairwise_dist(x[:, :, :M].contiguous(), x))
+    inside = ring[0] <= 2.0                                    # algorithmic bytes: scanned prefix of every row
+    cs = torch.cumsum(inside.int(), -1)
+    kth = (cs >= K).int().argmax(-1)
+    prefix = int(torch.where(cs[..., -1] >= K, kth + 1, torch.full_like(kth, N)).sum().item())
+    del inside, cs, kth
+    alg = 4.0 * prefix + 4.0 * B * M * K
+    t = timed(lambda i: ops.ball_query(ring[i], 2.0, K), len(ring))
+    row("ball_query (dist-in, cube, B'=16)", alg, t, "ball_query_kernel<1, true> |wg=%d" % (B * M),
+        "stand-alone leg, ring of 3 distinct 537 MB inputs (defeats the 256 MB Infinity Cache)")
+    del ring
+    for C in (64, 128):
+        n_ring = 8 if C == 64 else 4                           # 8 x 67 MB / 4 x 134 MB of values
+        data = [torch.randn(B, C, N, device=dev) for _ in range(n_ring)]
+        idx = [torch.randint(0, M, (B, N), device=dev, dtype=torch.int32) for _ in range(n_ring)]
+        alg = 4.0 * (B * C * N + B * N + B * C * M)
+        t = timed(lambda i: ops.index_max(data[i], idx[i], M), n_ring)
+        ch, u = ops.index_max_geometry(B, C, N, M)
+        row("index_max (C=%d, B'=16)" % C, alg, t, "index_max_kernel<%d, %d, true> |wg=%d" % (ch, u, B * C // ch),
+            "stand-alone leg, ring of %d distinct inputs (%d MB)" % (n_ring, n_ring * B * C * N * 4 // 1000000))
+        del data, idx
+    return rows
+
+
 def cpu_baseline(args, model):
-    """The oracle (PyTorch-CPU restatement, proven equal to the reference by the golden fixtures)
-    on a bounded sample: 1 pair = 2 clouds of the same workload, 1 warm-up + 2 timed steps."""
+    """the oracle (PyTorch-CPU restatement of the same step, proven equal to the reference by the golden
+    fixtures) on a bounded sample -- 1 pair = 2 clouds of the same workload -- for BOTH detectors: (A)
+    RPN_Detector_Ball, the K=64 headline model, and (B) RPN_Detector, the reference's default.  3 warm-up + 5 timed
+    steps each, median.  `value` is the model this run benchmarks; the other is under `models`."""
     import numpy as np
     from oracle import detector as od
     from usip_amd import synth
     from usip_amd.networks import detector_param_shapes
     # ATen's strided reductions oversubscribe badly on a many-core host (62 s/step with 256
-    # threads vs ~5 s with 8-16): use at most 16 threads and report that count.
-    cores = min(os.cpu_count() or 1, 16)
+    # threads vs ~5 s with 8-16): use at most 16 threads and report that count next to the host's.
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
     torch.set_num_threads(cores)
-    shapes = detector_param_shapes(model, 4)
-    filled = synth.fill_parameters(shapes)
-    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
-         if not ("running_" in k or "num_batches" in k)}
-    bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
     batch = {k: torch.from_numpy(v) for k, v in
              synth.make_pair_batch(99, 1, args.n, args.m, 4, args.cloud).items()}
-    times = []
-    for i in range(3):
-        for p in P.values():
-            p.grad = None
-        t0 = time.perf_counter()
-        od.detector_step(P, bufs, batch, model, 16, 1e-3, 0.01)
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
-    return dict(value=2.0 / t, unit="point-clouds/s", cores=cores, kind="port",
-                sample="1 pair (2 clouds) N=%d M=%d model=%s, oracle/detector.py fwd+losses+bwd, "
-                       "median of 2 after 1 warm-up (%.2f s/step)" % (args.n, args.m, model, t))
+    res = {}
+    for mdl in ("ball", "som"):
+        filled = synth.fill_parameters(detector_param_shapes(mdl, 4))
+        P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
+             if not ("running_" in k or "num_batches" in k)}
+        bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
+        times = []
+        for i in range(3 + 5):
+            for p in P.values():
+                p.grad = None
+            t0 = time.perf_counter()
+            od.detector_step(P, bufs, batch, mdl, 16, 1e-3, 0.01)
+            times.append(time.perf_counter() - t0)
+        t = sorted(times[3:])
+        res[mdl] = dict(value=2.0 / t[len(t) // 2], s_per_step=round(t[len(t) // 2], 3), p10=round(t[0], 3),
+                        p90=round(t[-1], 3))
+    me = model if model in res else "ball"
+    return dict(value=res[me]["value"], unit="point-clouds/s", cores=cores, host_cores=host_cores, kind="port",
+                thread_cap="16 (ATen's strided reductions slow down beyond that: 62 s/step at 256 threads vs ~6 s)",
+                models={"RPN_Detector_Ball": res["ball"], "RPN_Detector": res["som"]},
+                sample="1 pair (2 clouds) N=%d M=%d, oracle/detector.py fwd+losses+bwd, median of 5 after 3 warm-up; "
+                       "value = %s (%.2f s/step)" % (args.n, args.m, {"ball": "RPN_Detector_Ball", "som": "RPN_Detector"}[me],
+                                                     res[me]["s_per_step"]))
 
 
 def main():
@@ -97,8 +192,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not args.graph:
-        args.no_graph = True
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     # One process per GPU over RCCL ("nccl" IS RCCL on ROCm).  USIP_DIST_BACKEND=gloo + USIP_SHARE_DEVICE=1 is a
@@ -106,6 +199,18 @@ def main():
     backend = os.environ.get("USIP_DIST_BACKEND", "nccl")
     if os.environ.get("USIP_SHARE_DEVICE") == "1":
         local_rank = 0
+    if world > 1 and hasattr(os, "sched_setaffinity"):
+        # one disjoint core set per rank: eight launch threads (+ RCCL's proxy threads) on one host otherwise
+        # migrate across each other's caches; harmless if the container restricts the set already
+        try:
+            cores = sorted(os.sched_getaffinity(0))
+            per = max(1, len(cores) // world)
+            lr = int(os.environ.get("LOCAL_RANK", "0"))
+            mine = cores[lr * per:(lr + 1) * per]
+            if len(mine) >= 2:
+                os.sched_setaffinity(0, mine)
+        except OSError:
+            pass
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -116,6 +221,9 @@ def main():
 
     from usip_amd import ops, prof, synth
     from usip_amd.networks import DetectorOptions
+    if args.only_kernels:
+        print(json.dumps({"kernels": kernel_leg(dev, load_traffic_db(args.precision)[0])}), flush=True)
+        return
     ops.set_matmul_mode(args.precision)
     mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
     from usip_amd.step import DetectorStep, batch_to_device
@@ -148,7 +256,7 @@ def main():
             st.step(batch)
         batch = st.static_batch(batch) or batch              # feed the captured input buffers directly
 
-    graphed = not args.no_graph
+    graphed = (not args.no_graph) and st.use_graph          # False when the capture was refused (eager fallback)
 
     def barrier():
         if world > 1:
@@ -250,19 +358,7 @@ def main():
             out["step_ms_rank0"] = {"p10": round(pick(0.1), 4), "median": round(pick(0.5), 4), "p90": round(pick(0.9), 4),
                                     "max": round(per_step[-1], 4), "first": round(raw_steps[0], 4)}
         if not args.no_kernel_timing:
-            # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/profile_roofline.sh:
-            # separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per
-            # MI355X_MICROARCH.md).  Keyed by kernel template + workgroup count; a key shared by several
-            # layer shapes carries their average.
-            traffic_db, traffic_src = {}, None
-            import glob
-            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
-                if ("bf16" in os.path.basename(f)) != (args.precision == "bf16"):
-                    continue                               # each precision mode has its own kernels and PMC passes
-                try:
-                    traffic_db, traffic_src = json.load(open(f)), os.path.basename(f)
-                except (OSError, ValueError):
-                    pass
+            traffic_db, traffic_src = load_traffic_db(args.precision)
             kernels = []
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
@@ -321,6 +417,12 @@ def main():
                 if light:
                     out["kernels_note"] = ("shared_mlp_* rows: HIP events inside the timed region (one eager step); the "
                                            "other rows: one instrumented eager step run after the timed region")
+        if world == 1 and not args.no_kernel_leg and not args.no_kernel_timing and args.model != "descriptor":
+            del st, batch
+            torch.cuda.empty_cache()
+            out.setdefault("kernels", []).extend(kernel_leg(dev, load_traffic_db(args.precision)[0]))
+            out["kernels_note"] = (out.get("kernels_note", "") + "; rows with calls_per_step 0: stand-alone roofline leg "
+                                   "after the timed region (see their note)").lstrip("; ")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.model)
         print(json.dumps(out), flush=True)

@@ -31,6 +31,14 @@ extern "C" {
 /* Library identification: "usip_hip <version> gfx950". */
 const char* usip_version(void);
 
+/* Launch-geometry knobs for measurement sweeps (tools/): they change HOW a result is computed (rows per
+ * workgroup, prefetch depth, tile order), never the result.  0 restores the library's heuristic.  No reference
+ * counterpart.  Returns USIP_EINVAL for an unknown name. */
+enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_WGRAD_XCD, USIP_TUNE_NARROW_BWD,
+       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_COUNT };
+int usip_set_tuning(const char* name, int value);
+int usip_tuning_value(int knob);
+
 /* ------------------------------------------------------------------ a-1  index_max
  * Replaces index_max.forward_cuda / forward_cuda_shared_mem
  * (models/index_max_ext/index_max.cpp:132-148 -> index_max_cuda.cu:9-25, :29-61, :65-98).

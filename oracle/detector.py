@@ -102,7 +102,16 @@ def som_cluster(x: torch.Tensor, min_idx: torch.Tensor, count: torch.Tensor):
 
 
 # --------------------------------------------------------------------------- KNN fusion + head
-def knn_fusion(P: Params, bufs, prefix: str, query, database, x, K: int, train: bool):
+def _max_over_k(h: torch.Tensor, keepdim: bool, pools: Optional[list]):
+    """torch.max(h, dim=3) as the reference calls it (networks.py:706,710, layers.py:433,438).  `pools`
+    (optional list) receives the arg-max tensor [B,C,M]: the position autograd routes the gradient to."""
+    pooled, arg = torch.max(h, dim=3, keepdim=keepdim)
+    if pools is not None:
+        pools.append(arg.reshape(arg.shape[0], arg.shape[1], arg.shape[2]).detach())
+    return pooled
+
+
+def knn_fusion(P: Params, bufs, prefix: str, query, database, x, K: int, train: bool, pools: Optional[list] = None):
     """GeneralKNNFusionModule.forward (layers.py:401-440). Returns (feature [B,512,M], knn_I)."""
     q = query.detach()
     d = database.detach()
@@ -116,13 +125,13 @@ def knn_fusion(P: Params, bufs, prefix: str, query, database, x, K: int, train: 
     while "%s.layers_before.%d.conv.weight" % (prefix, i) in P:
         h = shared_mlp(h, P, bufs, "%s.layers_before.%d" % (prefix, i), train)
         i += 1
-    pooled, _ = torch.max(h, dim=3, keepdim=True)
+    pooled = _max_over_k(h, True, pools)
     y = torch.cat((pooled.expand_as(h), h), dim=1)
     i = 0
     while "%s.layers_after.%d.conv.weight" % (prefix, i) in P:
         y = shared_mlp(y, P, bufs, "%s.layers_after.%d" % (prefix, i), train)
         i += 1
-    out, _ = torch.max(y, dim=3, keepdim=False)
+    out = _max_over_k(y, False, pools)
     return out, knn_I
 
 
@@ -162,12 +171,13 @@ def rpn_detector_forward(P: Params, bufs, x, sn, node, node_knn_k: int,
     second = h
     second_idx = index_max_op(second, min_idx.int(), M).long()
     second_max = second.gather(2, second_idx) * has_pts
+    pools = []
     knn_feat, knn_I = knn_fusion(P, bufs, "knnlayer_1", cluster_mean, cluster_mean, second_max,
-                                 node_knn_k, train)
+                                 node_knn_k, train, pools)
     agg = torch.cat((second_max, knn_feat), dim=1)
     keypoints, sigmas = head(P, bufs, agg, cluster_mean, sigma_lower_bound, train)
     return dict(node=cluster_mean, keypoints=keypoints, sigmas=sigmas, min_idx=min_idx,
-                first_idx=first_idx, second_idx=second_idx, knn_I=knn_I)
+                first_idx=first_idx, second_idx=second_idx, knn_I=knn_I, pool_args=pools)
 
 
 def rpn_detector_ball_forward(P: Params, bufs, x, sn, node, node_knn_k: int,
@@ -183,15 +193,16 @@ def rpn_detector_ball_forward(P: Params, bufs, x, sn, node, node_knn_k: int,
     h = g
     for name in ("conv1", "conv2", "conv3"):
         h = shared_mlp(h, P, bufs, name, train)
-    pooled, _ = torch.max(h, dim=3, keepdim=True)
+    pools = []
+    pooled = _max_over_k(h, True, pools)
     h = torch.cat((h, pooled.expand_as(h)), dim=1)          # note order: (features, max) :708
     for name in ("conv4", "conv5"):
         h = shared_mlp(h, P, bufs, name, train)
-    second_max, _ = torch.max(h, dim=3, keepdim=False)
-    knn_feat, knn_I = knn_fusion(P, bufs, "knnlayer_1", node, node, second_max, node_knn_k, train)
+    second_max = _max_over_k(h, False, pools)
+    knn_feat, knn_I = knn_fusion(P, bufs, "knnlayer_1", node, node, second_max, node_knn_k, train, pools)
     agg = torch.cat((second_max, knn_feat), dim=1)
     keypoints, sigmas = head(P, bufs, agg, node, sigma_lower_bound, train)
-    return dict(node=node, keypoints=keypoints, sigmas=sigmas, ball_idx=ball_idx, knn_I=knn_I)
+    return dict(node=node, keypoints=keypoints, sigmas=sigmas, ball_idx=ball_idx, knn_I=knn_I, pool_args=pools)
 
 
 # --------------------------------------------------------------------------- losses
@@ -298,4 +309,4 @@ def descriptor_step(P: Params, bufs, batch, perm, radius=2, K=64, gamma=0.5, sig
 
 def to_numpy(d):
     return {k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
-            for k, v in d.items() if v is not None}
+            for k, v in d.items() if v is not None and not isinstance(v, list)}

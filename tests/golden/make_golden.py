@@ -71,6 +71,12 @@ class Opt:
 
 def save(name, **arrays):
     path = os.path.join(HERE, name)
+    if os.path.exists(path) and "--allow-changes" not in sys.argv:
+        # regenerating must not move what earlier rounds pinned: every key already in the fixture stays bit-equal
+        old = np.load(path, allow_pickle=False)
+        for k in old.files:
+            new = np.asarray(arrays[k])
+            assert k in arrays and np.array_equal(old[k], new, equal_nan=new.dtype.kind == "f"), (name, k)
     np.savez_compressed(path, **arrays)
     print("%-34s %8.1f KB" % (name, os.path.getsize(path) / 1024))
 
@@ -207,13 +213,16 @@ def load_filled(module, head_std=0.05):
 
 
 def grad_digest(module):
-    """Per-parameter gradient digests: first 48 flat entries, L2 norm, sum."""
+    """Per-parameter gradient digests: first 48 flat entries, L2 norm, sum, and four seeded +-1 projections
+    (usip_amd.synth.grad_projections: every entry of the gradient enters each of them, so a digest of 4 numbers
+    pins the whole tensor without storing 1.2 M floats per fixture)."""
     d = {}
     for k, p in module.named_parameters():
         g = p.grad.detach().numpy().ravel()
         d["grad_head/" + k] = g[:48].copy()
         d["grad_norm/" + k] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
         d["grad_sum/" + k] = np.float64(g.astype(np.float64).sum())
+        d["grad_proj/" + k] = synth.grad_projections(k, g)
     return d
 
 
@@ -261,6 +270,42 @@ def gen_layers(layers):
                knn_gf=f.grad.numpy(), knn_gw0=knn.layers_before[0].conv.weight.grad.numpy(),
                knn_gw_after0=knn.layers_after[0].conv.weight.grad.numpy())
     save("layers_cases.npz", **out)
+
+
+def gen_bn_decay(layers):
+    """a-13: epoch-driven BatchNorm momentum (layers.py:61-71, :112-121): momentum = momentum0 *
+    decay ** (epoch // step) once epoch >= 1, clamped below at 0.01.  Two training forwards per epoch value
+    through MyConv2d and EquivariantLayer with decay_step=2, decay=0.6; the fixture holds the momentum the
+    reference module ends up with and its running statistics after every call."""
+    rng = np.random.default_rng(1313)
+    out = {}
+    x2 = rng.normal(0.3, 1.2, (2, 3, 5, 7, 4)).astype(np.float32)        # [call, B, C, M, K]
+    x1 = rng.normal(-0.2, 0.8, (2, 3, 6, 33)).astype(np.float32)         # [call, B, C, N]
+    epochs = [None, 0, 1, 2, 5, 9, 40]
+    out.update(x2=x2, x1=x1, epochs=np.asarray([-1 if e is None else e for e in epochs], dtype=np.int32))
+    for e in epochs:
+        tag = "none" if e is None else str(e)
+        conv = layers.MyConv2d(5, 8, kernel_size=(1, 1), stride=1, padding=0, bias=True, activation="relu",
+                               normalization="batch", momentum=0.1, bn_momentum_decay_step=2, bn_momentum_decay=0.6)
+        eq = layers.EquivariantLayer(6, 10, activation="relu", normalization="batch", momentum=0.1,
+                                     bn_momentum_decay_step=2, bn_momentum_decay=0.6)
+        load_filled(conv)
+        load_filled(eq)
+        conv.train()
+        eq.train()
+        for call in range(2):
+            y2 = conv(torch.from_numpy(x2[call]), e)
+            y1 = eq(torch.from_numpy(x1[call]), e)
+            out["conv_rm_%s_%d" % (tag, call)] = conv.norm.running_mean.numpy().copy()
+            out["conv_rv_%s_%d" % (tag, call)] = conv.norm.running_var.numpy().copy()
+            out["eq_rm_%s_%d" % (tag, call)] = eq.norm.running_mean.numpy().copy()
+            out["eq_rv_%s_%d" % (tag, call)] = eq.norm.running_var.numpy().copy()
+        out["conv_y_%s" % tag] = y2.detach().numpy()
+        out["eq_y_%s" % tag] = y1.detach().numpy()
+        out["momentum_%s" % tag] = np.float64(conv.norm.momentum)
+        assert conv.norm.momentum == eq.norm.momentum
+    assert out["momentum_40"] == 0.01 and out["momentum_none"] == 0.1 and out["momentum_1"] == 0.1
+    save("bn_decay_cases.npz", **out)
 
 
 def gen_losses(losses):
@@ -343,12 +388,25 @@ def capture_indices(networks_mod, som_mod):
         if kw.get("sorted", True) and kw.get("largest", True) is False:
             rec["knn_I"] = r[1].numpy().astype(np.int32).copy()
         return r
+
+    orig_max = torch.max
+
+    def max_wrap(*a, **kw):
+        # the four max-pools over the K neighbours (networks.py:706,710, layers.py:433,438): torch.max(x4d, dim=3)
+        r = orig_max(*a, **kw)
+        if kw.get("dim") == 3 and len(a) == 1 and a[0].dim() == 4:
+            arg = r[1].reshape(a[0].shape[0], a[0].shape[1], a[0].shape[2])
+            assert a[0].shape[3] <= 127
+            rec["pool_arg_%d" % sum(k.startswith("pool_arg_") for k in rec)] = arg.numpy().astype(np.int8).copy()
+        return r
     im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem = im_wrap, bq_wrap
     torch.topk = topk_wrap
+    torch.max = max_wrap
 
     def restore():
         im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem = orig_im, orig_bq
         torch.topk = orig_topk
+        torch.max = orig_max
     return rec, restore
 
 
@@ -507,10 +565,17 @@ if __name__ == "__main__":
     if "--only-descriptor" in sys.argv:
         gen_descriptor(networks, losses)
         sys.exit(0)
+    if "--only-detectors" in sys.argv:
+        gen_detectors(networks, losses, som)
+        sys.exit(0)
+    if "--only-bn-decay" in sys.argv:
+        gen_bn_decay(layers)
+        sys.exit(0)
     gen_index_max(ref_im)
     gen_dist_ball()
     gen_som(som)
     gen_layers(layers)
+    gen_bn_decay(layers)
     gen_losses(losses)
     gen_detectors(networks, losses, som)
     gen_descriptor(networks, losses)

@@ -67,3 +67,26 @@ def test_host_entry_points_match_reference_golden(tag, threads):
     out = im.forward_cpu(d, i, K) if threads == 1 else im.forward_multi_thread_cpu(d, i, K, threads)
     assert out.dtype == torch.int32
     assert np.array_equal(out.numpy(), g[tag + "_out"])
+
+
+def test_bn_momentum_decay_rule_matches_reference():
+    """a-13 host logic: the momentum _EpochDecayBatchNorm switches to equals what the reference's MyBatchNorm1d/2d
+    end up with (models/layers.py:61-71, :112-121; fixture from the reference itself): no change for epoch None / 0,
+    momentum0 * decay ** (epoch // step) from epoch 1 on, clamped below at 0.01, and never reset afterwards."""
+    from conftest import load_golden
+    from usip_amd.layers import MyBatchNorm1d, MyBatchNorm2d
+    g = load_golden("bn_decay_cases.npz")
+    for cls in (MyBatchNorm1d, MyBatchNorm2d):
+        for e in g["epochs"]:
+            epoch = None if e < 0 else int(e)
+            bn = cls(4, momentum=0.1, momentum_decay_step=2, momentum_decay=0.6)
+            bn.decay_momentum(epoch)
+            assert bn.momentum == float(g["momentum_%s" % ("none" if e < 0 else int(e))]), (cls, e)
+            assert bn.epoch_driven == (epoch is not None)
+        bn = cls(4, momentum=0.1, momentum_decay_step=2, momentum_decay=0.6)
+        bn.decay_momentum(9)
+        bn.decay_momentum(None)                     # the reference keeps the decayed value
+        assert bn.momentum == float(g["momentum_9"])
+        bn = cls(4, momentum=0.1, momentum_decay_step=None, momentum_decay=0.6)
+        bn.decay_momentum(40)
+        assert bn.momentum == 0.1

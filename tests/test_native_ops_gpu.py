@@ -280,3 +280,76 @@ def test_multi_transpose_matches_per_tensor_transposes():
     ops.multi_transpose(src, dst, torch.tensor(rows, dtype=torch.int32, device=DEV), tiles)
     for (so, r, c, do, _), _s in zip(rows, shapes):
         assert torch.equal(dst[do:do + r * c].view(c, r), src[so:so + r * c].view(r, c).t())
+
+
+def test_knn_overflowed_and_nan_distances_are_enumerated_in_index_order():
+    """Degenerate inputs: database points so far away that the distance overflows to +inf (or is NaN) are still
+    returned -- after every finite candidate, lowest index first, no index twice -- as torch.topk's K distinct
+    indices would be; they used to come back as index 0 repeated."""
+    ops = _ops()
+    B, M, N, K = 2, 9, 70, 70
+    g = torch.Generator().manual_seed(11)
+    db = torch.randn(B, 3, N, generator=g)
+    far = [5, 17, 18, 64, 69]
+    db[:, 0, far] = 3.0e38                         # dx*dx overflows
+    db[1, 1, 33] = float("nan")
+    q = torch.randn(B, 3, M, generator=g)
+    got = ops.knn(q.to(DEV), db.to(DEV), K).cpu().numpy()
+    dist = torch.norm(q.unsqueeze(3) - db.unsqueeze(2), dim=1)
+    for b in range(B):
+        bad = sorted(far + ([33] if b == 1 else []))
+        for m in range(M):
+            row = got[b, m]
+            assert sorted(row.tolist()) == list(range(N))                      # a permutation: nothing twice
+            nfin = N - len(bad)
+            assert row[nfin:].tolist() == bad                                    # the non-finite tail, in index order
+            d = dist[b, m, torch.from_numpy(row[:nfin].astype(np.int64))]
+            assert bool((d[1:] >= d[:-1]).all()) and bool(torch.isfinite(d).all())
+
+
+def test_nms_rejects_negative_or_nan_radius():
+    """usip_nms_f32 terminates because the selected point suppresses itself at distance 0 <= radius; a negative or
+    NaN radius would spin forever on the device, so it is refused on the host."""
+    ops = _ops()
+    kp = torch.randn(1, 3, 32, device=DEV)
+    sg = torch.rand(1, 32, device=DEV)
+    for r in (-1.0, float("nan")):
+        with pytest.raises(RuntimeError):
+            ops.nms(kp, sg, r)
+    order, count = ops.nms(kp, sg, 0.0)           # radius 0: only exact duplicates are suppressed
+    assert int(count[0]) == 32
+
+
+def test_som_entry_points_validate_their_limits():
+    ops = _ops()
+    x = torch.randn(1, 3, 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.som_assign(x, torch.randn(1, 3, 6000, device=DEV))       # node table would not fit 64 KiB of LDS
+    with pytest.raises(RuntimeError):
+        ops.som_cluster(x, torch.zeros(1, 63, dtype=torch.int32, device=DEV), 8)
+
+
+def test_index_max_launch_geometries_agree():
+    """Channel rows per workgroup (1..8) and prefetch depth (1, 2, 4) are speed knobs: every geometry must give
+    the bit-identical result, ragged N (not a multiple of the 1024*U step) and ties included."""
+    ops = _ops()
+    from usip_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    try:
+        for (B, C, N, K, ties) in [(2, 64, 16384, 512, False), (3, 8, 5000, 37, True), (1, 16, 1028, 5, True)]:
+            data = torch.randn(B, C, N, generator=g)
+            if ties:
+                data = torch.round(data * 2) / 2
+            idx = torch.randint(0, K, (B, N), generator=g, dtype=torch.int32)
+            want = native.index_max(data.numpy(), idx.numpy(), K)
+            for ch in (1, 2, 4, 8):
+                for u in (1, 2, 4):
+                    lib.usip_set_tuning(b"index_max_ch", ch)
+                    lib.usip_set_tuning(b"index_max_unroll", u)
+                    got = ops.index_max(data.to(DEV), idx.to(DEV), K).cpu().numpy()
+                    assert np.array_equal(got, want), (B, C, N, K, ch, u)
+    finally:
+        lib.usip_set_tuning(b"index_max_ch", 0)
+        lib.usip_set_tuning(b"index_max_unroll", 0)
+    assert lib.usip_set_tuning(b"no_such_knob", 1) != 0

@@ -123,6 +123,12 @@ def test_detector_step_oracle_matches_reference(fix):
     if "idx/ball_idx" in g:
         assert np.array_equal(res["ball_idx"].numpy(), g["idx/ball_idx"])
     assert np.array_equal(res["knn_I"].numpy(), g["idx/knn_I"])
+    # the arg-max of every max-pool over K (the position the gradient is routed to), as the reference's own
+    # torch.max returned it
+    n_pools = sum(k.startswith("idx/pool_arg_") for k in g)
+    assert n_pools == len(res["pool_args"]) == (4 if "idx/ball_idx" in g else 2)
+    for i, arg in enumerate(res["pool_args"]):
+        assert np.array_equal(arg.numpy(), g["idx/pool_arg_%d" % i].astype(np.int64)), i
     # floats: 1e-5 relative
     for k in ("node", "keypoints", "sigmas", "loss", "loss_chamfer", "chamfer_pure", "chamfer_weighted",
               "loss_on_pc_src", "loss_on_pc_dst"):
@@ -139,6 +145,10 @@ def test_detector_step_oracle_matches_reference(fix):
         scale = max(np.abs(gr).max(), 1e-30)
         err = np.abs(gr[:48] - g["grad_head/" + k].astype(np.float64)).max() / scale
         assert err <= 2e-5, (k, err)
+        # four +-1 projections of the WHOLE gradient (normalised by sqrt(len): an entry-wise error e shows up as ~e)
+        from usip_amd import synth
+        proj = synth.grad_projections(k, gr)
+        assert np.abs(proj - g["grad_proj/" + k]).max() <= 2e-5 * scale, (k, proj, g["grad_proj/" + k])
     for k, v in bufs.items():
         assert_close(v.numpy(), g["buf/" + k], name=k)
 

@@ -15,5 +15,10 @@ CMD="python $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-ti
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- $CMD > "$OUT/write.log" 2>&1
+# the stand-alone leg of the two HBM-bound integer kernels (dist-in ball_query, index_max): same three passes
+KCMD="python $ROOT/bench.py --only-kernels"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o ktrace -- $KCMD > "$OUT/ktrace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o kfetch -- $KCMD > "$OUT/kfetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o kwrite -- $KCMD > "$OUT/kwrite.log" 2>&1
 find "$OUT" -name "*.csv" | head -20
 python "$ROOT/tools/pmc_summary.py" "$OUT" "$OUT/summary_$TAG.txt" "$OUT/traffic_$TAG.json"

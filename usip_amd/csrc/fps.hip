@@ -131,6 +131,7 @@ extern "C" int usip_nms_f32(const float* keypoints, const float* sigmas, float r
                             int32_t* count, int B, int M, void* stream)
 {
     if (B < 0 || M < 1 || M > 1024) return USIP_EINVAL;
+    if (!(radius >= 0.0f)) return USIP_EINVAL;        // negative or NaN: the selected point would never suppress itself
     if (B == 0) return USIP_OK;
     if (!keypoints || !sigmas || !order || !count) return USIP_EINVAL;
     USIP_LAUNCH(nms_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, keypoints, sigmas, radius, order, count, M);

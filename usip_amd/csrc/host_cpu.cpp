@@ -48,4 +48,20 @@ extern "C" int usip_index_max_f32_cpu(const float* data, const int32_t* index, i
     return USIP_OK;
 }
 
-extern "C" const char* usip_version(void) { return "usip_hip 0.1 gfx950"; }
+extern "C" const char* usip_version(void) { return "usip_hip 0.2 gfx950"; }
+
+// Launch-geometry knobs (speed only, never results): 0 = the library's own heuristic.  tools/ sweeps set them to
+// measure alternatives on the GPU; the product never does.
+#include <string.h>
+static int g_tuning[USIP_TUNE_COUNT];
+static const char* const g_tuning_names[USIP_TUNE_COUNT] = {
+    "index_max_ch", "index_max_unroll", "wgrad_xcd", "narrow_bwd", "gemm_split3",
+};
+extern "C" int usip_tuning_value(int knob) { return (knob >= 0 && knob < USIP_TUNE_COUNT) ? g_tuning[knob] : 0; }
+extern "C" int usip_set_tuning(const char* name, int value)
+{
+    if (!name) return USIP_EINVAL;
+    for (int i = 0; i < USIP_TUNE_COUNT; ++i)
+        if (strcmp(name, g_tuning_names[i]) == 0) { g_tuning[i] = value; return USIP_OK; }
+    return USIP_EINVAL;
+}

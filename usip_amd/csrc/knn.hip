@@ -26,11 +26,13 @@ __global__ __launch_bounds__(256) void knn_kernel(
     const float* db = database + (long long)b * 3 * N;
     const float qx = qb[m], qy = qb[M + m], qz = qb[2 * M + m];
     float d[CPL];
+    unsigned taken = 0;                                               // bit i: candidate slot i is out of the race
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
         const int j = i * 64 + lane;
         d[i] = (j < N) ? usip_dist(qx, qy, qz, db[j], db[N + j], db[2 * N + j]) : __builtin_inff();
-        if (!(d[i] == d[i])) d[i] = __builtin_inff();                 // NaN never selected
+        if (!(d[i] == d[i])) d[i] = __builtin_inff();                 // NaN sorts last, like an overflowed distance
+        if (j >= N) taken |= 1u << i;
     }
     int32_t* o = out + ((long long)b * M + m) * K;
     for (int k = 0; k < K; ++k) {
@@ -39,7 +41,9 @@ __global__ __launch_bounds__(256) void knn_kernel(
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int j = i * 64 + lane;
-            if (d[i] < best) { best = d[i]; bj = j; }                 // ascending i: lowest index on ties
+            // ascending i: lowest index on ties; an infinite distance is still a candidate (it is selected, in
+            // index order, once the finite ones are gone -- torch.topk returns distinct indices there too)
+            if (!((taken >> i) & 1u) && (bj == 0x7fffffff || d[i] < best)) { best = d[i]; bj = j; }
         }
         float wbest = best;
         int wj = bj;
@@ -49,14 +53,8 @@ __global__ __launch_bounds__(256) void knn_kernel(
             const int oj = __shfl_xor(wj, off);
             if (ov < wbest || (ov == wbest && oj < wj)) { wbest = ov; wj = oj; }
         }
-        if (wj == 0x7fffffff) wj = 0;                                 // fewer than K finite candidates
-        if (lane == 0) o[k] = wj;
-        if ((wj & 63) == lane) {
-            const int slot = wj >> 6;
-#pragma unroll
-            for (int i = 0; i < CPL; ++i)
-                if (i == slot) d[i] = __builtin_inff();
-        }
+        if (lane == 0) o[k] = (wj == 0x7fffffff) ? 0 : wj;            // unreachable for K <= N
+        if (wj != 0x7fffffff && (wj & 63) == lane) taken |= 1u << (wj >> 6);
     }
 }
 

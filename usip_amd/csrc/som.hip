@@ -118,7 +118,9 @@ extern "C" int usip_som_assign_f32(const float* x, const float* node, int32_t* m
 {
     if (B < 0 || N < 0 || M < 1) return USIP_EINVAL;
     if ((long long)B * N == 0) return USIP_OK;
-    if (!x || !node || !min_idx || B > 65535 || M > 12288) return USIP_EINVAL;   // 3*M*4 B LDS
+    // the node table lives in dynamic LDS: 3*M*4 B within the 64 KiB a launch gets without raising the kernel's
+    // MaxDynamicSharedMemorySize attribute (node counts on the path are 64..512)
+    if (!x || !node || !min_idx || B > 65535 || M > 5461) return USIP_EINVAL;
     dim3 grid(usip_ceil_div(N, 256), B), block(256);
     USIP_LAUNCH(som_assign_kernel, grid, block, (size_t)3 * M * sizeof(float), (hipStream_t)stream,
                        x, node, min_idx, N, M);

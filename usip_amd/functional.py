@@ -28,6 +28,27 @@ DEFER_BN_COUNTERS = False
 WT_CACHE = None
 
 
+# Test hook (tests/test_modules_gpu.py, whole-step gradient parity): when set to a list of int32 device tensors
+# [B,C,M], the max-pools over K of the step take their ROUTING from it, in call order, instead of from their own
+# arg-max: pooled = activation at the given position, gradient to the given position.  A rounding-level
+# difference between two correct forwards can flip a near-tie of a max-pool and move a handful of gradient
+# entries by O(1e-2); with the routing pinned to the reference's, gradients can be compared at 1e-5.
+PIN_POOL_ARGS = None
+
+
+def _pooled_act(y4, coef, relu):
+    """(max over K of the lazily activated y4 [B,C,M,K], arg-max i32 [B,C,M]); coef None: y4 is already activated."""
+    pooled, arg = ops.group_max_act(y4, coef, relu) if coef is not None else ops.group_max(y4)
+    if PIN_POOL_ARGS is not None:
+        arg = PIN_POOL_ARGS.pop(0).to(device=y4.device, dtype=torch.int32).contiguous()
+        if tuple(arg.shape) != tuple(y4.shape[:3]):
+            raise RuntimeError("PIN_POOL_ARGS: routing %s does not fit a pool over %s" % (tuple(arg.shape), tuple(y4.shape)))
+        B, C, M, K = y4.shape
+        act = ops.bn_apply(y4.view(B, C, M * K), coef, relu).view(B, C, M, K) if coef is not None else y4
+        pooled = act.gather(3, arg.long().unsqueeze(3)).squeeze(3).contiguous()
+    return pooled, arg
+
+
 def _kmajor(w2):
     """[Cin, Cout] copy of the weight matrix w2 [Cout, Cin]."""
     cached = WT_CACHE.get(w2.data_ptr()) if WT_CACHE is not None else None
@@ -35,6 +56,10 @@ def _kmajor(w2):
 
 
 def _sink(*params):
+    """The .grad storages the backward kernels of one layer will OVERWRITE (not accumulate into), or None when
+    the sink is off.  Overwriting is only right when a parameter is used once per step: a second use in the same
+    step (weight sharing, gradient accumulation over micro-batches) would silently drop the first contribution,
+    so it raises instead.  FlatGradBucket.zero() starts a new step."""
     if not GRAD_SINK:
         return None
     out = []
@@ -43,6 +68,12 @@ def _sink(*params):
         if p is not None and (g is None or not g.is_contiguous()):
             return None
         out.append(g)
+    for p in params:
+        if p is not None:
+            if getattr(p, "_usip_sink_used", False):
+                raise RuntimeError("usip_amd: a parameter is used twice in one step while the gradient sink is on "
+                                   "(its backward overwrites .grad); run this step without DetectorStep's sink")
+            p._usip_sink_used = True
     return tuple(out)
 
 
@@ -298,7 +329,7 @@ class _SharedMLPLayerMax(torch.autograd.Function):
         y, stats = ops.mlp_gemm(_kmajor(w2), x3, bias, want_stats=True,
                                 pro=0 if xcoef is None else 1, coef=xcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum, running_mean, running_var)
-        pooled, arg = ops.group_max_act(y.view(B, Cout, M, K), coef, True)
+        pooled, arg = _pooled_act(y.view(B, Cout, M, K), coef, True)
         ctx.save_for_backward(x3, xcoef, w2, y, coef, mean, invstd, gamma, arg)
         ctx.dims, ctx.sink, ctx.x_shape = (B, Cin, Cout, M, K), sink, tuple(x.shape)
         return pooled
@@ -490,7 +521,7 @@ class _GroupMax(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z):
-        pooled, arg = ops.group_max(z.contiguous())
+        pooled, arg = _pooled_act(z.contiguous(), None, False)
         ctx.save_for_backward(arg)
         ctx.K = z.shape[3]
         return pooled
@@ -506,7 +537,7 @@ class _GroupMaxAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y4, coef, relu):
-        pooled, arg = ops.group_max_act(y4.contiguous(), coef, relu)
+        pooled, arg = _pooled_act(y4.contiguous(), coef, relu)
         ctx.save_for_backward(arg)
         ctx.K = y4.shape[3]
         return pooled
@@ -525,7 +556,7 @@ class _GroupMaxActFork(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y4, coef, relu):
-        pooled, arg = ops.group_max_act(y4.contiguous(), coef, relu)
+        pooled, arg = _pooled_act(y4.contiguous(), coef, relu)
         ctx.save_for_backward(arg)
         ctx.K = y4.shape[3]
         ctx.set_materialize_grads(False)
@@ -538,9 +569,11 @@ class _GroupMaxActFork(torch.autograd.Function):
             return dy, None, None
         if dy is None:
             return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K), None, None
-        # dy is the data gradient the consuming layer just produced for this node alone (contiguous() copies
-        # anything autograd may have expanded), so it can be updated in place
-        return ops.group_max_backward_add_(dy.contiguous(), dpooled.contiguous(), arg), None, None
+        # Inside the training step (GRAD_SINK: no hooks, no retained graph, one consumer) dy is the data gradient the
+        # consuming layer just produced for this node alone, so it is updated in place; anywhere else autograd may
+        # share that buffer (retain_grad, hooks, a second consumer), so the sum goes into a private copy
+        dy = dy.contiguous() if GRAD_SINK else dy.clone(memory_format=torch.contiguous_format)
+        return ops.group_max_backward_add_(dy, dpooled.contiguous(), arg), None, None
 
 
 def group_max_fork(z):

@@ -28,17 +28,27 @@ class _EpochDecayBatchNorm(_BatchNorm):
         self.momentum_decay_step = momentum_decay_step
         self.momentum_decay = momentum_decay
         self.momentum_original = self.momentum
+        self.epoch_driven = False
 
     def _check_input_dim(self, input):
         if input.dim() not in self._dims:
             raise ValueError("expected %s input (got %dD input)" %
                              (" or ".join("%dD" % d for d in self._dims), input.dim()))
 
-    def decay_momentum(self, epoch):
+    def momentum_for(self, epoch):
+        """The momentum a forward at `epoch` switches to, or None when the rule does not apply (the module then
+        keeps whatever momentum it has -- the reference never resets it, layers.py:61-66)."""
         if epoch is not None and epoch >= 1 and self.momentum_decay_step is not None \
                 and self.momentum_decay_step > 0:
-            self.momentum = max(0.01, self.momentum_original *
-                                self.momentum_decay ** (epoch // self.momentum_decay_step))
+            return max(0.01, self.momentum_original * self.momentum_decay ** (epoch // self.momentum_decay_step))
+        return None
+
+    def decay_momentum(self, epoch):
+        if epoch is not None:
+            self.epoch_driven = True          # this module is handed the epoch by its caller (not all are)
+        m = self.momentum_for(epoch)
+        if m is not None:
+            self.momentum = m
 
     def forward(self, input, epoch=None):
         self._check_input_dim(input)

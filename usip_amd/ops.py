@@ -49,6 +49,25 @@ def index_max(data: torch.Tensor, index: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
+def index_max_geometry(B: int, C: int, N: int, K: int):
+    """(channel rows per workgroup, prefetch depth) usip_index_max_f32 picks for this shape (csrc/index_max.hip);
+    lets a profiler name the launch."""
+    rows, ch = B * C, 1
+    for cand in (8, 4, 2):
+        if C % cand == 0 and rows // cand >= 512 and cand * K * 8 <= 65536:
+            ch = cand
+            break
+    u = (4 if ch <= 4 else 2) if N >= 4096 else 1
+    tch = _lib.lib().usip_tuning_value(0)
+    tu = _lib.lib().usip_tuning_value(1)
+    if tch > 0 and C % tch == 0 and tch * K * 8 <= 65536:
+        ch = tch
+    if tu > 0:
+        u = tu
+    u = 4 if (u >= 4 and ch <= 4) else (2 if u >= 2 else 1)
+    return ch, u
+
+
 def ball_query(dist: torch.Tensor, radius: float, K: int) -> torch.Tensor:
     """a-2: dist f32 [B,M,N] -> i32 [B,M,K] (ball_query_cuda.cu:53-70)."""
     K = int(K)
@@ -119,6 +138,8 @@ def som_cluster(x: torch.Tensor, min_idx: torch.Tensor, M: int, decenter: bool =
     _need_pts(x, "x")
     _need(min_idx, "min_idx", torch.int32)
     B, _, N = x.shape
+    if tuple(min_idx.shape) != (B, N):
+        raise RuntimeError("som_cluster: min_idx must be [B,N] = %s (got %s)" % ((B, N), tuple(min_idx.shape)))
     mean = torch.empty((B, 3, int(M)), dtype=torch.float32, device=x.device)
     count = torch.empty((B, int(M)), dtype=torch.int32, device=x.device)
     dec = torch.empty_like(x) if decenter else None

@@ -9,6 +9,7 @@ Sharding: every (src, dst) pair is independent in forward, losses an
 BatchNorm statistics are per replica in the reference (nn.DataParallel, no SyncBN) and stay
 per rank here.  Rank r owns pairs [r*B/W, (r+1)*B/W); the only exchange is the gradient sum.
 """
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -50,6 +51,8 @@ class FlatGradBucket:
 
     def zero(self):
         self.flat.zero_()
+        for p in self.params:                                 # a new step: every parameter may be written once again
+            p._usip_sink_used = False
 
     def all_reduce_mean(self, group=None):
         """sum over ranks then / world: gradients of the mean-of-means loss (equal shards)."""
@@ -70,7 +73,8 @@ class _GraphedStep:
     the captured input buffers (skipped when the caller already passes those buffers) and replays; the kernels,
     their order and their results are those of the eager step -- only the per-launch host work and the gaps
     between launches go away (detector: 9.65 -> 9.44 ms per step).  A batch of another shape, or another
-    BatchNorm momentum (epoch-dependent decay), captures a new graph."""
+    BatchNorm momentum (epoch-dependent decay), captures a new graph; the cache keeps the `max_graphs` most recently
+    used ones."""
 
     def _setup(self, module, opt, device, with_optimizer: bool, graph: bool):
         self.opt = opt
@@ -103,11 +107,14 @@ class _GraphedStep:
                 self._wt = (flat_wt, table, tiles,
                             {ptr: flat_wt[o:o + ci * co].view(ci, co) for ptr, (o, ci, co) in views.items()})
         self.last: Dict[str, torch.Tensor] = {}
-        self._graphs: Dict = {}                               # key -> (graph A, graph B or None, static batch, last, loss)
+        # key -> (graph A, graph B or None, static batch, last, loss), least recently used first.  Every entry owns
+        # a private memory pool with all activations of a step (GBs at N=16384), so the cache is bounded: a
+        # training run with epoch-decayed BatchNorm momentum or varying cloud sizes evicts instead of growing.
+        self._graphs: "OrderedDict" = OrderedDict()
+        self.max_graphs = 3
         self._eager_calls = 0
-        self._bn_counters = [m.num_batches_tracked for m in module.modules()
-                             if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
-                             and m.num_batches_tracked is not None]
+        self._bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+        self._bn_counters = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
 
     def load_numpy_state(self, state: Dict):
         sd = self.module.state_dict()
@@ -158,11 +165,29 @@ class _GraphedStep:
             self.optimizer.step()
         return loss
 
+    def _bn_momenta(self, epoch):
+        """The momentum every BatchNorm will run this step with (a kernel argument, so part of what a captured
+        graph froze): epoch-driven modules switch to their decayed value (models/layers.py:61-71), the others --
+        and all of them while the rule does not apply -- keep what they have.  The value changes once every
+        `bn_momentum_decay_step` epochs and stops at the 0.01 clamp, so keying on it (not on the epoch) re-captures
+        only when a replay would be wrong."""
+        out = []
+        for bn in self._bns:
+            m = bn.momentum
+            if getattr(bn, "epoch_driven", False):
+                nxt = bn.momentum_for(epoch)
+                if nxt is not None:
+                    m = nxt
+            out.append(None if m is None else round(float(m), 12))
+        return tuple(out)
+
     def _step_graph(self, batch, epoch, group):
         decays = getattr(self.opt, "bn_momentum_decay_step", None)
         key = (tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())),
-               epoch if (decays is not None and decays > 0) else None)
+               self._bn_momenta(epoch) if (decays is not None and decays > 0) else None)
         entry = self._graphs.get(key)
+        if entry is not None:
+            self._graphs.move_to_end(key)
         if entry is None:
             if self._eager_calls < 2:                         # allocator, rocBLAS handles, lazily built state
                 self._eager_calls += 1
@@ -188,10 +213,16 @@ class _GraphedStep:
                 self.use_graph = False
                 return self._step_eager(batch, epoch, group)
             entry = self._graphs[key] = (ga, gb, static, last, loss)   # capture launches nothing: replay below
+            while len(self._graphs) > self.max_graphs:
+                _, old = self._graphs.popitem(last=False)     # drops the graphs and, with them, their memory pool
+                del old
         ga, gb, static, last, loss = entry
         for k, v in batch.items():
             if v.data_ptr() != static[k].data_ptr():
                 static[k].copy_(v, non_blocking=True)
+        if key[1] is not None:                                # what the Python forward would have left behind
+            for bn, m in zip(self._bns, key[1]):
+                bn.momentum = m
         ga.replay()
         self.bucket.all_reduce_mean(group)
         if gb is not None:

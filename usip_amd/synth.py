@@ -102,3 +102,16 @@ def fill_parameters(named_shapes: Dict[str, tuple], head_std: float = 0.05
             v = 0.1 * n
         out[name] = v.astype(np.float32)
     return out
+
+
+def grad_projections(name: str, g: np.ndarray, count: int = 4) -> np.ndarray:
+    """`count` seeded +-1 (Rademacher) projections of a flat gradient, accumulated in float64 and divided by
+    sqrt(len): every entry of the tensor enters every projection, so a handful of numbers pins the whole
+    gradient in a fixture.  The sign vectors are a function of the parameter name only."""
+    g = np.asarray(g, dtype=np.float64).ravel()
+    rng = np.random.default_rng(zlib.crc32(("proj/" + name).encode()))
+    out = np.empty(count, dtype=np.float64)
+    for i in range(count):
+        signs = rng.integers(0, 2, g.size).astype(np.float64) * 2.0 - 1.0
+        out[i] = float(signs @ g) / math.sqrt(max(g.size, 1))
+    return out
