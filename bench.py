@@ -44,12 +44,17 @@ def parse():
                     help="ball = RPN_Detector_Ball (the K=64 headline model), som = RPN_Detector, "
                          "descriptor = DescriptorLiteOld step (BASELINE configs[4], SURVEY 8 f-1)")
     ap.add_argument("--pairs", type=int, default=8, help="pairs per GPU (B); the detector sees 2B clouds")
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--m", type=int, default=512)
+    # --points / --nodes: the same options under names torch.distributed.run cannot mistake for abbreviations of its
+    # own (--n.. / --m..) when it scans the command line
+    ap.add_argument("--n", "--points", dest="n", type=int, default=16384)
+    ap.add_argument("--m", "--nodes", dest="m", type=int, default=512)
     ap.add_argument("--cloud", default="slab")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
-                    help="f32 = fp32 MFMA (parity mode, the headline); bf16 = bf16 multiply / fp32 accumulate in the "
-                         "shared-MLP kernels, tensors stay fp32 (perf mode of BASELINE configs[1]; NOT the headline)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3", "bf16"],
+                    help="f32 = fp32 MFMA everywhere; f32x3 = fp32-ACCURATE products on the bf16 matrix cores for the "
+                         "matrix-bound layers (three bf16 planes per operand, six plane products, fp32 accumulation; "
+                         "error at the fp32 FMA chain's level, tests/test_f32x3_mode_gpu.py), fp32 MFMA for the rest; "
+                         "bf16 = bf16 multiply / fp32 accumulate, tensors stay fp32 (perf mode of BASELINE configs[1]; "
+                         "NOT a parity mode)")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every kernel from the host instead of replaying the step from HIP graphs")
     ap.add_argument("--graph", action="store_true",
@@ -139,8 +144,8 @@ def kernel_leg(dev, traffic_db, iters=12):
         idx = [torch.randint(0, M, (B, N), device=dev, dtype=torch.int32) for _ in range(n_ring)]
         alg = 4.0 * (B * C * N + B * N + B * C * M)
         t = timed(lambda i: ops.index_max(data[i], idx[i], M), n_ring)
-        ch, u = ops.index_max_geometry(B, C, N, M)
-        row("index_max (C=%d, B'=16)" % C, alg, t, "index_max_kernel<%d, %d, true> |wg=%d" % (ch, u, B * C // ch),
+        ch, u, th = ops.index_max_geometry(B, C, N, M)
+        row("index_max (C=%d, B'=16)" % C, alg, t, "index_max_kernel<%d, %d, true, %d> |wg=%d" % (ch, u, th, B * C // ch),
             "stand-alone leg, ring of %d distinct inputs (%d MB)" % (n_ring, n_ring * B * C * N * 4 // 1000000))
         del data, idx
     return rows
@@ -226,6 +231,8 @@ def main():
         return
     ops.set_matmul_mode(args.precision)
     mfma_peak = PEAK_BF16_TFLOPS if args.precision == "bf16" else PEAK_F32_TFLOPS
+    # f32x3: rows of the split kernels are priced against the bf16 matrix peak / 6 (six plane products per fp32
+    # product), rows that stayed on the fp32 kernel against the fp32 peak -- see the per-kernel `peak` fields
     from usip_amd.step import DetectorStep, batch_to_device
 
     opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=16)
@@ -334,7 +341,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16 multiply, f32 accumulate and storage (perf mode)",
+            "dtype": {"f32": "f32", "f32x3": "f32 (matrix-bound products as six bf16-plane MFMAs of an exact three-way "
+                                             "split, fp32 accumulate: fp32-accurate)",
+                      "bf16": "bf16 multiply, f32 accumulate and storage (perf mode)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("KITTI descriptor head N=%d, 256 keypoints, K=64, batch=%d pairs/GPU (BASELINE "
                                     "configs[4])" % (args.n, args.pairs)) if args.model == "descriptor" else
@@ -359,11 +368,17 @@ def main():
                                     "max": round(per_step[-1], 4), "first": round(raw_steps[0], 4)}
         if not args.no_kernel_timing:
             traffic_db, traffic_src = load_traffic_db(args.precision)
+            def is_x3(r):
+                key = r.get("rocprof_key") or ""
+                return "bf16_kernel" in key and key.split(">")[0].endswith(", 3")
+
             kernels = []
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
                 ach = r["TFLOPs"] if mfma else r["GBps"]
-                peak = mfma_peak if mfma else PEAK_HBM_GBPS
+                # a split-product launch does six bf16 matrix products per fp32 product: its ceiling in fp32-equivalent
+                # flops is the dense bf16 peak / 6
+                peak = (PEAK_BF16_TFLOPS / 6.0 if is_x3(r) else mfma_peak) if mfma else PEAK_HBM_GBPS
                 kernels.append({"kernel": name, "calls_per_step": r["calls"] / timed_steps_sampled,
                                 "avg_us": round(r["avg_us"], 2),
                                 "share_of_step": round(r["total_ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
@@ -395,7 +410,9 @@ def main():
                 top_name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
                 avg_s = top["ms"] * 1e-3 / top["calls"]
                 if top["mfma"]:
-                    ach, peak, unit, bound = top["flops"] / top["calls"] / avg_s / 1e12, mfma_peak, "TFLOP/s", "mfma"
+                    top_peak = PEAK_BF16_TFLOPS / 6.0 if (top_name.split(">")[0].endswith(", 3") and "bf16_kernel" in top_name) \
+                        else mfma_peak
+                    ach, peak, unit, bound = top["flops"] / top["calls"] / avg_s / 1e12, top_peak, "TFLOP/s", "mfma"
                 else:
                     ach, peak, unit, bound = top["nbytes"] / top["calls"] / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
                 out["roofline"] = {

@@ -35,7 +35,7 @@ const char* usip_version(void);
  * workgroup, prefetch depth, tile order), never the result.  0 restores the library's heuristic.  No reference
  * counterpart.  Returns USIP_EINVAL for an unknown name. */
 enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_WGRAD_XCD, USIP_TUNE_NARROW_BWD,
-       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_COUNT };
+       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_COUNT };
 int usip_set_tuning(const char* name, int value);
 int usip_tuning_value(int knob);
 
@@ -167,6 +167,16 @@ int usip_mlp_gemm_bf16(const float* At, int lda, const float* X, const float* X2
                        int pro, const float* bias, const float* rowbias, int rb_group,
                        const float* pool_dp, const int32_t* pool_arg, int pool_group,
                         float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
+/* Same contract with an fp32-ACCURATE product on the bf16 matrix cores ("f32x3"): each fp32 operand is split
+ * exactly into three bf16 planes and the six plane pairs of weight >= 2^-18 are accumulated in fp32 by
+ * v_mfma_f32_32x32x16_bf16 (relative error of a product <= 3 * 2^-27, below fp32's own rounding; 2.7x the
+ * fp32-MFMA rate).  Used for the launches that are matrix-bound (usip_mlp_gemm_f32x3_used(...) == 1); the others
+ * are handed to the fp32 kernel, so the entry point is a drop-in for usip_mlp_gemm_f32 everywhere. */
+int usip_mlp_gemm_f32x3(const float* At, int lda, const float* X, const float* X2, const float* coef,
+                       int pro, const float* bias, const float* rowbias, int rb_group,
+                       const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                        float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
+int usip_mlp_gemm_f32x3_used(int M, int K, int P, int nb);
 
 /* K-major copies of many weight matrices in one launch: for every t < ntensors, table[5t..5t+4] =
  * (source offset, rows, cols, destination offset, index of its first 32 x 32 tile), offsets in floats into src / dst;
@@ -227,6 +237,12 @@ int usip_mlp_wgrad_bf16(const float* G, const float* G2, const float* coef, int 
                         const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                         float* workspace, float* dW, int ldw, int coloff,
                         int M, int N, int P, int nb, void* stream);
+/* f32x3 variant (see usip_mlp_gemm_f32x3); same workspace, same deterministic fp32 reduction. */
+int usip_mlp_wgrad_f32x3(const float* G, const float* G2, const float* coef, int pro, const float* X,
+                        const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                        float* workspace, float* dW, int ldw, int coloff,
+                        int M, int N, int P, int nb, void* stream);
+int usip_mlp_wgrad_f32x3_used(int M, int N, int P, int nb);
 
 /* ------------------------------------------------------------------ a-6 / a-7 / a-12  grouping, pooling
  * out[b][coff+c][m][k] = x[b][c][idx[b][m][k]] - (c < nsub ? sub[b][c][m] : 0), written into the

@@ -365,6 +365,9 @@ def run_step(net, losses_mod, opt, batch, alpha):
     return out
 
 
+RELU_NEAR = 1e-4       # |BatchNorm output| below which a ReLU decision is stored in the fixture
+
+
 def capture_indices(networks_mod, som_mod):
     """Record the index tensors the forward computes, by wrapping the shim entry points."""
     rec = {}
@@ -399,14 +402,29 @@ def capture_indices(networks_mod, som_mod):
             assert a[0].shape[3] <= 127
             rec["pool_arg_%d" % sum(k.startswith("pool_arg_") for k in rec)] = arg.numpy().astype(np.int8).copy()
         return r
+    orig_relu = torch.nn.ReLU.forward
+
+    def relu_wrap(self, x):
+        # every ReLU of the path sits behind a BatchNorm (layers.py:167,215,301): x is O(1).  Record the decisions
+        # that another correct fp32 forward could take differently: pre-activations within 1e-4 of zero
+        # (flat index, on/off).  Everything farther from zero is unambiguous (forwards agree to ~1e-6).
+        i = sum(k.startswith("relu_near_idx_") for k in rec)
+        flat = x.detach().reshape(-1)
+        idx = torch.nonzero(flat.abs() < RELU_NEAR, as_tuple=False).reshape(-1)
+        rec["relu_near_idx_%d" % i] = idx.numpy().astype(np.int32)
+        rec["relu_near_on_%d" % i] = (flat[idx] > 0).numpy()
+        rec["relu_numel_%d" % i] = np.int64(flat.numel())
+        return orig_relu(self, x)
     im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem = im_wrap, bq_wrap
     torch.topk = topk_wrap
     torch.max = max_wrap
+    torch.nn.ReLU.forward = relu_wrap
 
     def restore():
         im.forward_cuda_shared_mem, bq.forward_cuda_shared_mem = orig_im, orig_bq
         torch.topk = orig_topk
         torch.max = orig_max
+        torch.nn.ReLU.forward = orig_relu
     return rec, restore
 
 

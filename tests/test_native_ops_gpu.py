@@ -330,7 +330,7 @@ def test_som_entry_points_validate_their_limits():
 
 
 def test_index_max_launch_geometries_agree():
-    """Channel rows per workgroup (1..8) and prefetch depth (1, 2, 4) are speed knobs: every geometry must give
+    """Channel rows per workgroup (1..8), prefetch depth (1, 2, 4) and workgroup size are speed knobs: every geometry must give
     the bit-identical result, ragged N (not a multiple of the 1024*U step) and ties included."""
     ops = _ops()
     from usip_amd import _lib
@@ -345,11 +345,14 @@ def test_index_max_launch_geometries_agree():
             want = native.index_max(data.numpy(), idx.numpy(), K)
             for ch in (1, 2, 4, 8):
                 for u in (1, 2, 4):
-                    lib.usip_set_tuning(b"index_max_ch", ch)
-                    lib.usip_set_tuning(b"index_max_unroll", u)
-                    got = ops.index_max(data.to(DEV), idx.to(DEV), K).cpu().numpy()
-                    assert np.array_equal(got, want), (B, C, N, K, ch, u)
+                    for th in (256, 512, 1024):
+                        lib.usip_set_tuning(b"index_max_ch", ch)
+                        lib.usip_set_tuning(b"index_max_unroll", u)
+                        lib.usip_set_tuning(b"index_max_threads", th)
+                        got = ops.index_max(data.to(DEV), idx.to(DEV), K).cpu().numpy()
+                        assert np.array_equal(got, want), (B, C, N, K, ch, u, th)
     finally:
         lib.usip_set_tuning(b"index_max_ch", 0)
         lib.usip_set_tuning(b"index_max_unroll", 0)
+        lib.usip_set_tuning(b"index_max_threads", 0)
     assert lib.usip_set_tuning(b"no_such_knob", 1) != 0

@@ -694,7 +694,19 @@ extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
     return nb * ((P + BN - 1) / BN);
 }
 
-static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, const float* X2,
+// mode: 0 = fp32 MFMA, 1 = bf16 multiply (perf mode), 2 = f32x3 (fp32-accurate split products on the bf16 matrix
+// cores) for the launches that are matrix-bound -- the others run the fp32 kernel, whose result is the same to
+// rounding and which is faster where the layer is HBM-bound (C <= 64) or too small to fill the chip.
+static bool x3_gemm_pays(int M, int K, int P, int nb)
+{
+    const int t = usip_tuning_value(USIP_TUNE_GEMM_SPLIT3);          // 1: never, 2: whenever the shape allows
+    if (t == 1) return false;
+    const long long tiles = (long long)nb * ((P + 127) / 128) * ((M + 127) / 128);
+    if (t == 2) return M > 64 && K >= 16;
+    return M >= 128 && K >= 128 && tiles >= 512;
+}
+
+static int mlp_gemm_impl(int mode, const float* At, int lda, const float* X, const float* X2,
                          const float* coef, int pro, const float* bias, const float* rowbias,
                          int rb_group, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                          float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream)
@@ -717,7 +729,8 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
     GemmArgs a{At, lda, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
                a_trans, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
-    if (bf16) return launch_gemm_bf16(a, pro, st);
+    if (mode == 1) return launch_gemm_bf16(a, pro, st);
+    if (mode == 2 && x3_gemm_pays(M, K, P, nb)) return launch_gemm_x3(a, pro, st);
     // K-step 16: 32 was measured slower (LDS per workgroup doubles, occupancy halves)
     // fewer than two workgroups per CU: halve the rows per wave (32 x 256 resp. 64 x 128 workgroups)
     if (M <= 64)
@@ -735,8 +748,11 @@ static int mlp_gemm_impl(bool bf16, const float* At, int lda, const float* X, co
 #define USIP_GEMM_ARGS \
     At, lda, X, X2, coef, pro, bias, rowbias, rb_group, pool_dp, pool_arg, pool_group, Y, y_rows, stats, \
         M, K, P, nb, stream
-extern "C" int usip_mlp_gemm_f32(USIP_GEMM_PARAMS) { return mlp_gemm_impl(false, USIP_GEMM_ARGS); }
-extern "C" int usip_mlp_gemm_bf16(USIP_GEMM_PARAMS) { return mlp_gemm_impl(true, USIP_GEMM_ARGS); }
+extern "C" int usip_mlp_gemm_f32(USIP_GEMM_PARAMS) { return mlp_gemm_impl(0, USIP_GEMM_ARGS); }
+extern "C" int usip_mlp_gemm_bf16(USIP_GEMM_PARAMS) { return mlp_gemm_impl(1, USIP_GEMM_ARGS); }
+extern "C" int usip_mlp_gemm_f32x3(USIP_GEMM_PARAMS) { return mlp_gemm_impl(2, USIP_GEMM_ARGS); }
+// 1 when usip_mlp_gemm_f32x3 runs this shape on the split-product kernel, 0 when it hands it to the fp32 kernel
+extern "C" int usip_mlp_gemm_f32x3_used(int M, int K, int P, int nb) { return x3_gemm_pays(M, K, P, nb) ? 1 : 0; }
 #undef USIP_GEMM_PARAMS
 #undef USIP_GEMM_ARGS
 
@@ -782,7 +798,16 @@ extern "C" int usip_mlp_wgrad_blocks(int M, int N, int P, int nb)
     return tiles * nb * segs;
 }
 
-static int mlp_wgrad_impl(bool bf16, const float* G, const float* G2, const float* coef, int pro,
+static bool x3_wgrad_pays(int M, int N, int P, int nb)
+{
+    const int t = usip_tuning_value(USIP_TUNE_GEMM_SPLIT3);
+    if (t == 1) return false;
+    if (t == 2) return M > 64 || N > 64;
+    return M >= 128 && N >= 128 && (long long)nb * P >= 32768;
+}
+extern "C" int usip_mlp_wgrad_f32x3_used(int M, int N, int P, int nb) { return x3_wgrad_pays(M, N, P, nb) ? 1 : 0; }
+
+static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float* coef, int pro,
                           const float* X, const float* xcoef, const float* pool_dp, const int32_t* pool_arg,
                           int pool_group, float* workspace, float* dW, int ldw,
                           int coloff, int M, int N, int P, int nb, void* stream)
@@ -798,6 +823,7 @@ static int mlp_wgrad_impl(bool bf16, const float* G, const float* G2, const floa
         return USIP_EINVAL;
     int seglen, segs, small, tiles;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
+    const bool bf16 = (mode == 1), x3 = (mode == 2) && !small && x3_wgrad_pays(M, N, P, nb);
     WgradArgs a{G, G2, coef, X, xcoef, pool_dp, pool_arg, pool_group, workspace, M, N, P, nb, seglen, segs};
     const bool xpro = xcoef != nullptr;
     const bool vec = (P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
@@ -811,8 +837,12 @@ static int mlp_wgrad_impl(bool bf16, const float* G, const float* G2, const floa
         const int rc = launch_wgrad_bf16(a, pro, xpro, vec, small, (unsigned)blocks, st);
         if (rc != USIP_OK) return rc;
     }
+    if (x3) {
+        const int rc = launch_wgrad_x3(a, pro, xpro, vec, (unsigned)blocks, st);
+        if (rc != USIP_OK) return rc;
+    }
 #define USIP_WGRAD_CASE(T_, P_, X_, V_)                                                        \
-    if (!bf16 && small == (T_ == 1) && pro == P_ && xpro == X_ && vec == V_) {                \
+    if (!bf16 && !x3 && small == (T_ == 1) && pro == P_ && xpro == X_ && vec == V_) {         \
         USIP_LAUNCH((wgrad_kernel<T_, T_, P_, X_, V_>), grid, block, 0, st, a);                \
         USIP_LAUNCH_CHECK();                                                                   \
     }
@@ -840,8 +870,9 @@ static int mlp_wgrad_impl(bool bf16, const float* G, const float* G2, const floa
         int coloff, int M, int N, int P, int nb, void *stream
 #define USIP_WGRAD_ARGS \
     G, G2, coef, pro, X, xcoef, pool_dp, pool_arg, pool_group, workspace, dW, ldw, coloff, M, N, P, nb, stream
-extern "C" int usip_mlp_wgrad_f32(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(false, USIP_WGRAD_ARGS); }
-extern "C" int usip_mlp_wgrad_bf16(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(true, USIP_WGRAD_ARGS); }
+extern "C" int usip_mlp_wgrad_f32(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(0, USIP_WGRAD_ARGS); }
+extern "C" int usip_mlp_wgrad_bf16(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(1, USIP_WGRAD_ARGS); }
+extern "C" int usip_mlp_wgrad_f32x3(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(2, USIP_WGRAD_ARGS); }
 #undef USIP_WGRAD_PARAMS
 #undef USIP_WGRAD_ARGS
 

@@ -3,8 +3,18 @@
 // rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when they are written to LDS, v_mfma_f32_32x32x16_bf16 accumulates
 // in fp32, and bias / row bias / BatchNorm statistics in the epilogue are fp32 as in shared_mlp.hip.
 //
-// This is the perf mode of BASELINE.json configs[1] ("bf16"); it is NOT the parity mode: products carry
-// 2^-9 relative rounding per operand.  Reference: models/layers.py:208-216, :293-303 under
+// NS = 1 is the perf mode of BASELINE.json configs[1] ("bf16"); it is NOT the parity mode: products carry
+// 2^-9 relative rounding per operand.
+//
+// NS = 3 ("f32x3") is an fp32-ACCURATE product on the bf16 matrix cores: every fp32 operand is split exactly into
+// three bf16 planes x = x0 + x1 + x2 (x0 = rne(x), x1 = rne(x - x0), x2 = rne(x - x0 - x1); the residual is below
+// 2^-26 |x|) and the product is formed from the six plane pairs whose weight is >= 2^-18:
+//     x.y ~= x0y0 + (x0y1 + x1y0) + (x1y1 + x0y2 + x2y0),     dropped: x1y2, x2y1, x2y2 <= 3 * 2^-27 |x||y|
+// Each plane pair is an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16: six matrix
+// instructions of 32 cycles each do the work of eight v_mfma_f32_32x32x2_f32 of 64 cycles (2.7x the fp32-MFMA
+// rate at the same K), with a relative error at or below the fp32 FMA chain's own rounding (tests/ compare both
+// with fp64).  gfx950 has no xf32/TF32 path; this is how the wide (compute-bound) layers leave the 157 TFLOP/s
+// fp32 ceiling without giving up fp32 results.  Reference: models/layers.py:208-216, :293-303 under
 // torch.autocast-style bf16, which the reference itself never ran -- tolerance is documented in DESIGN.md.
 //
 // LDS layout: both operands [row][k] with k contiguous (the MFMA lane (row = l & 31, h = l >> 5) reads the
@@ -46,8 +56,32 @@ __device__ __forceinline__ void store_bf16_run(__bf16* dst, const float (&v)[N])
     }
 }
 
-template <int WM, int WN, int BK, int PRO, int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
+// n consecutive fp32 -> NS bf16 planes (plane stride `plane` elements); NS = 1: plain RNE rounding
+template <int NS, int N>
+__device__ __forceinline__ void store_planes(__bf16* dst, int plane, const float (&v)[N])
+{
+    float r[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = v[i];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        float q[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const __bf16 h = (__bf16)r[i];                   // RNE
+            q[i] = r[i];
+            if (s + 1 < NS) r[i] = r[i] - (float)h;          // exact: the difference fits the fp32 mantissa
+        }
+        store_bf16_run<N>(dst + s * plane, q);
+    }
+}
+
+// The plane pairs of the f32x3 product, smallest terms first.
+__device__ constexpr int X3_PA[6] = {2, 0, 1, 1, 0, 0};
+__device__ constexpr int X3_PB[6] = {0, 2, 1, 0, 1, 0};
+
+template <int WM, int WN, int BK, int PRO, int EPI, int NS>
+__global__ __launch_bounds__(256, NS == 1 ? 4 : 2) void gemm_bf16_kernel(const GemmArgs a)
 {
     constexpr int BM = WM * 64, BN = WN * 64;
     constexpr int KA = BM * BK / 256;           // consecutive k per thread, matrix operand
@@ -55,10 +89,11 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
     constexpr int PITCH = BK + 8;
     constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
     constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
-    constexpr int LDS_BYTES = 2 * (BM + BN) * PITCH * 2;
+    constexpr int LDS_BYTES = 2 * NS * (BM + BN) * PITCH * 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    __bf16 (*As)[BM][PITCH] = reinterpret_cast<__bf16 (*)[BM][PITCH]>(smem);
-    __bf16 (*Bs)[BN][PITCH] = reinterpret_cast<__bf16 (*)[BN][PITCH]>(smem + 2 * BM * PITCH * 2);
+    // [buffer][plane][row][k]
+    __bf16 (*As)[NS][BM][PITCH] = reinterpret_cast<__bf16 (*)[NS][BM][PITCH]>(smem);
+    __bf16 (*Bs)[NS][BN][PITCH] = reinterpret_cast<__bf16 (*)[NS][BN][PITCH]>(smem + 2 * NS * BM * PITCH * 2);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,7 +158,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
         float va[KA], vx[KX];
 #pragma unroll
         for (int i = 0; i < KA; ++i) va[i] = (a_ok && k0 + akg + i < a.K) ? ra[i] : 0.0f;
-        store_bf16_run<KA>(&As[buf][am][akg], va);
+        store_planes<NS, KA>(&As[buf][0][am][akg], BM * PITCH, va);
 #pragma unroll
         for (int i = 0; i < KX; ++i) {
             const bool ok = x_ok && (k0 + xkg + i < a.K);
@@ -139,7 +174,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
             }
             vx[i] = ok ? v : 0.0f;
         }
-        store_bf16_run<KX>(&Bs[buf][xp][xkg], vx);
+        store_planes<NS, KX>(&Bs[buf][0][xp][xkg], BN * PITCH, vx);
     };
 
     const int nk = (a.K + BK - 1) / BK;
@@ -150,24 +185,33 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
     const int kh = (lane >> 5) * 8, c = lane & 31;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) load_stage((kt + 1) * BK);          // in flight under the MFMAs below
-        bf16x8 fa0 = *reinterpret_cast<const bf16x8*>(&As[cur][wm * 64 + c][kh]);
-        bf16x8 fa1 = *reinterpret_cast<const bf16x8*>(&As[cur][wm * 64 + 32 + c][kh]);
-        bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + c][kh]);
-        bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + 32 + c][kh]);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-            const bf16x8 a0 = fa0, a1 = fa1, b0 = fb0, b1 = fb1;
-            if (kk + 16 < BK) {                              // next 16 k under this step's four MFMAs
-                fa0 = *reinterpret_cast<const bf16x8*>(&As[cur][wm * 64 + c][kk + 16 + kh]);
-                fa1 = *reinterpret_cast<const bf16x8*>(&As[cur][wm * 64 + 32 + c][kk + 16 + kh]);
-                fb0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + c][kk + 16 + kh]);
-                fb1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + 32 + c][kk + 16 + kh]);
+            bf16x8 fa[NS][2], fb[NS][2];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fa[s][t] = *reinterpret_cast<const bf16x8*>(&As[cur][s][wm * 64 + t * 32 + c][kk + kh]);
+                    fb[s][t] = *reinterpret_cast<const bf16x8*>(&Bs[cur][s][wn * 64 + t * 32 + c][kk + kh]);
+                }
             }
             // operands swapped: D'[position][channel], see gemm_epilogue
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+            if constexpr (NS == 1) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][0], fa[0][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][1], fa[0][0], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][0], fa[0][1], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][1], fa[0][1], acc[1][1], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int pa = X3_PA[q], pb = X3_PB[q];
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pb][0], fa[pa][0], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pb][1], fa[pa][0], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pb][0], fa[pa][1], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[pb][1], fa[pa][1], acc[1][1], 0, 0, 0);
+                }
+            }
         }
         if (kt + 1 < nk) store_stage(cur ^ 1, (kt + 1) * BK);
         __syncthreads();
@@ -176,7 +220,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(const GemmArgs a)
     gemm_epilogue<WM, WN, EPI>(a, acc, reinterpret_cast<float*>(smem), LDS_BYTES / 4, b, m0, p0, tn, tpc);
 }
 
-template <int WM, int WN, int BK>
+template <int WM, int WN, int BK, int NS>
 int launch_gemm_bf16_t(const GemmArgs& a, int pro, hipStream_t st)
 {
     constexpr int BM = WM * 64, BN = WN * 64;
@@ -187,7 +231,7 @@ int launch_gemm_bf16_t(const GemmArgs& a, int pro, hipStream_t st)
     dim3 grid((unsigned)total), block(256);
 #define USIP_GEMM_CASE(P_, E_)                                                                  \
     if (pro == P_ && epi == E_) {                                                               \
-        USIP_LAUNCH((gemm_bf16_kernel<WM, WN, BK, P_, E_>), grid, block, 0, st, a);             \
+        USIP_LAUNCH((gemm_bf16_kernel<WM, WN, BK, P_, E_, NS>), grid, block, 0, st, a);         \
         USIP_LAUNCH_CHECK();                                                                    \
         return USIP_OK;                                                                         \
     }
@@ -204,12 +248,13 @@ int launch_gemm_bf16_t(const GemmArgs& a, int pro, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 // weight gradient: both operands are [row][positions] with the contraction (positions) contiguous, so the
 // float4 a thread loads becomes four consecutive k of its LDS row directly (no transposing scatter).
-template <int TM, int TN, int PRO, bool XPRO, bool VEC>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
+template <int TM, int TN, int PRO, bool XPRO, bool VEC, int NS>
+__global__ __launch_bounds__(256, NS == 1 ? 1 : 2) void wgrad_bf16_kernel(const WgradArgs a)
 {
-    constexpr int WN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32, BKP = 32, PITCH = BKP + 8;
-    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][BM][PITCH];
-    __shared__ __attribute__((aligned(16))) __bf16 Xs[2][BN][PITCH];
+    // NS = 3 stages 16 positions at a time: three planes of a 32-position stage would leave one workgroup per CU
+    constexpr int WN = 2, BM = 2 * TM * 32, BN = 2 * TN * 32, BKP = (NS == 1) ? 32 : 16, PITCH = BKP + 8;
+    __shared__ __attribute__((aligned(16))) __bf16 Gs[2][NS][BM][PITCH];
+    __shared__ __attribute__((aligned(16))) __bf16 Xs[2][NS][BN][PITCH];
     constexpr int NG4 = BM * BKP / 4 / 256, NX4 = BN * BKP / 4 / 256;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -242,17 +287,16 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
     auto load_pool = [&](int p) {
 #pragma unroll
         for (int i = 0; i < NG4; ++i) {
-            const int f = tid + i * 256, row = f / 8, kq = (f % 8) * 4;
+            const int f = tid + i * 256, row = f / (BKP / 4), kq = (f % (BKP / 4)) * 4;
             const int rc = min(m0 + row, a.M - 1), pc = min(p + kq, a.P - 4);
             const long long g = ((long long)b * a.M + rc) * pgrp + pc / a.pool_group;
             rg[i] = make_float4(a.pool_dp[g], __int_as_float(a.pool_arg[g]), __int_as_float(pc % a.pool_group), 0.f);
             rg2[i] = *reinterpret_cast<const float4*>(G2b + (long long)rc * a.P + pc);
         }
     };
-    auto to_lds = [&](__bf16* dst, const float4& v) {
-        bf16x4 pk;
-        pk[0] = (__bf16)v.x; pk[1] = (__bf16)v.y; pk[2] = (__bf16)v.z; pk[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(dst) = pk;
+    auto to_lds = [&](__bf16* dst, int plane, const float4& v) {
+        const float q[4] = {v.x, v.y, v.z, v.w};
+        store_planes<NS, 4>(dst, plane, q);
     };
     // per-row prologue coefficients, loaded once (a thread's rows are the same in every stage)
     float gc[TWO ? NG4 : 1][4], xc[XPRO ? NX4 : 1][2];
@@ -292,7 +336,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
                 v.z = (rok && p + kq + 2 < pend) ? pro_apply<PRO_BN_BWD>(v.z, w.z, c0, c1, c2, c3) : 0.f;
                 v.w = (rok && p + kq + 3 < pend) ? pro_apply<PRO_BN_BWD>(v.w, w.w, c0, c1, c2, c3) : 0.f;
             }
-            to_lds(&Gs[buf][row][kq], v);
+            to_lds(&Gs[buf][0][row][kq], BM * PITCH, v);
         }
 #pragma unroll
         for (int i = 0; i < NX4; ++i) {
@@ -310,15 +354,15 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
                 }
             }
             if (VEC && !(n0 + row < a.N && p + kq < pend)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            to_lds(&Xs[buf][row][kq], v);
+            to_lds(&Xs[buf][0][row][kq], BN * PITCH, v);
         }
     };
 
     const int nst = (pend - pbeg + BKP - 1) / BKP;
     if (nst > 0) {
         if (POOL) load_pool(pbeg);
-        else wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
-        wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx, rdummy);
+        else wgrad_load_rows<NG4, TWO, VEC, BKP / 4>(Gb, G2b, a.M, a.P, m0, pbeg, pend, tid, rg, rg2);
+        wgrad_load_rows<NX4, false, VEC, BKP / 4>(Xb, nullptr, a.N, a.P, n0, pbeg, pend, tid, rx, rdummy);
         store_stage(0, pbeg);
     }
     __syncthreads();
@@ -327,26 +371,41 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradArgs a)
     for (int s = 0; s < nst; ++s) {
         if (s + 1 < nst) {
             if (POOL) load_pool(pbeg + (s + 1) * BKP);
-            else wgrad_load_rows<NG4, TWO, VEC>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
-            wgrad_load_rows<NX4, false, VEC>(Xb, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx, rdummy);
+            else wgrad_load_rows<NG4, TWO, VEC, BKP / 4>(Gb, G2b, a.M, a.P, m0, pbeg + (s + 1) * BKP, pend, tid, rg, rg2);
+            wgrad_load_rows<NX4, false, VEC, BKP / 4>(Xb, nullptr, a.N, a.P, n0, pbeg + (s + 1) * BKP, pend, tid, rx, rdummy);
         }
-        bf16x8 fa[2][TM], fb[2][TN];                   // both 16-position halves of the stage up front
+        constexpr int NH = BKP / 16;
+        bf16x8 fa[NH][NS][TM], fb[NH][NS][TN];          // all 16-position groups of the stage up front
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[h][i] = *reinterpret_cast<const bf16x8*>(&Gs[cur][(wm * TM + i) * 32 + c][h * 16 + kh]);
+            for (int pl = 0; pl < NS; ++pl) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                fb[h][j] = *reinterpret_cast<const bf16x8*>(&Xs[cur][(wn * TN + j) * 32 + c][h * 16 + kh]);
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
+                    fa[h][pl][i] = *reinterpret_cast<const bf16x8*>(&Gs[cur][pl][(wm * TM + i) * 32 + c][h * 16 + kh]);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][i], fb[h][j], acc[i][j], 0, 0, 0);
+                    fb[h][pl][j] = *reinterpret_cast<const bf16x8*>(&Xs[cur][pl][(wn * TN + j) * 32 + c][h * 16 + kh]);
+            }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            if constexpr (NS == 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][0][i], fb[h][0][j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[h][X3_PA[q]][i], fb[h][X3_PB[q]][j],
+                                                                                acc[i][j], 0, 0, 0);
+            }
+        }
         if (s + 1 < nst) store_stage(cur ^ 1, pbeg + (s + 1) * BKP);
         __syncthreads();
         cur ^= 1;
@@ -362,30 +421,48 @@ int launch_gemm_bf16(const GemmArgs& a, int pro, hipStream_t st)
 {
     // K-step 16 (one MFMA group per stage): 32 was measured slower on every layer shape of the detector
     // (7.70 vs 7.16 ms per step) -- the kernels are bound by L2 -> L1 operand traffic, not by barriers.
-    return (a.M <= 64) ? launch_gemm_bf16_t<1, 4, 16>(a, pro, st) : launch_gemm_bf16_t<2, 2, 16>(a, pro, st);
+    return (a.M <= 64) ? launch_gemm_bf16_t<1, 4, 16, 1>(a, pro, st) : launch_gemm_bf16_t<2, 2, 16, 1>(a, pro, st);
 }
 
-int launch_wgrad_bf16(const WgradArgs& a, int pro, bool xpro, bool vec, int small, unsigned blocks, hipStream_t st)
+int launch_gemm_x3(const GemmArgs& a, int pro, hipStream_t st)
+{
+    return launch_gemm_bf16_t<2, 2, 16, 3>(a, pro, st);
+}
+
+template <int NS>
+static int launch_wgrad_planes(const WgradArgs& a, int pro, bool xpro, bool vec, int small, unsigned blocks, hipStream_t st)
 {
     dim3 grid(blocks), block(256);
 #define USIP_WGRAD_CASE(T_, P_, X_, V_)                                                        \
     if (small == (T_ == 1) && pro == P_ && xpro == X_ && vec == V_) {                          \
-        USIP_LAUNCH((wgrad_bf16_kernel<T_, T_, P_, X_, V_>), grid, block, 0, st, a);           \
+        USIP_LAUNCH((wgrad_bf16_kernel<T_, T_, P_, X_, V_, NS>), grid, block, 0, st, a);       \
         USIP_LAUNCH_CHECK();                                                                   \
         return USIP_OK;                                                                        \
     }
 #define USIP_WGRAD_CASES(T_, P_) \
     USIP_WGRAD_CASE(T_, P_, false, true) USIP_WGRAD_CASE(T_, P_, false, false) \
     USIP_WGRAD_CASE(T_, P_, true, true) USIP_WGRAD_CASE(T_, P_, true, false)
-    USIP_WGRAD_CASES(1, PRO_NONE)
-    USIP_WGRAD_CASES(1, PRO_BN_BWD)
+    if constexpr (NS == 1) {
+        USIP_WGRAD_CASES(1, PRO_NONE)
+        USIP_WGRAD_CASES(1, PRO_BN_BWD)
+        USIP_WGRAD_CASE(1, PRO_BN_BWD_POOL, false, true) USIP_WGRAD_CASE(1, PRO_BN_BWD_POOL, true, true)
+    }
     USIP_WGRAD_CASES(2, PRO_NONE)
     USIP_WGRAD_CASES(2, PRO_BN_BWD)
-    USIP_WGRAD_CASE(1, PRO_BN_BWD_POOL, false, true) USIP_WGRAD_CASE(1, PRO_BN_BWD_POOL, true, true)
     USIP_WGRAD_CASE(2, PRO_BN_BWD_POOL, false, true) USIP_WGRAD_CASE(2, PRO_BN_BWD_POOL, true, true)
 #undef USIP_WGRAD_CASES
 #undef USIP_WGRAD_CASE
     return USIP_EINVAL;
+}
+
+int launch_wgrad_bf16(const WgradArgs& a, int pro, bool xpro, bool vec, int small, unsigned blocks, hipStream_t st)
+{
+    return launch_wgrad_planes<1>(a, pro, xpro, vec, small, blocks, st);
+}
+
+int launch_wgrad_x3(const WgradArgs& a, int pro, bool xpro, bool vec, unsigned blocks, hipStream_t st)
+{
+    return launch_wgrad_planes<3>(a, pro, xpro, vec, 0, blocks, st);
 }
 
 }  // namespace usip_mlp

@@ -49,6 +49,45 @@ def _pooled_act(y4, coef, relu):
     return pooled, arg
 
 
+# Second test hook, same purpose: ReLU decisions.  A pre-activation within rounding distance of zero is "on" in one
+# correct forward and "off" in another; with a few hundred positions per channel in the head (M nodes per cloud)
+# one such flip moves that channel's gradient -- and everything upstream of it -- by O(1e-2).  When set to a list
+# of (flat index int64 [n], on bool [n]) pairs, one per BatchNorm+ReLU layer in call order (the decisions of the
+# REFERENCE for every pre-activation within 1e-4 of zero, from a fixture), every layer nudges the few pre-BN values
+# whose decision differs from the given one across zero (by ~4e-7 of the activation's scale), so that ALL
+# consumers of that y (the next GEMM's prologue, pooling, every backward kernel) take the given decision; every
+# pre-activation NOT in the list must be farther than `PIN_RELU_MARGIN` from zero, i.e. unambiguous.
+PIN_RELU_FIX = None
+PIN_RELU_MARGIN = 5e-5
+PIN_RELU_FLIPS = []          # number of nudged elements per layer, for the test's report
+
+
+def _align_relu_decisions(y, coef):
+    """y [nb,C,P] pre-BN output, coef [>=2,C] -> y whose relu decisions at the listed elements are the given ones."""
+    idx, on = PIN_RELU_FIX.pop(0)
+    idx, on = idx.to(y.device), on.to(y.device)
+    z = ops.bn_apply(y, coef, False)                     # the kernels' own arithmetic: fma(y, coef0, coef1)
+    zf = z.reshape(-1)
+    listed = torch.zeros(zf.numel(), dtype=torch.bool, device=y.device)
+    listed[idx] = True
+    if idx.numel() < zf.numel() and float(zf[~listed].abs().min()) < PIN_RELU_MARGIN:
+        raise RuntimeError("PIN_RELU_FIX: an unlisted pre-activation is within %.0e of zero" % PIN_RELU_MARGIN)
+    flip = (zf[idx] > 0) != on
+    n = int(flip.sum())
+    PIN_RELU_FLIPS.append(n)
+    if n:
+        C, P = y.shape[1], y.shape[2]
+        fi, fon = idx[flip], on[flip]
+        ch = (fi // P) % C
+        sc, sh = coef[0][ch], coef[1][ch]
+        t = torch.where(fon, 1.0, -1.0) * 4e-7 * torch.clamp(sh.abs(), min=1.0)
+        y = y.clone()
+        y.view(-1)[fi] = (t - sh) / sc
+        if not bool(((ops.bn_apply(y, coef, False).reshape(-1)[idx] > 0) == on).all()):
+            raise RuntimeError("PIN_RELU_FIX: could not align the decisions of a layer")
+    return y
+
+
 def _kmajor(w2):
     """[Cin, Cout] copy of the weight matrix w2 [Cout, Cin]."""
     cached = WT_CACHE.get(w2.data_ptr()) if WT_CACHE is not None else None
@@ -252,6 +291,8 @@ class _SharedMLPLayer(torch.autograd.Function):
             y, stats = ops.mlp_gemm(wt, x, bias, want_stats=True, pro=pro, coef=xcoef)
             mean, invstd, coef = ops.bn_finalize(stats, nb * P, gamma, beta, eps, momentum,
                                                  running_mean, running_var)
+            if PIN_RELU_FIX is not None and relu:
+                y = _align_relu_decisions(y, coef)
         else:
             y, _ = ops.mlp_gemm(wt, x, bias, pro=pro, coef=xcoef)
             invstd = torch.rsqrt(running_var + eps)
@@ -329,6 +370,8 @@ class _SharedMLPLayerMax(torch.autograd.Function):
         y, stats = ops.mlp_gemm(_kmajor(w2), x3, bias, want_stats=True,
                                 pro=0 if xcoef is None else 1, coef=xcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum, running_mean, running_var)
+        if PIN_RELU_FIX is not None:
+            y = _align_relu_decisions(y, coef)
         pooled, arg = _pooled_act(y.view(B, Cout, M, K), coef, True)
         ctx.save_for_backward(x3, xcoef, w2, y, coef, mean, invstd, gamma, arg)
         ctx.dims, ctx.sink, ctx.x_shape = (B, Cin, Cout, M, K), sink, tuple(x.shape)
@@ -414,6 +457,8 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
                                 pro=0 if hcoef is None else 1, coef=hcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum,
                                              running_mean, running_var)
+        if PIN_RELU_FIX is not None and relu:
+            y = _align_relu_decisions(y, coef)
         ctx.save_for_backward(h3, hcoef, pooled, w2, y, coef, mean, invstd, gamma)
         ctx.dims = (B, Ch, Cp, Cout, M, K, poff, hoff)
         ctx.h_shape = tuple(h.shape)

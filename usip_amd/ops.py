@@ -50,22 +50,24 @@ def index_max(data: torch.Tensor, index: torch.Tensor, K: int) -> torch.Tensor:
 
 
 def index_max_geometry(B: int, C: int, N: int, K: int):
-    """(channel rows per workgroup, prefetch depth) usip_index_max_f32 picks for this shape (csrc/index_max.hip);
-    lets a profiler name the launch."""
-    rows, ch = B * C, 1
-    for cand in (8, 4, 2):
-        if C % cand == 0 and rows // cand >= 512 and cand * K * 8 <= 65536:
-            ch = cand
-            break
-    u = (4 if ch <= 4 else 2) if N >= 4096 else 1
-    tch = _lib.lib().usip_tuning_value(0)
-    tu = _lib.lib().usip_tuning_value(1)
+    """(channel rows per workgroup, prefetch depth, threads) usip_index_max_f32 picks for this shape
+    (csrc/index_max.hip); lets a profiler name the launch."""
+    rows = B * C
+    ch = 2 if (C % 2 == 0 and rows // 2 >= 512 and 2 * K * 8 <= 65536) else 1
+    u = 2 if N >= 4096 else 1
+    t = 256
+    tch, tu, tt = (_lib.lib().usip_tuning_value(i) for i in (0, 1, 5))
     if tch > 0 and C % tch == 0 and tch * K * 8 <= 65536:
         ch = tch
     if tu > 0:
         u = tu
-    u = 4 if (u >= 4 and ch <= 4) else (2 if u >= 2 else 1)
-    return ch, u
+    if tt in (512, 1024):
+        t = tt
+    if t > 256:
+        u = 2 if u >= 2 else 1
+    else:
+        u = 4 if (u >= 4 and ch <= 4) else (2 if u >= 2 else 1)
+    return ch, u, t
 
 
 def ball_query(dist: torch.Tensor, radius: float, K: int) -> torch.Tensor:
@@ -208,7 +210,9 @@ def _opt(t):
 
 # "f32": fp32 MFMA (the parity mode and the headline).  "bf16": operands rounded to bf16 inside the GEMM and
 # weight-gradient kernels, fp32 accumulate, everything else fp32 (BASELINE.json configs[1] perf mode).
-MATMUL_MODES = ("f32", "bf16")
+#   "f32x3": fp32-accurate products on the bf16 matrix cores (three bf16 planes per operand, six plane products) for
+#   the matrix-bound launches, the fp32 kernel for the rest; results equal "f32" to fp32 rounding.
+MATMUL_MODES = ("f32", "bf16", "f32x3")
 _matmul_mode = "f32"
 
 
@@ -268,14 +272,17 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
     a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
     bf16 = _matmul_mode == "bf16"
-    fn_name = "usip_mlp_gemm_bf16" if bf16 else "usip_mlp_gemm_f32"
+    fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
+    x3 = _matmul_mode == "f32x3" and bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb))
 
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         e = 1 if want_stats else 0
         if bf16:
-            return "gemm_bf16_kernel<%d, %d, 16, %d, %d> |wg=%d" % (wm, wn, pro, e, tiles * ((M + wm * 64 - 1) // (wm * 64)))
+            return "gemm_bf16_kernel<%d, %d, 16, %d, %d, 1> |wg=%d" % (wm, wn, pro, e, tiles * ((M + wm * 64 - 1) // (wm * 64)))
+        if x3:
+            return "gemm_bf16_kernel<2, 2, 16, %d, %d, 3> |wg=%d" % (pro, e, nb * ((P + 127) // 128) * ((M + 127) // 128))
         # csrc/shared_mlp.hip mlp_gemm_impl: 32 rows per wave when 128-row tiles would not fill the chip
         tm = 1 if ((M > 64 and nb * ((P + 127) // 128) * ((M + 127) // 128) < 512)
                    or (M <= 32 and nb * ((P + 255) // 256) < 512)) else 2
@@ -377,14 +384,16 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     ldw = dW.shape[1]
     bf16 = _matmul_mode == "bf16"
-    fn_name = "usip_mlp_wgrad_bf16" if bf16 else "usip_mlp_wgrad_f32"
+    fn_name = {"bf16": "usip_mlp_wgrad_bf16", "f32x3": "usip_mlp_wgrad_f32x3"}.get(_matmul_mode, "usip_mlp_wgrad_f32")
+    x3 = _matmul_mode == "f32x3" and not (M <= 64 and N <= 64) and bool(_lib.lib().usip_mlp_wgrad_f32x3_used(M, N, P, nb))
 
     def _key():
         t = 1 if (M <= 64 and N <= 64) else 2
-        return "%s<%d, %d, %d, %s, %s> |wg=%d" % ("wgrad_bf16_kernel" if bf16 else "wgrad_kernel", t, t, pro,
-                                                  "true" if xcoef is not None else "false",
-                                                  "true" if P % 4 == 0 else "false",
-                                                  _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
+        planes = ", 1" if bf16 else (", 3" if x3 else "")
+        return "%s<%d, %d, %d, %s, %s%s> |wg=%d" % ("wgrad_bf16_kernel" if (bf16 or x3) else "wgrad_kernel", t, t, pro,
+                                                    "true" if xcoef is not None else "false",
+                                                    "true" if P % 4 == 0 else "false", planes,
+                                                    _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
 
     with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
                                              4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
