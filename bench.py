@@ -369,8 +369,8 @@ def main():
         if not args.no_kernel_timing:
             traffic_db, traffic_src = load_traffic_db(args.precision)
             def is_x3(r):
-                key = r.get("rocprof_key") or ""
-                return "bf16_kernel" in key and key.split(">")[0].endswith(", 3")
+                key = (r.get("rocprof_key") or "").split(" |wg=")[0]
+                return "x3" in key or ("bf16_kernel" in key and key.rstrip(">").endswith(", 3"))
 
             kernels = []
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
@@ -410,8 +410,7 @@ def main():
                 top_name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
                 avg_s = top["ms"] * 1e-3 / top["calls"]
                 if top["mfma"]:
-                    top_peak = PEAK_BF16_TFLOPS / 6.0 if (top_name.split(">")[0].endswith(", 3") and "bf16_kernel" in top_name) \
-                        else mfma_peak
+                    top_peak = PEAK_BF16_TFLOPS / 6.0 if is_x3({"rocprof_key": top_name}) else mfma_peak
                     ach, peak, unit, bound = top["flops"] / top["calls"] / avg_s / 1e12, top_peak, "TFLOP/s", "mfma"
                 else:
                     ach, peak, unit, bound = top["nbytes"] / top["calls"] / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"

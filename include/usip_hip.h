@@ -177,6 +177,18 @@ int usip_mlp_gemm_f32x3(const float* At, int lda, const float* X, const float* X
                        const float* pool_dp, const int32_t* pool_arg, int pool_group,
                         float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
 int usip_mlp_gemm_f32x3_used(int M, int K, int P, int nb);
+/* The same f32x3 product with the MATRIX operand split ahead of time (once per optimizer step instead of once per
+ * workgroup and stage): usip_mlp_split3_f32 turns the K-major operand At (A[m][k] = At[k*lda + m], M x K) into the
+ * image the kernel copies straight into LDS -- per (128-row tile, 16-k stage) three contiguous 4 KiB bf16 planes,
+ * zero padded -- usip_mlp_split3_bytes(M, K) bytes, 16-B aligned.  usip_mlp_gemm_x3p_f32 then has the contract of
+ * usip_mlp_gemm_f32 with `planes` in place of (At, lda); K <= 640. */
+int usip_mlp_x3p_tile_rows(int M);                 /* rows per tile (128 or 256): profiling aid */
+long long usip_mlp_split3_bytes(int M, int K);
+int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream);
+int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                          const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
+                          const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
+                          int M, int K, int P, int nb, void* stream);
 
 /* K-major copies of many weight matrices in one launch: for every t < ntensors, table[5t..5t+4] =
  * (source offset, rows, cols, destination offset, index of its first 32 x 32 tile), offsets in floats into src / dst;

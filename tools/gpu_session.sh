@@ -9,6 +9,7 @@ for STEP in "$@"; do
   case $STEP in
     pytest)    timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log ;;
     pytestx)   timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log ;;
+    pytest_x3) USIP_MATMUL_MODE=f32x3 timeout 1500 python -m pytest tests -m gpu -q --deselect tests/test_bf16_mode_gpu.py > gpurun_out/${TAG}_pytest_x3.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_x3.log ;;
     pinned)    timeout 600 python -m pytest tests/test_modules_gpu.py -m gpu -q -k "pinned or two_ranks" > gpurun_out/${TAG}_pinned.log 2>&1; echo "rc=$?" >> gpurun_out/${TAG}_pinned.log ;;
     x3test)    timeout 900 python -m pytest tests/test_f32x3_mode_gpu.py tests/test_bf16_mode_gpu.py -m gpu -q > gpurun_out/${TAG}_x3test.log 2>&1; echo "rc=$?" >> gpurun_out/${TAG}_x3test.log ;;
     x3bench)   timeout 600 python tools/x3_bench.py > gpurun_out/${TAG}_x3bench.txt 2>&1 ;;
@@ -27,7 +28,7 @@ for STEP in "$@"; do
   esac
   echo "== $STEP done ($(date +%T))"
 done
-for f in gpurun_out/${TAG}_pytest.log gpurun_out/${TAG}_pinned.log gpurun_out/${TAG}_x3test.log; do [ -f $f ] && { echo "--- $f"; tail -n 15 $f; }; done
+for f in gpurun_out/${TAG}_pytest.log gpurun_out/${TAG}_pytest_x3.log gpurun_out/${TAG}_pinned.log gpurun_out/${TAG}_x3test.log; do [ -f $f ] && { echo "--- $f"; tail -n 15 $f; }; done
 for f in gpurun_out/${TAG}_x3bench.txt gpurun_out/${TAG}_index_max_sweep.txt gpurun_out/${TAG}_host_overhead.txt; do [ -f $f ] && { echo "--- $f"; cat $f; }; done
 for f in gpurun_out/${TAG}_bench*.json; do [ -f $f ] && { echo "--- $f"; head -c 700 $f; echo; }; done
 exit 0

@@ -42,6 +42,11 @@ SIGNATURES = {
     "usip_mlp_gemm_f32x3": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                              _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_f32x3_used": ([_int, _int, _int, _int], _int),
+    "usip_mlp_x3p_tile_rows": ([_int], _int),
+    "usip_mlp_split3_bytes": ([_int, _int], ctypes.c_longlong),
+    "usip_mlp_split3_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
+    "usip_mlp_gemm_x3p_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
+                               _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3_used": ([_int, _int, _int, _int], _int),
     "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p,
                                           _f32p, _int, _int, _int, _int, _stream], _int),

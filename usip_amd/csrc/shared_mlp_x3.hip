@@ -1,0 +1,342 @@
+// usip_amd/csrc/shared_mlp_x3.hip -- the matrix-bound shared-MLP GEMMs (forward and data gradient of the 128..640-
+// wide layers: models/layers.py:208-216, :293-303, :401-440) as fp32-ACCURATE products on the bf16 matrix cores.
+//
+// Arithmetic ("f32x3", see shared_mlp_bf16.hip for the derivation): every fp32 operand is split exactly into three
+// bf16 planes, the six plane pairs of weight >= 2^-18 are accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
+//
+// What this file adds over the NS = 3 instantiation of gemm_bf16_kernel is the instruction diet the counters asked
+// for.  That kernel spends 230 VALU + 150 SALU instructions per 24 MFMAs (SQ_INSTS_*; MFMA pipe 35 % busy): it is
+// issue-bound on the operand preparation, not on memory and not on the matrix pipe.  Here
+//   * the WEIGHT operand is split ONCE per step by split3_tiles_kernel into the exact LDS image of every
+//     (128-row, 16-k) stage -- three 4 KiB planes, contiguous -- so a stage of A is three coalesced 16-B loads and
+//     three ds_write_b128 per thread, no arithmetic (was: 8 dword loads, 8 three-way splits, 8 selects);
+//   * the streamed operand is converted in PAIRS (v_cvt_pk_bf16_f32 takes two floats), unpacked with one shift and
+//     one mask per pair, and is never masked per lane: rows of k beyond K meet zero weights (the planes are zero
+//     padded), positions beyond P are never stored or counted, so clamped loads suffice;
+//   * prologue coefficients come from LDS (loaded once per workgroup) instead of 16 scalar loads per stage whose
+//     s_waitcnt lgkmcnt(0) also drained the LDS queue;
+//   * LDS rows are 32 B (16 bf16) with the two 16-B halves swapped in every other block of 8 rows: conflict-free
+//     ds_read_b128 without padding, 48 KiB for both stages of both operands (two workgroups per CU).
+#include "mlp_common.h"
+
+using namespace usip_mlp;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int XBK = 16;                                        // k per stage: one MFMA step
+
+// Two fp32 -> three packed bf16 pairs (low half = first element), x = h + m + l exactly up to 2^-26 |x|.
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    f32x2 v = {x, y};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);             // v_cvt_pk_bf16_f32, RNE
+    p0 = __builtin_bit_cast(unsigned, h);
+    v.x = x - __uint_as_float(p0 << 16);                       // exact
+    v.y = y - __uint_as_float(p0 & 0xffff0000u);
+    bf16x2 m = __builtin_convertvector(v, bf16x2);
+    p1 = __builtin_bit_cast(unsigned, m);
+    v.x = v.x - __uint_as_float(p1 << 16);
+    v.y = v.y - __uint_as_float(p1 & 0xffff0000u);
+    bf16x2 l = __builtin_convertvector(v, bf16x2);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+// byte offset of (row, 16-B half) inside a [rows][16 bf16] plane: halves swapped in every other block of 8 rows
+__device__ __forceinline__ int lds_off(int row, int half) { return row * 32 + ((half ^ (row >> 3)) & 1) * 16; }
+
+// ------------------------------------------------------------------------------------------------
+// Weight operand -> per-stage LDS images.  At is the K-major operand of usip_mlp_gemm_f32 (A[m][k] = At[k*lda + m]);
+// out[((mt * ksteps + ks) * 3 + plane) * bm*2 + lds_off(row, half) / 16] (16-B chunks) with the chunk holding
+// k = ks*16 + half*8 .. +7 of row mt*bm + row, zero outside M x K.  bm (128 or 256) = rows of the GEMM's tile.
+// One workgroup of 2*bm threads per (mt, ks) stage.
+__global__ __launch_bounds__(512) void split3_tiles_kernel(const float* __restrict__ At, int lda, int M, int K,
+                                                           uint4* __restrict__ out, int ksteps, int bm)
+{
+    const int ks = blockIdx.x % ksteps, mt = blockIdx.x / ksteps;
+    const int row = threadIdx.x % bm, half = threadIdx.x / bm;
+    const int m = mt * bm + row;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = ks * XBK + half * 8 + i;
+        v[i] = (m < M && k < K) ? At[(long long)k * lda + m] : 0.0f;
+    }
+    unsigned p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    uint4* stage = out + (long long)blockIdx.x * (3 * bm * 2);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)          // chunk position = its LDS position (lds_off / 16): the GEMM copies linearly
+        stage[s * (bm * 2) + row * 2 + ((half ^ (row >> 3)) & 1)] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// amdgpu_waves_per_eu(2, 2): LDS already limits the kernel to two workgroups per CU; telling the register allocator
+// so stops it from aiming at three waves per SIMD and spilling the staged A planes to scratch around the MFMAs.
+// Tile: 2 x WN waves, each TM x 2 MFMA tiles of 32 x 32: XBM = 64*TM channels x XBN = 64*WN positions.
+//   (TM, WN) = (2, 2): 128 x 128, 256 threads, two workgroups per CU   (layers with 128 output channels)
+//              (4, 2): 256 x 128, 256 threads, two workgroups per CU   (the wide layers: every streamed element is
+//                      prepared for 256 channels instead of 128 -- half the preparation per MFMA, half the L2 reads)
+//              (4, 4): 256 x 256, 512 threads, one workgroup per CU
+template <int PRO, int EPI, int TM, int WN>
+__global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x3p_kernel(const GemmArgs a, const uint4* __restrict__ planes)
+{
+    constexpr int XBM = 64 * TM, XBN = 64 * WN, NT = 128 * WN;
+    constexpr int APL = XBM * 32, BPL = XBN * 32;              // bytes of one plane of one stage
+    constexpr int ASTAGE = 3 * APL, BSTAGE = 3 * BPL;
+    constexpr int NA = XBM * 2 / NT;                           // 16-B chunks of an A plane per thread: 1 or 2
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
+    constexpr int NCOEF = (PRO == PRO_NONE) ? 0 : (TWO ? 4 : 2);
+    constexpr int OPER_BYTES = 2 * (ASTAGE + BSTAGE);          // two stages of both operands
+    // widest contraction of the path: 640 inputs (mlp1) forward, 512 outputs backward; 4 x 512 floats keep two
+    // workgroups of the 256 x 128 tile inside the CU's 160 KiB
+    constexpr int KMAX = (NCOEF == 4) ? 512 : 640;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES + (NCOEF ? NCOEF : 1) * KMAX * 4];
+    unsigned char* As = smem;                                  // [stage][plane][row][16 k]
+    unsigned char* Bs = smem + 2 * ASTAGE;
+    float* cf = reinterpret_cast<float*>(smem + OPER_BYTES);   // [NCOEF][KMAX]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // same logical tile order and XCD remap as the fp32 kernel
+    const int tpc = (a.P + XBN - 1) / XBN, nmt = (a.M + XBM - 1) / XBM;
+    const int total = a.nb * tpc * nmt;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+    const int mt = L % nmt, tn = L / nmt;
+    const int b = tn / tpc, pt = tn % tpc;
+    const int m0 = mt * XBM, p0 = pt * XBN;
+    const int nk = (a.K + XBK - 1) / XBK;
+
+    if (NCOEF) {
+        for (int i = tid; i < NCOEF * a.K; i += NT) cf[(i / a.K) * KMAX + i % a.K] = a.coef[i];
+    }
+
+    // A: the global image IS the LDS image, so a stage of A is copied by LDS-DMA (global_load_lds_dwordx4: every lane
+    // sends 16 B, the wave's 1 KiB lands at a wave-uniform LDS base) -- no staging registers, no ds_write
+    const uint4* Ag = planes + (long long)mt * nk * (ASTAGE / 16) + tid;
+    const int a_wave = wave * 64 * 16;                         // byte offset of this wave's first chunk in a plane
+    // X: thread -> position p = tid % XBN, k-group = tid / XBN (wave-uniform): 8 consecutive k of one position
+    const int xp = tid & (XBN - 1);
+    const int xkg = __builtin_amdgcn_readfirstlane(tid / XBN);
+    const int xpc = min(p0 + xp, a.P - 1);
+    const int x_lds = lds_off(xp, xkg);
+    const float* Xp = (POOL ? a.X2 : a.X) + (long long)b * a.K * a.P + xpc;       // + k * P
+    const float* X2p = TWO ? a.X2 + (long long)b * a.K * a.P + xpc : nullptr;
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const float* pdp = POOL ? a.pool_dp + (long long)b * a.K * pgrp + xpc / a.pool_group : nullptr;
+    const int* parg = POOL ? a.pool_arg + (long long)b * a.K * pgrp + xpc / a.pool_group : nullptr;
+    const int xkin = POOL ? xpc % a.pool_group : 0;
+
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float rx[8], ry[TWO ? 8 : 1];
+    int rarg[POOL ? 8 : 1];
+
+    auto dma_stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < NA; ++j)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(Ag + (long long)kt * (ASTAGE / 16) + s * (APL / 16) + j * NT),
+                    (__attribute__((address_space(3))) void*)(As + buf * ASTAGE + s * APL + j * NT * 16 + a_wave), 16, 0, 0);
+    };
+    auto load_stage = [&](int kt) {
+        const int kb = kt * XBK + xkg * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kc = min(kb + i, a.K - 1);               // scalar: the k-group is wave-uniform
+            if (POOL) {
+                rx[i] = pdp[(long long)kc * pgrp];
+                rarg[i] = parg[(long long)kc * pgrp];
+            } else {
+                rx[i] = Xp[(long long)kc * a.P];
+            }
+            if (TWO) ry[i] = X2p[(long long)kc * a.P];
+        }
+    };
+    auto store_stage = [&](int buf, int kt) {
+        const int kb = kt * XBK + xkg * 8;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float x = rx[i];
+            if (PRO != PRO_NONE) {
+                const int kc = min(kb + i, a.K - 1);
+                const float c0 = cf[kc], c1 = cf[KMAX + kc];
+                float c2 = 0.f, c3 = 0.f, w = x;
+                if (TWO) { c2 = cf[2 * KMAX + kc]; c3 = cf[3 * KMAX + kc]; w = ry[i]; }
+                if (POOL) x = (rarg[POOL ? i : 0] == xkin) ? x : 0.f;
+                constexpr int PA = POOL ? PRO_BN_BWD : PRO;
+                x = pro_apply<PA>(x, w, c0, c1, c2, c3);
+            }
+            v[i] = x;
+        }
+        // k >= K (the tail of a 131-wide layer): the loads were clamped to row K-1 -- finite data -- and meet the
+        // zero padding of the weight planes, so no masking is needed (a branch here would also split the loop body
+        // and with it the MFMA / preparation interleave)
+        unsigned p[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            *reinterpret_cast<uint4*>(Bs + buf * BSTAGE + s * BPL + x_lds) =
+                make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
+    };
+
+    // Software pipeline, one barrier per stage:
+    //   registers hold the RAW operands of stage kt+1 (loaded during stage kt-1);
+    //   during the 24 MFMAs of stage kt the wave also (a) runs prologue + split on those registers and writes the
+    //   LDS image of stage kt+1 into the other buffer, (b) re-issues the loads for stage kt+2 into the same
+    //   registers.  In-order issue lets ~5 other instructions slip between two 32-cycle MFMAs, so the operand
+    //   preparation overlaps the matrix pipe; hipcc interleaves the two streams on its own (pinning the order with
+    //   sched_group_barrier was measured 8-25 % slower and removed).  (Measured by
+    //   ablation before this structure: MFMA + fragment reads 290 us, + global loads 145 us, + split/LDS writes
+    //   110 us -- the three added up, 562-634 us for the 512 x 512 forward.)
+    const int c = lane & 31, kh = lane >> 5;
+    int fa_off[TM], fb_off[2];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa_off[t] = lds_off((wm * TM + t) * 32 + c, kh);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) fb_off[t] = lds_off(wn * 64 + t * 32 + c, kh);
+    constexpr int NXL = POOL ? 24 : (TWO ? 16 : 8);            // register loads of one stage of the streamed operand
+    dma_stage(0, 0);
+    load_stage(0);
+    __syncthreads();                                           // prologue coefficients are in LDS
+    store_stage(0, 0);
+    load_stage(min(1, nk - 1));
+    __syncthreads();
+    int cur = 0;
+    // the six plane pairs, smallest terms first; operands swapped: D'[position][channel], see gemm_epilogue
+#define USIP_X3_PRODUCT(PA_, PB_)                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_][0], fa[PA_][i], acc[i][0], 0, 0, 0);        \
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_][1], fa[PA_][i], acc[i][1], 0, 0, 0);        \
+        }
+#define USIP_X3_READ_FRAGS()                                                                                       \
+        bf16x8 fa[3][TM], fb[3][2];                                                                                \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                            \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
+                fa[s][t] = *reinterpret_cast<const bf16x8*>(As + cur * ASTAGE + s * APL + fa_off[t]);              \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
+                fb[s][t] = *reinterpret_cast<const bf16x8*>(Bs + cur * BSTAGE + s * BPL + fb_off[t]);              \
+        }
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        dma_stage(cur ^ 1, kt + 1);                            // A of stage kt+1: memory -> LDS (the other buffer is free)
+        USIP_X3_READ_FRAGS()
+        USIP_X3_PRODUCT(2, 0) USIP_X3_PRODUCT(0, 2) USIP_X3_PRODUCT(1, 1)
+        store_stage(cur ^ 1, kt + 1);                          // X of stage kt+1: registers -> LDS
+        load_stage(min(kt + 2, nk - 1));                       // X of stage kt+2: memory -> registers (last: a harmless repeat)
+        USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) USIP_X3_PRODUCT(0, 0)
+        // The DMA (issued before the register loads of stage kt+2, loads retire in order) must have landed and this
+        // wave's LDS writes must be done before anyone reads the other buffer; the register loads stay in flight
+        // across the barrier -- __syncthreads() would drain them (it waits vmcnt(0) while an LDS-DMA is pending).
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NXL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+    {
+        USIP_X3_READ_FRAGS()
+        USIP_X3_PRODUCT(2, 0) USIP_X3_PRODUCT(0, 2) USIP_X3_PRODUCT(1, 1)
+        USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) USIP_X3_PRODUCT(0, 0)
+        __syncthreads();
+    }
+#undef USIP_X3_PRODUCT
+#undef USIP_X3_READ_FRAGS
+    gemm_epilogue<2, WN, EPI, TM>(a, acc, reinterpret_cast<float*>(smem), OPER_BYTES / 4, b, m0, p0, tn, tpc);
+}
+
+}  // namespace
+
+// Rows of the tile usip_mlp_gemm_x3p_f32 uses for an M-row operand (= rows per block of the split image).
+extern "C" int usip_mlp_x3p_tile_rows(int M)
+{
+    const int t = usip_tuning_value(USIP_TUNE_NARROW_BWD);        // measurement: 1 = always 128-row tiles
+    return (M > 128 && t != 1) ? 256 : 128;
+}
+
+// Bytes of the split weight image usip_mlp_split3_f32 writes for an M x K operand.
+extern "C" long long usip_mlp_split3_bytes(int M, int K)
+{
+    if (M < 1 || K < 1) return 0;
+    const int bm = usip_mlp_x3p_tile_rows(M);
+    return (long long)((M + bm - 1) / bm) * ((K + XBK - 1) / XBK) * 3 * bm * 32;
+}
+
+extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream)
+{
+    if (!At || !planes || M < 1 || K < 1 || lda < M || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
+    const int bm = usip_mlp_x3p_tile_rows(M);
+    const int ksteps = (K + XBK - 1) / XBK, mts = (M + bm - 1) / bm;
+    USIP_LAUNCH(split3_tiles_kernel, dim3((unsigned)(mts * ksteps)), dim3(2 * bm), 0, (hipStream_t)stream, At, lda, M, K,
+                reinterpret_cast<uint4*>(planes), ksteps, bm);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+template <int TM, int WN>
+static int launch_x3p(const GemmArgs& a, const uint4* pl, int pro, hipStream_t st)
+{
+    constexpr int BM = 64 * TM, BN = 64 * WN;
+    const int tpc = (a.P + BN - 1) / BN, nmt = (a.M + BM - 1) / BM;
+    const long long total = (long long)a.nb * tpc * nmt;
+    if (total > 0x7fffffffLL) return USIP_EINVAL;
+    const int epi = a.stats ? EPI_STATS : EPI_NONE;
+    dim3 grid((unsigned)total), block(128 * WN);
+#define USIP_X3P_CASE(P_, E_)                                                                 \
+    if (pro == P_ && epi == E_) {                                                             \
+        USIP_LAUNCH((gemm_x3p_kernel<P_, E_, TM, WN>), grid, block, 0, st, a, pl);            \
+        USIP_LAUNCH_CHECK();                                                                  \
+        return USIP_OK;                                                                       \
+    }
+    USIP_X3P_CASE(PRO_NONE, EPI_STATS)
+    USIP_X3P_CASE(PRO_NONE, EPI_NONE)
+    USIP_X3P_CASE(PRO_AFFINE_RELU, EPI_STATS)
+    USIP_X3P_CASE(PRO_AFFINE_RELU, EPI_NONE)
+    USIP_X3P_CASE(PRO_BN_BWD, EPI_NONE)
+    USIP_X3P_CASE(PRO_BN_BWD_POOL, EPI_NONE)
+#undef USIP_X3P_CASE
+    return USIP_EINVAL;
+}
+
+// Y[b] = A . pro(X[b]) + bias (+ rowbias) with A given as the split image of usip_mlp_split3_f32 (same M, K).
+// Contract of usip_mlp_gemm_f32 otherwise; K <= 640, P % 4 == 0 not required.
+extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                                     const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
+                                     const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
+                                     int M, int K, int P, int nb, void* stream)
+{
+    if (M < 1 || K < 1 || K > 640 || P < 0 || nb < 0) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && K > 512) return USIP_EINVAL;
+    if ((long long)P * nb == 0) return USIP_OK;
+    if (!planes || !Y || pro < 0 || pro > 3 || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
+    if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
+    if (pro != PRO_NONE && !coef) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || stats)) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 1 || P % pool_group != 0)) return USIP_EINVAL;
+    if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
+    if (y_rows == 0) y_rows = M;
+    if (y_rows < M) return USIP_EINVAL;
+    GemmArgs a{nullptr, 0, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
+               0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    const uint4* pl = reinterpret_cast<const uint4*>(planes);
+    if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2>(a, pl, pro, st);
+    // measurement only (256-position tiles change the layout of the statistics partials): launches without them
+    if (usip_tuning_value(USIP_TUNE_NARROW_BWD) == 4 && !stats) return launch_x3p<4, 4>(a, pl, pro, st);
+    return launch_x3p<4, 2>(a, pl, pro, st);
+}

@@ -214,6 +214,11 @@ def _opt(t):
 #   the matrix-bound launches, the fp32 kernel for the rest; results equal "f32" to fp32 rounding.
 MATMUL_MODES = ("f32", "bf16", "f32x3")
 _matmul_mode = "f32"
+import os as _os                                             # noqa: E402
+if _os.environ.get("USIP_MATMUL_MODE"):                      # lets the whole GPU test suite run under another mode
+    if _os.environ["USIP_MATMUL_MODE"] not in MATMUL_MODES:
+        raise ValueError("USIP_MATMUL_MODE must be one of %s" % (MATMUL_MODES,))
+    _matmul_mode = _os.environ["USIP_MATMUL_MODE"]
 
 
 def set_matmul_mode(mode: str) -> str:
@@ -227,6 +232,28 @@ def set_matmul_mode(mode: str) -> str:
 
 def matmul_mode() -> str:
     return _matmul_mode
+
+
+# f32x3 mode: split images of the weight operands (usip_mlp_split3_f32), keyed by (storage pointer, lda, column
+# offset, M, K).  The training step sets this to a dict for the duration of one forward + backward (weights do not
+# change in between), so every weight is split once per step; None: split at every call.
+PLANES_CACHE = None
+
+
+def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int) -> torch.Tensor:
+    """Split image (uint8 tensor) of the M x K operand A[m][k] = At[k, a_offset + m] for usip_mlp_gemm_x3p_f32."""
+    lda = At.shape[1]
+    key = (At.data_ptr(), lda, int(a_offset), int(M), int(K))
+    if PLANES_CACHE is not None and key in PLANES_CACHE:
+        return PLANES_CACHE[key][1]
+    nbytes = int(_lib.lib().usip_mlp_split3_bytes(M, K))
+    planes = torch.empty(nbytes, dtype=torch.uint8, device=At.device)
+    with torch.cuda.device(At.device), prof.kernel("weight_split3", 4.0 * M * K + nbytes):
+        _lib.check(_lib.lib().usip_mlp_split3_f32(ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset)), lda, M, K,
+                                                  _ptr(planes), _stream(At)), "usip_mlp_split3_f32")
+    if PLANES_CACHE is not None:
+        PLANES_CACHE[key] = (At, planes)      # holding At keeps its storage (the key) from being reused meanwhile
+    return planes
 
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
@@ -274,6 +301,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     bf16 = _matmul_mode == "bf16"
     fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
     x3 = _matmul_mode == "f32x3" and bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb))
+    x3p = x3 and not a_trans and K <= (512 if pro >= 2 else 640)       # weight operand split ahead of time
 
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
@@ -281,6 +309,9 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         e = 1 if want_stats else 0
         if bf16:
             return "gemm_bf16_kernel<%d, %d, 16, %d, %d, 1> |wg=%d" % (wm, wn, pro, e, tiles * ((M + wm * 64 - 1) // (wm * 64)))
+        if x3p:
+            bm = _lib.lib().usip_mlp_x3p_tile_rows(M)
+            return "gemm_x3p_kernel<%d, %d, %d, 2> |wg=%d" % (pro, e, bm // 64, nb * ((P + 127) // 128) * ((M + bm - 1) // bm))
         if x3:
             return "gemm_bf16_kernel<2, 2, 16, %d, %d, 3> |wg=%d" % (pro, e, nb * ((P + 127) // 128) * ((M + 127) // 128))
         # csrc/shared_mlp.hip mlp_gemm_impl: 32 rows per wave when 128-row tiles would not fill the chip
@@ -290,9 +321,17 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         return "gemm_kernel<%d, %d, 16, %d, %d, %s, %d> |wg=%d" % (wm, wn, pro, e, "true" if P % 4 == 0 else "false", tm,
                                                                    tiles * ((M + bm - 1) // bm))
 
+    planes = weight_planes(At, a_offset, M, K) if x3p else None
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P, rocprof_key=_key):
+        if x3p:
+            _lib.check(_lib.lib().usip_mlp_gemm_x3p_f32(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
+                                                        _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
+                                                        _opt(pool_dp), _opt(pool_arg), int(pool_group), y_ptr,
+                                                        int(y_rows), _opt(stats), M, K, P, nb, _stream(X)),
+                       "usip_mlp_gemm_x3p_f32")
+            return Y, stats
         _lib.check(getattr(_lib.lib(), fn_name)(a_ptr, -lda if a_trans else lda,
                                                 None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),

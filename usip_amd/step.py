@@ -139,12 +139,14 @@ class _GraphedStep:
                 flat_wt, table, tiles, views = self._wt
                 ops.multi_transpose(self.bucket.flat_param.data, flat_wt, table, tiles)
                 Fh.WT_CACHE = views
+            ops.PLANES_CACHE = {}                             # f32x3 mode: every weight operand is split once per step
             loss = self.forward_losses(batch, epoch)
             loss.backward()
         finally:
             Fh.GRAD_SINK = False
             Fh.DEFER_BN_COUNTERS = False
             Fh.WT_CACHE = None
+            ops.PLANES_CACHE = None
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)         # every BatchNorm ran exactly once
         return loss
