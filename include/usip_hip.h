@@ -255,6 +255,7 @@ int usip_mlp_wgrad_f32x3(const float* G, const float* G2, const float* coef, int
                         float* workspace, float* dW, int ldw, int coloff,
                         int M, int N, int P, int nb, void* stream);
 int usip_mlp_wgrad_f32x3_used(int M, int N, int P, int nb);
+int usip_mlp_wgrad_f32x3_blocks(int M, int N, int P, int nb);   /* < 0: the 256 x 256-tile kernel, |value| workgroups */
 
 /* ------------------------------------------------------------------ a-6 / a-7 / a-12  grouping, pooling
  * out[b][coff+c][m][k] = x[b][c][idx[b][m][k]] - (c < nsub ? sub[b][c][m] : 0), written into the

@@ -219,5 +219,8 @@ int launch_wgrad_bf16(const WgradArgs& a, int pro, bool xpro, bool vec, int smal
 // fp32-accurate products out of three bf16 planes per operand (128 x 128 tiles only; see shared_mlp_bf16.hip)
 int launch_gemm_x3(const GemmArgs& a, int pro, hipStream_t st);
 int launch_wgrad_x3(const WgradArgs& a, int pro, bool xpro, bool vec, unsigned blocks, hipStream_t st);
+// 256 x 256 tiles, own slicing (shared_mlp_x3.hip); needs the vector path (P % 4 == 0, 16-B aligned operands)
+void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* tiles);
+int launch_wgrad_x3_256(const WgradArgs& a, int pro, bool xpro, unsigned blocks, hipStream_t st);
 
 }  // namespace usip_mlp

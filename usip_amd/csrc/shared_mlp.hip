@@ -785,9 +785,10 @@ static void wgrad_plan(int M, int N, int P, int nb, int* seglen, int* segs, int*
 
 extern "C" long long usip_mlp_wgrad_workspace(int M, int N, int P, int nb)
 {
-    int seglen, segs, small, tiles;
+    int seglen, segs, small, tiles, sl3, sg3, t3;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
-    return (long long)nb * segs * M * N;
+    wgrad_x3_plan(M, N, P, nb, &sl3, &sg3, &t3);              // the f32x3 kernel slices differently: cover both
+    return (long long)nb * (segs > sg3 ? segs : sg3) * M * N;
 }
 
 // Number of workgroups usip_mlp_wgrad_f32 launches (lets a profiler match launches to layer shapes).
@@ -807,6 +808,19 @@ static bool x3_wgrad_pays(int M, int N, int P, int nb)
 }
 extern "C" int usip_mlp_wgrad_f32x3_used(int M, int N, int P, int nb) { return x3_wgrad_pays(M, N, P, nb) ? 1 : 0; }
 
+// Workgroups usip_mlp_wgrad_f32x3 launches, negative when it runs the 256 x 256-tile kernel (profiling aid).
+extern "C" int usip_mlp_wgrad_f32x3_blocks(int M, int N, int P, int nb)
+{
+    int seglen, segs, small, tiles;
+    wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
+    const bool x3 = !small && x3_wgrad_pays(M, N, P, nb);
+    if (x3 && P % 4 == 0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_WGRAD_XCD) != 1) {
+        wgrad_x3_plan(M, N, P, nb, &seglen, &segs, &tiles);
+        return -(tiles * nb * segs);
+    }
+    return tiles * nb * segs;
+}
+
 static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float* coef, int pro,
                           const float* X, const float* xcoef, const float* pool_dp, const int32_t* pool_arg,
                           int pool_group, float* workspace, float* dW, int ldw,
@@ -824,6 +838,12 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
     int seglen, segs, small, tiles;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
     const bool bf16 = (mode == 1), x3 = (mode == 2) && !small && x3_wgrad_pays(M, N, P, nb);
+    // 256 x 256 tiles for the wide layers (every streamed element is prepared for twice as many partners)
+    const bool vec0 = (P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
+                      (pro == PRO_NONE || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
+    const bool x3big = x3 && vec0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_WGRAD_XCD) != 1;
+    if (x3big) wgrad_x3_plan(M, N, P, nb, &seglen, &segs, &tiles);
     WgradArgs a{G, G2, coef, X, xcoef, pool_dp, pool_arg, pool_group, workspace, M, N, P, nb, seglen, segs};
     const bool xpro = xcoef != nullptr;
     const bool vec = (P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
@@ -838,7 +858,8 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
         if (rc != USIP_OK) return rc;
     }
     if (x3) {
-        const int rc = launch_wgrad_x3(a, pro, xpro, vec, (unsigned)blocks, st);
+        const int rc = x3big ? launch_wgrad_x3_256(a, pro, xpro, (unsigned)blocks, st)
+                             : launch_wgrad_x3(a, pro, xpro, vec, (unsigned)blocks, st);
         if (rc != USIP_OK) return rc;
     }
 #define USIP_WGRAD_CASE(T_, P_, X_, V_)                                                        \

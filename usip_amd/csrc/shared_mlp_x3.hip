@@ -260,6 +260,178 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     gemm_epilogue<2, WN, EPI, TM>(a, acc, reinterpret_cast<float*>(smem), OPER_BYTES / 4, b, m0, p0, tn, tpc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient dW[m][n] = sum_p pro(G)[m][p] * X[n][p] with f32x3 products.  Both operands are streamed
+// activations (prologue + split on the fly), so what can be saved is how often an element is prepared: a 256 x 256
+// output tile per workgroup (8 waves, each 128 x 64 = 4 x 2 MFMA tiles) prepares every element for 256 partners
+// instead of 128 -- 16 elements per thread per 48 MFMAs (the 128 x 128 kernel: 16 per 24).  Same two-stage
+// software pipeline as the GEMM; positions are the contraction index, 16 per stage, contiguous in memory, so a
+// thread's float4 becomes 8 B of its LDS row directly.
+template <int PRO, bool XPRO>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_x3_kernel(const WgradArgs a)
+{
+    constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256, NT = 512;
+    constexpr int PL = BM * 32, STAGE = 3 * PL;                // bytes: one plane, one operand stage (BM == BN)
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * STAGE];       // [stage][G | X][plane][row][16 p]
+    unsigned char* Gs = smem;
+    unsigned char* Xs = smem + 2 * STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nmt = (a.M + BM - 1) / BM, nnt = (a.N + BN - 1) / BN;
+    const int total = gridDim.x;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+    const int tile = L % (nmt * nnt), slice = L / (nmt * nnt);
+    const int m0 = (tile / nnt) * BM, n0 = (tile % nnt) * BN;
+    const int b = slice / a.segs, seg = slice % a.segs;
+    const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
+    const int nst = (pend - pbeg + 15) / 16;
+
+    // thread -> two (row, 4 positions) pieces per operand and stage: f = tid + i*512, row = f / 4, kq = (f % 4) * 4
+    int grow[2], xrow[2], lds[2];
+    bool gok[2];
+    const float* gp[2];
+    const float* g2p[2];
+    const float* xp[2];
+    const float* pdp[2];
+    const int* pap[2];
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const int kq = (tid & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid + i * NT) >> 2;
+        grow[i] = min(m0 + row, a.M - 1);
+        xrow[i] = min(n0 + row, a.N - 1);
+        gok[i] = m0 + row < a.M;
+        lds[i] = lds_off(row, kq >> 3) + (kq & 7) * 2;
+        gp[i] = POOL ? nullptr : a.G + ((long long)b * a.M + grow[i]) * a.P;
+        g2p[i] = TWO ? a.G2 + ((long long)b * a.M + grow[i]) * a.P : nullptr;
+        xp[i] = a.X + ((long long)b * a.N + xrow[i]) * a.P;
+        pdp[i] = POOL ? a.pool_dp + ((long long)b * a.M + grow[i]) * pgrp : nullptr;
+        pap[i] = POOL ? a.pool_arg + ((long long)b * a.M + grow[i]) * pgrp : nullptr;
+    }
+    float gc[TWO ? 2 : 1][4], xc[XPRO ? 2 : 1][2];
+    if (TWO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gc[i][j] = a.coef[j * a.M + grow[i]];
+    }
+    if (XPRO) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { xc[i][0] = a.xcoef[xrow[i]]; xc[i][1] = a.xcoef[a.N + xrow[i]]; }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 rg[2], rg2[TWO ? 2 : 1], rx[2];
+    auto load_stage = [&](int st) {
+        const int pc = min(pbeg + st * 16 + kq, a.P - 4);      // clamped: always a valid, aligned float4
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (POOL) {
+                const int g = pc / a.pool_group;
+                rg[i] = make_float4(pdp[i][g], __int_as_float(pap[i][g]), __int_as_float(pc % a.pool_group), 0.f);
+            } else {
+                rg[i] = *reinterpret_cast<const float4*>(gp[i] + pc);
+            }
+            if (TWO) rg2[i] = *reinterpret_cast<const float4*>(g2p[i] + pc);
+            rx[i] = *reinterpret_cast<const float4*>(xp[i] + pc);
+        }
+    };
+    auto store_stage = [&](int buf, int st) {
+        const bool pok = pbeg + st * 16 + kq < pend;           // float4 granularity: P % 4 == 0, segments start at 32 p
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = rg[i];
+            if (TWO) {
+                const float4 w = rg2[i];
+                if (POOL) {
+                    const int hit = __float_as_int(v.y) - __float_as_int(v.z);
+                    const float g = v.x;
+                    v = make_float4(hit == 0 ? g : 0.f, hit == 1 ? g : 0.f, hit == 2 ? g : 0.f, hit == 3 ? g : 0.f);
+                }
+                const float c0 = gc[TWO ? i : 0][0], c1 = gc[TWO ? i : 0][1], c2 = gc[TWO ? i : 0][2], c3 = gc[TWO ? i : 0][3];
+                v.x = pro_apply<PRO_BN_BWD>(v.x, w.x, c0, c1, c2, c3);
+                v.y = pro_apply<PRO_BN_BWD>(v.y, w.y, c0, c1, c2, c3);
+                v.z = pro_apply<PRO_BN_BWD>(v.z, w.z, c0, c1, c2, c3);
+                v.w = pro_apply<PRO_BN_BWD>(v.w, w.w, c0, c1, c2, c3);
+            }
+            // only G is masked (rows beyond M, positions beyond the segment): whatever finite value the clamped X
+            // load returned there meets a zero
+            if (!(gok[i] && pok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned p0[2], p1[2], p2[2];
+            split_pair(v.x, v.y, p0[0], p1[0], p2[0]);
+            split_pair(v.z, v.w, p0[1], p1[1], p2[1]);
+            *reinterpret_cast<uint2*>(Gs + buf * STAGE + 0 * PL + lds[i]) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(Gs + buf * STAGE + 1 * PL + lds[i]) = make_uint2(p1[0], p1[1]);
+            *reinterpret_cast<uint2*>(Gs + buf * STAGE + 2 * PL + lds[i]) = make_uint2(p2[0], p2[1]);
+            float4 x = rx[i];
+            if (XPRO) {
+                const float s0 = xc[XPRO ? i : 0][0], s1 = xc[XPRO ? i : 0][1];
+                x.x = fmaxf(__builtin_fmaf(x.x, s0, s1), 0.f); x.y = fmaxf(__builtin_fmaf(x.y, s0, s1), 0.f);
+                x.z = fmaxf(__builtin_fmaf(x.z, s0, s1), 0.f); x.w = fmaxf(__builtin_fmaf(x.w, s0, s1), 0.f);
+            }
+            split_pair(x.x, x.y, p0[0], p1[0], p2[0]);
+            split_pair(x.z, x.w, p0[1], p1[1], p2[1]);
+            *reinterpret_cast<uint2*>(Xs + buf * STAGE + 0 * PL + lds[i]) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(Xs + buf * STAGE + 1 * PL + lds[i]) = make_uint2(p1[0], p1[1]);
+            *reinterpret_cast<uint2*>(Xs + buf * STAGE + 2 * PL + lds[i]) = make_uint2(p2[0], p2[1]);
+        }
+    };
+
+    const int c = lane & 31, kh = lane >> 5;
+    int fa_off[TM], fb_off[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa_off[t] = lds_off((wm * TM + t) * 32 + c, kh);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) fb_off[t] = lds_off((wn * TN + t) * 32 + c, kh);
+#define USIP_X3W_PRODUCT(PA_, PB_)                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA_][i], fb[PB_][j], acc[i][j], 0, 0, 0);
+#define USIP_X3W_READ_FRAGS()                                                                                      \
+        bf16x8 fa[3][TM], fb[3][TN];                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                            \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
+                fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + cur * STAGE + s * PL + fa_off[t]);                \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                         \
+                fb[s][t] = *reinterpret_cast<const bf16x8*>(Xs + cur * STAGE + s * PL + fb_off[t]);                \
+        }
+    int cur = 0;
+    if (nst > 0) {
+        load_stage(0);
+        store_stage(0, 0);
+        load_stage(min(1, nst - 1));
+        __syncthreads();
+        for (int st = 0; st + 1 < nst; ++st) {
+            USIP_X3W_READ_FRAGS()
+            USIP_X3W_PRODUCT(2, 0) USIP_X3W_PRODUCT(0, 2) USIP_X3W_PRODUCT(1, 1)
+            store_stage(cur ^ 1, st + 1);                      // stage st+1: registers -> LDS
+            load_stage(min(st + 2, nst - 1));                  // stage st+2: memory -> registers
+            USIP_X3W_PRODUCT(1, 0) USIP_X3W_PRODUCT(0, 1) USIP_X3W_PRODUCT(0, 0)
+            __syncthreads();
+            cur ^= 1;
+        }
+        USIP_X3W_READ_FRAGS()
+        USIP_X3W_PRODUCT(2, 0) USIP_X3W_PRODUCT(0, 2) USIP_X3W_PRODUCT(1, 1)
+        USIP_X3W_PRODUCT(1, 0) USIP_X3W_PRODUCT(0, 1) USIP_X3W_PRODUCT(0, 0)
+    }
+#undef USIP_X3W_PRODUCT
+#undef USIP_X3W_READ_FRAGS
+    wgrad_store_partial<TM, TN>(a, acc, slice, m0, n0, wm, wn, lane);
+}
+
 }  // namespace
 
 // Rows of the tile usip_mlp_gemm_x3p_f32 uses for an M-row operand (= rows per block of the split image).
@@ -340,3 +512,41 @@ extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const f
     if (usip_tuning_value(USIP_TUNE_NARROW_BWD) == 4 && !stats) return launch_x3p<4, 4>(a, pl, pro, st);
     return launch_x3p<4, 2>(a, pl, pro, st);
 }
+
+// ---- weight gradient, 256 x 256 tiles -------------------------------------------------------------------------
+namespace usip_mlp {
+
+// Slicing of the 256 x 256-tile weight gradient: ~512 workgroups (one per CU at a time, two rounds), position
+// segments that are multiples of 32 and at least 512 long (a workgroup writes a 256 KiB partial tile; shorter
+// segments would make that the dominant traffic).
+void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* tiles)
+{
+    *tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    long long want = 512 / (*tiles);
+    if (want < 1) want = 1;
+    long long per_cloud = (want + nb - 1) / nb;
+    if (per_cloud < 1) per_cloud = 1;
+    long long sl = (P + per_cloud - 1) / per_cloud;
+    sl = ((sl + 31) / 32) * 32;
+    if (sl < 512) sl = 512;
+    *seglen = (int)sl;
+    *segs = (int)((P + sl - 1) / sl);
+}
+
+int launch_wgrad_x3_256(const WgradArgs& a, int pro, bool xpro, unsigned blocks, hipStream_t st)
+{
+    dim3 grid(blocks), block(512);
+#define USIP_X3W_CASE(P_, X_)                                                             \
+    if (pro == P_ && xpro == X_) {                                                        \
+        USIP_LAUNCH((wgrad_x3_kernel<P_, X_>), grid, block, 0, st, a);                    \
+        USIP_LAUNCH_CHECK();                                                              \
+        return USIP_OK;                                                                   \
+    }
+    USIP_X3W_CASE(PRO_NONE, false) USIP_X3W_CASE(PRO_NONE, true)
+    USIP_X3W_CASE(PRO_BN_BWD, false) USIP_X3W_CASE(PRO_BN_BWD, true)
+    USIP_X3W_CASE(PRO_BN_BWD_POOL, false) USIP_X3W_CASE(PRO_BN_BWD_POOL, true)
+#undef USIP_X3W_CASE
+    return USIP_EINVAL;
+}
+
+}  // namespace usip_mlp

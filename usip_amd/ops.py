@@ -428,6 +428,10 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
 
     def _key():
         t = 1 if (M <= 64 and N <= 64) else 2
+        if x3:
+            blocks = _lib.lib().usip_mlp_wgrad_f32x3_blocks(M, N, P, nb)
+            if blocks < 0:
+                return "wgrad_x3_kernel<%d, %s> |wg=%d" % (pro, "true" if xcoef is not None else "false", -blocks)
         planes = ", 1" if bf16 else (", 3" if x3 else "")
         return "%s<%d, %d, %d, %s, %s%s> |wg=%d" % ("wgrad_bf16_kernel" if (bf16 or x3) else "wgrad_kernel", t, t, pro,
                                                     "true" if xcoef is not None else "false",
