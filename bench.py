@@ -49,10 +49,12 @@ def parse():
     ap.add_argument("--n", "--points", dest="n", type=int, default=16384)
     ap.add_argument("--m", "--nodes", dest="m", type=int, default=512)
     ap.add_argument("--cloud", default="slab")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3", "bf16"],
-                    help="f32 = fp32 MFMA everywhere; f32x3 = fp32-ACCURATE products on the bf16 matrix cores for the "
+    ap.add_argument("--precision", default="f32x3", choices=["f32", "f32x3", "bf16"],
+                    help="f32x3 (default) = fp32-ACCURATE products on the bf16 matrix cores for the "
                          "matrix-bound layers (three bf16 planes per operand, six plane products, fp32 accumulation; "
-                         "error at the fp32 FMA chain's level, tests/test_f32x3_mode_gpu.py), fp32 MFMA for the rest; "
+                         "error at the fp32 kernels' level, every parity test passes in this mode: "
+                         "tests/test_f32x3_mode_gpu.py, USIP_MATMUL_MODE=f32x3 pytest -m gpu), fp32 MFMA for the rest; "
+                         "f32 = fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere; "
                          "bf16 = bf16 multiply / fp32 accumulate, tensors stay fp32 (perf mode of BASELINE configs[1]; "
                          "NOT a parity mode)")
     ap.add_argument("--no-graph", action="store_true",
@@ -80,7 +82,8 @@ def load_traffic_db(precision):
     db, src = {}, []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         if ("bf16" in os.path.basename(f)) != (precision == "bf16"):
-            continue                               # each precision mode has its own kernels and PMC passes
+            continue                               # the bf16 perf mode has its own kernels and PMC passes (f32 and
+            #                                        f32x3 kernels have distinct names and share one database)
         try:
             db.update(json.load(open(f)))          # later rounds override earlier ones key by key
             src.append(os.path.basename(f))
@@ -352,7 +355,7 @@ def main():
                        "detector": {"ball": "RPN_Detector_Ball", "som": "RPN_Detector",
                                     "descriptor": "DescriptorLiteOld (descriptor head, 256 keypoints)"}[args.model],
                        "clouds_per_gpu": 2 * args.pairs, "surface_normal_len": 4, "node_knn_k_1": 16,
-                       "ball_radius": 2, "ball_k": 64, "cloud": args.cloud,
+                       "ball_radius": 2, "ball_k": 64, "cloud": args.cloud, "matmul": args.precision,
                        "step": "fwd+losses+bwd" + ("+allreduce" if world > 1 else "") +
                                ("" if args.no_optimizer else "+adam"),
                        "launch": "HIP graph replay (2 graphs per step, all-reduce between them)" if graphed
@@ -417,7 +420,8 @@ def main():
                 out["roofline"] = {
                     "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": (top["traffic"] / top["traffic_calls"]) if top["traffic_calls"] else None,
-                    "kernel": top_name + (" (csrc/shared_mlp_bf16.hip)" if "bf16" in top_name else " (csrc/shared_mlp.hip)")
+                    "kernel": top_name + (" (csrc/shared_mlp_x3.hip)" if "x3" in top_name else
+                                          " (csrc/shared_mlp_bf16.hip)" if "bf16" in top_name else " (csrc/shared_mlp.hip)")
                     if top["mfma"] else top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
                     "avg_us": round(avg_s * 1e6, 2),
                     "share_of_step": round(top["ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
@@ -426,6 +430,10 @@ def main():
                                "(%d steps)" % (sample_every, timed_steps_sampled)),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
                     "traffic_source": traffic_src,
+                    "peak_note": ("fp32-equivalent: a split-product launch issues six bf16 matrix products per fp32 "
+                                  "product, so its ceiling is the dense bf16 peak (2500 TFLOP/s) / 6; the same launch "
+                                  "priced in bf16 flops actually issued: %.0f of 2500 TFLOP/s" % (6.0 * ach))
+                    if (top["mfma"] and peak != mfma_peak) else None,
                     "attainable_peak_note": "a pure fp32-MFMA loop (tools/mfma_peak.hip) sustains 121-141 TFLOP/s with "
                                             "random operands on this chip (clock 1.85-2.15 GHz under load), see "
                                             "profiles/r01_mfma_attainable_peak.txt" if (top["mfma"] and args.precision == "f32") else None}

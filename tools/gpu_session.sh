@@ -18,6 +18,8 @@ for STEP in "$@"; do
     bench)     timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ;;
     benchq)    timeout 900 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ;;
     bench_x3)  timeout 900 python bench.py --precision f32x3 --no-cpu-baseline > gpurun_out/${TAG}_bench_x3.json 2> gpurun_out/${TAG}_bench_x3.err ;;
+    bench_f32) timeout 900 python bench.py --precision f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_f32.json 2> gpurun_out/${TAG}_bench_f32.err ;;
+    profile_f32) timeout 1200 bash tools/profile_roofline.sh ${TAG}_f32 --precision f32 > gpurun_out/${TAG}_profile_f32.log 2>&1 ;;
     bench_som) timeout 900 python bench.py --model som --no-cpu-baseline > gpurun_out/${TAG}_bench_som.json 2> gpurun_out/${TAG}_bench_som.err ;;
     bench_som_x3) timeout 900 python bench.py --model som --precision f32x3 --no-cpu-baseline > gpurun_out/${TAG}_bench_som_x3.json 2> gpurun_out/${TAG}_bench_som_x3.err ;;
     bench_desc) timeout 900 python bench.py --model descriptor > gpurun_out/${TAG}_bench_desc.json 2> gpurun_out/${TAG}_bench_desc.err ;;

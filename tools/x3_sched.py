@@ -23,7 +23,7 @@ for (M, K, P, nb) in [(512, 512, 8192, 16), (256, 256, 8192, 16), (256, 131, 819
     ops.PLANES_CACHE = {}
     truth = torch.matmul(At.double().t().unsqueeze(0), X[:1].double()) + b.double().view(1, M, 1)
     for name, bits in [("256x128 tile", 0), ("128x128 tile", 1), ("256x256 (no stats)", 4)]:
-        lib.usip_set_tuning(b"narrow_bwd", bits)
+        lib.usip_set_tuning(b"x3_gemm_tile", bits)
         ops.PLANES_CACHE = {}
         t0 = timed(lambda: ops.mlp_gemm(At, X, b, want_stats=True))
         t1 = timed(lambda: ops.mlp_gemm(At, X, b, want_stats=True, pro=1, coef=coef[:2].contiguous()))
@@ -32,4 +32,4 @@ for (M, K, P, nb) in [(512, 512, 8192, 16), (256, 256, 8192, 16), (256, 131, 819
         fl = 2.0 * M * K * P * nb
         print("M=%d K=%d %-18s fwd %6.1f us (%5.1f TF)  fwd+bnrelu %6.1f us (%5.1f TF)  dgrad(bn-bwd) %6.1f us (%5.1f TF)  err %.1e" %
               (M, K, name, t0, fl / t0 / 1e6, t1, fl / t1 / 1e6, t2, fl / t2 / 1e6, err), flush=True)
-lib.usip_set_tuning(b"narrow_bwd", 0)
+lib.usip_set_tuning(b"x3_gemm_tile", 0)

@@ -814,7 +814,7 @@ extern "C" int usip_mlp_wgrad_f32x3_blocks(int M, int N, int P, int nb)
     int seglen, segs, small, tiles;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
     const bool x3 = !small && x3_wgrad_pays(M, N, P, nb);
-    if (x3 && P % 4 == 0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_WGRAD_XCD) != 1) {
+    if (x3 && P % 4 == 0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 1) {
         wgrad_x3_plan(M, N, P, nb, &seglen, &segs, &tiles);
         return -(tiles * nb * segs);
     }
@@ -842,7 +842,7 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
     const bool vec0 = (P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
                       ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
                       (pro == PRO_NONE || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
-    const bool x3big = x3 && vec0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_WGRAD_XCD) != 1;
+    const bool x3big = x3 && vec0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 1;
     if (x3big) wgrad_x3_plan(M, N, P, nb, &seglen, &segs, &tiles);
     WgradArgs a{G, G2, coef, X, xcoef, pool_dp, pool_arg, pool_group, workspace, M, N, P, nb, seglen, segs};
     const bool xpro = xcoef != nullptr;

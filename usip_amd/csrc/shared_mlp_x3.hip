@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Rows of the tile usip_mlp_gemm_x3p_f32 uses for an M-row operand (= rows per block of the split image).
 extern "C" int usip_mlp_x3p_tile_rows(int M)
 {
-    const int t = usip_tuning_value(USIP_TUNE_NARROW_BWD);        // measurement: 1 = always 128-row tiles
+    const int t = usip_tuning_value(USIP_TUNE_X3_GEMM_TILE);        // measurement: 1 = always 128-row tiles
     return (M > 128 && t != 1) ? 256 : 128;
 }
 
@@ -509,7 +509,7 @@ extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const f
     const uint4* pl = reinterpret_cast<const uint4*>(planes);
     if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2>(a, pl, pro, st);
     // measurement only (256-position tiles change the layout of the statistics partials): launches without them
-    if (usip_tuning_value(USIP_TUNE_NARROW_BWD) == 4 && !stats) return launch_x3p<4, 4>(a, pl, pro, st);
+    if (usip_tuning_value(USIP_TUNE_X3_GEMM_TILE) == 4 && !stats) return launch_x3p<4, 4>(a, pl, pro, st);
     return launch_x3p<4, 2>(a, pl, pro, st);
 }
 
