@@ -244,6 +244,21 @@ int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int p
                        const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                        float* workspace, float* dW, int ldw, int coloff,
                        int M, int N, int P, int nb, void* stream);
+/* Backward of a NARROW layer (64 inputs, 64 or 128 outputs) in one pass over its tensors: data gradient AND weight
+ * gradient from one staged tile of (dZ, Y, X) -- these layers are HBM-bound and the two separate products read
+ * (dZ, Y) twice.  Replaces the pair usip_mlp_gemm_f32(pro = 2) + usip_mlp_wgrad_f32(pro = 2) for the grouped
+ * convolutions conv2 / conv3 / conv4 of RPN_Detector_Ball (models/networks.py:705-709; autograd's
+ * cudnn_convolution_backward in the reference).  Exact fp32 MFMA, deterministic (fixed-order partial sums).
+ *   dX[b][ci][p] = sum_co W[co*ldw + ci] * dY[b][co][p],  dW[co*lddw + ci] = sum_{b,p} dY[b][co][p] * act(X)[b][ci][p]
+ *   dY = BatchNorm'(ReLU'(dZ)) from (dZ, Y, coef4) as in usip_mlp_gemm_f32 pro = 2; act(X) = relu(X*xcoef[0]+xcoef[1])
+ *   (xcoef NULL: X as is).  X / dX point at the first of the 64 rows inside [nb][x_rows][P] / [nb][dx_rows][P].
+ * workspace: usip_mlp_narrow_backward_workspace(Cout, P, nb) floats. */
+int usip_mlp_narrow_backward_supported(int Cin, int Cout, int P);
+long long usip_mlp_narrow_backward_workspace(int Cout, int P, int nb);
+int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, const float* coef4, const float* X, int x_rows,
+                                 const float* xcoef, const float* W, int ldw, float* dX, int dx_rows,
+                                 float* workspace, float* dW, int lddw, int Cin, int Cout, int P, int nb,
+                                 void* stream);
 /* bf16-multiply variant (see usip_mlp_gemm_bf16); same workspace, same deterministic fp32 reduction. */
 int usip_mlp_wgrad_bf16(const float* G, const float* G2, const float* coef, int pro, const float* X,
                         const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,

@@ -182,3 +182,45 @@ def test_gemm_writes_a_channel_slice_of_a_wider_tensor():
     assert bool((out[:, :5] == 7.0).all()) and bool((out[:, 5 + M:] == 7.0).all())
     with pytest.raises(RuntimeError):
         ops.mlp_gemm(At, X, out=out, out_row_offset=10)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 4096, True, 64, 0), (2, 128, 2048, True, 64, 0), (3, 64, 1024, False, 64, 0),
+                                 (2, 128, 4096, True, 128, 64), (1, 128, 640, False, 128, 0)])
+def test_fused_narrow_backward_equals_separate_products(cfg):
+    """csrc/narrow_bwd.hip: data gradient and weight gradient of a 64-input layer from ONE pass over (dZ, Y, X) must
+    equal the two generic products (usip_mlp_gemm_f32 pro=2 and usip_mlp_wgrad_f32 pro=2) and fp64 truth; also for a
+    column block of a wider weight matrix (the feature half of the pooled-concat layer) and bit for bit on a re-run."""
+    from usip_amd import ops
+    nb, Cout, P, xpro, Ctot, wcol = cfg
+    Cin = 64
+    g = torch.Generator().manual_seed(Cout + P + wcol)
+    dz = torch.randn(nb, Cout, P, generator=g).to(DEV)
+    y = torch.randn(nb, Cout, P, generator=g).to(DEV)
+    x = torch.randn(nb, Cin, P, generator=g).to(DEV)
+    w2 = (torch.randn(Cout, Ctot, generator=g) * (2.0 / Cin) ** 0.5).to(DEV)
+    coef4 = torch.stack([1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g),
+                         0.05 * torch.randn(Cout, generator=g), 0.05 * torch.randn(Cout, generator=g)]).to(DEV)
+    xcoef = torch.stack([1 + 0.1 * torch.randn(Cin, generator=g), 0.1 * torch.randn(Cin, generator=g)]).to(DEV) if xpro else None
+    dw_out = torch.full((Cout, Ctot), 7.0, device=DEV)
+    dx, dw = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol=wcol, dw_out=dw_out)
+    # truth in float64
+    c = [coef4[i].double().view(1, Cout, 1) for i in range(4)]
+    fma = lambda a_, b_, c_: (a_.double() * b_.double() + c_.double()).float()
+    dyh = torch.where(fma(y, c[0], c[1]) > 0, dz, torch.zeros_like(dz))
+    dy = fma(c[0], dyh, fma(c[2], y, c[3])).double()
+    ax = torch.relu(fma(x, xcoef[0].view(1, Cin, 1), xcoef[1].view(1, Cin, 1))).double() if xpro else x.double()
+    wsub = w2[:, wcol:wcol + Cin].double()
+    want_dx = torch.einsum("oc,bop->bcp", wsub, dy)
+    want_dw = torch.einsum("bop,bcp->oc", dy, ax)
+    assert _rel(dx, want_dx) < 2e-6 and _rel(dw[:, wcol:wcol + Cin], want_dw) < 2e-6
+    if Ctot > Cin:                                       # columns outside the block are untouched
+        keep = torch.ones(Ctot, dtype=torch.bool)
+        keep[wcol:wcol + Cin] = False
+        assert bool((dw[:, keep.to(DEV)] == 7.0).all())
+    # the generic pair
+    wsub_c = w2[:, wcol:wcol + Cin].contiguous()
+    dx2 = ops.mlp_gemm(wsub_c, dz, pro=2, X2=y, coef=coef4, tag="dgrad")[0]
+    dw2 = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef)
+    assert _rel(dx, dx2) < 2e-6 and _rel(dw[:, wcol:wcol + Cin], dw2) < 2e-6
+    dx3, dw3 = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol=wcol, dw_out=torch.full((Cout, Ctot), 7.0, device=DEV))
+    assert torch.equal(dx3, dx) and torch.equal(dw3, dw)

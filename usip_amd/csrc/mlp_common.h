@@ -216,6 +216,8 @@ __device__ __forceinline__ void wgrad_store_partial(const WgradArgs& a, f32x16 (
 // bf16-multiply variants (shared_mlp_bf16.hip); same argument blocks, same outputs up to operand rounding
 int launch_gemm_bf16(const GemmArgs& a, int pro, hipStream_t st);
 int launch_wgrad_bf16(const WgradArgs& a, int pro, bool xpro, bool vec, int small, unsigned blocks, hipStream_t st);
+int launch_wgrad_reduce(const float* part, float* dW, long long elems, int slices, int N, int ldw, int coloff,
+                        hipStream_t st);
 // fp32-accurate products out of three bf16 planes per operand (128 x 128 tiles only; see shared_mlp_bf16.hip)
 int launch_gemm_x3(const GemmArgs& a, int pro, hipStream_t st);
 int launch_wgrad_x3(const WgradArgs& a, int pro, bool xpro, bool vec, unsigned blocks, hipStream_t st);

@@ -687,6 +687,16 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
 
 }  // namespace
 
+// fixed-order sum of weight-gradient partial tiles, for the other translation units of the shared MLP
+int usip_mlp::launch_wgrad_reduce(const float* part, float* dW, long long elems, int slices, int N, int ldw, int coloff,
+                                  hipStream_t st)
+{
+    USIP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st, part, dW, elems, slices, N,
+                ldw, coloff);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
 // ================================================================================================
 extern "C" int usip_mlp_gemm_tiles(int M, int P, int nb)
 {

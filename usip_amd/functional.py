@@ -22,6 +22,11 @@ GRAD_SINK = False
 DEFER_BN_COUNTERS = False
 
 
+# Narrow layers (64 inputs, 64 / 128 outputs) run their backward as ONE fused kernel (csrc/narrow_bwd.hip) instead of a
+# data-gradient and a weight-gradient GEMM that each re-read (dZ, Y).  Same arithmetic class (exact fp32 MFMA).
+FUSED_NARROW_BWD = True
+
+
 # Set by the training step for the duration of forward + backward: {weight.data_ptr(): K-major copy [Cin, Cout]}
 # made for ALL layers by one launch (ops.multi_transpose) after the last parameter update.  None: every layer
 # transposes its own weight (any caller outside the step).
@@ -331,6 +336,14 @@ class _SharedMLPLayer(torch.autograd.Function):
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
         x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
+        if (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
+                and ops.narrow_backward_supported(x.shape[1], w2.shape[0], x.shape[2])):
+            dx, dw = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
+                                             dw_out=sink[0].view(w2.shape) if sink else None)
+            db = torch.zeros_like(gamma) if (ctx.needs_input_grad[3] and not sink) else None
+            if sink:
+                dw = db = dgamma = dbeta = None
+            return (dx, None, dw, db, dgamma, dbeta) + tail
         dx = None
         if need_x:
             pre = ctx.nograd_prefix
@@ -485,9 +498,16 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         dpooled = dh = dw = None
         if ctx.needs_input_grad[3]:
             dpooled = ops.mlp_gemm(w2c, sdy, tag="dgrad_pooled", M=Cp, a_offset=poff)[0]
-        if ctx.needs_input_grad[0]:
+        fused = (FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[4] and ctx.relu
+                 and ops.narrow_backward_supported(Ch, Cout, M * K))
+        if fused:                                           # data and weight gradient of the feature half in one pass
+            dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
+            dh, _ = ops.mlp_narrow_backward(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch)
+            dh = dh.view(ctx.h_shape)
+            ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
+        if ctx.needs_input_grad[0] and not fused:
             dh = _dgrad(h3, w2c, dz, pro=2, X2=y, coef=coef4, M=Ch, a_offset=hoff).view(ctx.h_shape)
-        if ctx.needs_input_grad[4]:
+        if ctx.needs_input_grad[4] and not fused:
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
             ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff, xcoef=hcoef)
             ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)

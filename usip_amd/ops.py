@@ -447,6 +447,34 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     return dW
 
 
+def narrow_backward_supported(Cin: int, Cout: int, P: int) -> bool:
+    return _matmul_mode != "bf16" and bool(_lib.lib().usip_mlp_narrow_backward_supported(int(Cin), int(Cout), int(P)))
+
+
+def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64):
+    """Fused backward of a narrow layer (csrc/narrow_bwd.hip): -> (dx [nb,Cin,P], dW).
+    dz, y [nb,Cout,P]; x [nb,Cin,P]; w2 [Cout, Ctot] contiguous, the layer's inputs are its columns [wcol, wcol+Cin);
+    dw_out ([Cout, Ctot] contiguous) receives the weight gradient in the same columns."""
+    nb, Cout, P = dz.shape
+    dev = dz.device
+    for t, n in ((dz, "dz"), (y, "y"), (x, "x"), (w2, "w2"), (coef4, "coef4")):
+        _need(t, n, torch.float32)
+    ldw = w2.shape[1]
+    dW = dw_out if dw_out is not None else torch.empty_like(w2)
+    dx = torch.empty((nb, Cin, P), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(_lib.lib().usip_mlp_narrow_backward_workspace(Cout, P, nb)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("shared_mlp_narrow_bwd %dx%d" % (Cout, Cin),
+                                             4.0 * nb * P * (2 * Cout + 2 * Cin), 4.0 * Cout * Cin * nb * P,
+                                             rocprof_key="narrow_bwd_kernel<%d, %s> |wg=%d" % (
+                                                 Cout, "true" if xcoef is not None else "false", ws.numel() // (Cout * 64))):
+        _lib.check(_lib.lib().usip_mlp_narrow_backward_f32(
+            _ptr(dz), _ptr(y), _ptr(coef4), _ptr(x), int(x.shape[1]), _opt(xcoef),
+            ctypes.c_void_p(w2.data_ptr() + 4 * int(wcol)), int(ldw), _ptr(dx), Cin, _ptr(ws),
+            ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)), int(dW.shape[1]), Cin, Cout, P, nb, _stream(dz)),
+            "usip_mlp_narrow_backward_f32")
+    return dx, dW
+
+
 # --------------------------------------------------------------------------- grouping / pooling
 def group_gather(x, idx32, sub=None, out=None, coff: int = 0):
     """out[b, coff+c, m, k] = x[b, c, idx[b,m,k]] - (c < nsub ? sub[b,c,m] : 0).  x [B,C,N], idx i32 [B,M,K],
