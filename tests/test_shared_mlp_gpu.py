@@ -224,3 +224,71 @@ def test_fused_narrow_backward_equals_separate_products(cfg):
     assert _rel(dx, dx2) < 2e-6 and _rel(dw[:, wcol:wcol + Cin], dw2) < 2e-6
     dx3, dw3 = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol=wcol, dw_out=torch.full((Cout, Ctot), 7.0, device=DEV))
     assert torch.equal(dx3, dx) and torch.equal(dw3, dw)
+
+
+@pytest.mark.parametrize("Cout", [64, 128])
+def test_fused_narrow_backward_takes_the_producers_bn_sums(Cout):
+    """want_red: the BatchNorm-backward sums of the layer that PRODUCED X, taken by the fused kernel on its way out
+    (dX tile in registers, X tile in LDS), must give the same dgamma / dbeta / coef4 as that layer's own reduction
+    pass over (dX, X) -- also when a sparse max-pool gradient is added on top (sums are linear in the gradient)."""
+    from usip_amd import ops
+    nb, Cin, P, K = 2, 64, 4096, 64
+    g = torch.Generator().manual_seed(Cout)
+    dz = torch.randn(nb, Cout, P, generator=g).to(DEV)
+    y = torch.randn(nb, Cout, P, generator=g).to(DEV)
+    x = torch.randn(nb, Cin, P, generator=g).to(DEV)                       # pre-BN output of the producing layer
+    w2 = (torch.randn(Cout, Cin, generator=g) * 0.2).to(DEV)
+    coef4 = torch.stack([1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g),
+                         0.05 * torch.randn(Cout, generator=g), 0.05 * torch.randn(Cout, generator=g)]).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(Cin, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(Cin, generator=g)).to(DEV)
+    mean, var = x.mean((0, 2)), x.var((0, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    xcoef = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).contiguous()
+    dx, _, red = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, want_red=True)
+    dg, db, c4 = ops.bn_backward_from_partials(red, nb * P, xcoef, mean.contiguous(), invstd.contiguous())
+    dg2, db2, c42, _ = ops.bn_backward_reduce(dx, x, xcoef, mean.contiguous(), invstd.contiguous(), gamma, True)
+    for a_, b_, n in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (c4, c42, "coef4")):
+        assert _rel(a_, b_) < 5e-6, (n, _rel(a_, b_))
+    # plus a sparse pooling gradient at the arg-max of the activated producer output
+    M = P // K
+    pooled, arg = ops.group_max_act(x.view(nb, Cin, M, K), xcoef, True)
+    dpooled = torch.randn(nb, Cin, M, generator=g).to(DEV)
+    sparse = ops.bn_pool_backward_partials(dpooled, arg, x.view(nb, Cin, M, K), xcoef, xcoef[2], xcoef[3], True)
+    dg3, db3, c43 = ops.bn_backward_from_partials([red, sparse], nb * P, xcoef, mean.contiguous(), invstd.contiguous())
+    total = ops.group_max_backward_add_(dx.clone().view(nb, Cin, M, K), dpooled, arg).view(nb, Cin, P)
+    dg4, db4, c44, _ = ops.bn_backward_reduce(total, x, xcoef, mean.contiguous(), invstd.contiguous(), gamma, True)
+    for a_, b_, n in ((dg3, dg4, "dgamma"), (db3, db4, "dbeta"), (c43, c44, "coef4")):
+        assert _rel(a_, b_) < 5e-6, (n, _rel(a_, b_))
+
+
+def test_narrow_chain_gradients_do_not_depend_on_the_fused_backward():
+    """conv2 -> conv3 -> (max over K, conv4 on cat(features, max)) -> conv5 + max, the Ball front end's chain, with the
+    fused narrow backward (and the BatchNorm sums it hands upstream) on and off: all gradients agree to rounding."""
+    from usip_amd import functional as Fh
+    from usip_amd import layers
+
+    def run(fused):
+        torch.manual_seed(3)
+        kw = dict(kernel_size=(1, 1), stride=1, padding=0, bias=True, activation="relu", normalization="batch")
+        convs = [layers.MyConv2d(7, 64, **kw), layers.MyConv2d(64, 64, **kw), layers.MyConv2d(64, 64, **kw),
+                 layers.MyConv2d(128, 128, **kw), layers.MyConv2d(128, 128, **kw)]
+        convs = [c_.to(DEV).train() for c_ in convs]
+        g = torch.Generator().manual_seed(8)
+        x = torch.randn(2, 7, 32, 64, generator=g).to(DEV)
+        prev, Fh.FUSED_NARROW_BWD = Fh.FUSED_NARROW_BWD, fused
+        try:
+            h = convs[2](convs[1](convs[0](x, defer=True), defer=True), defer=True)
+            pooled, h = Fh.group_max_fork(h)
+            h = Fh.conv1x1_bn_act_pooled(h, pooled, convs[3].conv.weight, convs[3].conv.bias, convs[3].norm, True,
+                                         pooled_first=False, defer=True)
+            out = Fh.conv1x1_bn_relu_max(h, convs[4].conv.weight, convs[4].conv.bias, convs[4].norm)
+            (out * torch.randn(out.shape, generator=g).to(DEV)).sum().backward()
+        finally:
+            Fh.FUSED_NARROW_BWD = prev
+            Fh.PRE_BN_SUMS.clear()
+        return [p.grad.clone() for c_ in convs for p in c_.parameters()]
+
+    for a_, b_ in zip(run(True), run(False)):
+        if float(b_.abs().max()) > 0:
+            assert _rel(a_, b_) < 2e-5

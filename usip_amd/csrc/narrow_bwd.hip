@@ -24,9 +24,15 @@ struct NarrowArgs {
     float* dX; int dx_rows;                                // [nb][dx_rows][P], rows [0, CIN) written
     float* part;                                           // [nb * segs][COUT][CIN]
     int x_rows, P, nb, seglen, segs;
+    float* red;                                            // RED: [2][nb * segs][CIN] BatchNorm-backward sums of the INPUT layer
 };
 
-template <int COUT, bool XPRO>
+// RED (needs XPRO; xcoef is then the producing layer's [4][CIN] forward coefficients: scale, shift, mean, invstd): the
+// dX this kernel writes is the incoming gradient dZ' of the layer that produced X.  That layer's BatchNorm backward
+// starts with s1 = sum dZ' * [relu on], s2 = sum dZ' * [relu on] * xhat over all positions -- another full pass over
+// (dZ', X) in the generic path.  Here the tile of dX is in registers and the tile of X in LDS, so the sums are
+// accumulated on the way out (one partial pair per workgroup, combined in fixed order by usip_bn_backward_finalize_f32).
+template <int COUT, bool XPRO, bool RED>
 __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
 {
     constexpr int CIN = 64;
@@ -35,7 +41,7 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
     constexpr int Q = BP / 4;                                 // float4 per row of a tile
     constexpr int NG = COUT * Q / 256, NX = CIN * Q / 256;    // float4 per thread per tile: (4, 4) or (4, 2)
     __shared__ __attribute__((aligned(16))) float Gt[BP][LG];  // dY^T
-    __shared__ __attribute__((aligned(16))) float Xt[BP][LX];  // act(X)^T
+    __shared__ __attribute__((aligned(16))) float Xt[BP][LX];  // act(X)^T (RED: X^T raw, activated when read)
     __shared__ __attribute__((aligned(16))) float Ws[COUT][CIN];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             float4 v = rx[i];
-            if (XPRO) {
+            if (XPRO && !RED) {
                 v.x = fmaxf(__builtin_fmaf(v.x, xc[i][0], xc[i][1]), 0.f); v.y = fmaxf(__builtin_fmaf(v.y, xc[i][0], xc[i][1]), 0.f);
                 v.z = fmaxf(__builtin_fmaf(v.z, xc[i][0], xc[i][1]), 0.f); v.w = fmaxf(__builtin_fmaf(v.w, xc[i][0], xc[i][1]), 0.f);
             }
@@ -117,6 +123,13 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
 
     const int c = lane & 31, kr = lane >> 5;
     float* dXb = a.dX + (long long)b * a.dx_rows * a.P;
+    // RED: per-lane coefficients of the lane's input channel in the two roles
+    float wsc = 1.f, wsh = 0.f, rsc = 1.f, rsh = 0.f, rmu = 0.f, ris = 0.f, s1 = 0.f, s2 = 0.f;
+    if (RED) {
+        wsc = a.xcoef[dw_ct * 32 + c]; wsh = a.xcoef[CIN + dw_ct * 32 + c];
+        const int ci = dx_ct * 32 + c;
+        rsc = a.xcoef[ci]; rsh = a.xcoef[CIN + ci]; rmu = a.xcoef[2 * CIN + ci]; ris = a.xcoef[3 * CIN + ci];
+    }
     if (ntile > 0) load_tile(0);
     for (int t = 0; t < ntile; ++t) {
         __syncthreads();                                      // everyone is done with the previous tile's LDS (and Ws is loaded)
@@ -136,18 +149,50 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(orow + 8 * g) = make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+            if (RED) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float xv = Xt[dx_pt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kr][dx_ct * 32 + c];
+                    const float d = (__builtin_fmaf(xv, rsc, rsh) > 0.f) ? acc[r] : 0.f;
+                    s1 += d;
+                    s2 = __builtin_fmaf(d, (xv - rmu) * ris, s2);
+                }
+            }
         }
         if (does_dw) {
             // dW[co][ci] += sum_p dY^T[p][co] * act(X)^T[p][ci]
 #pragma unroll 4
             for (int k = 0; k < BP; k += 2) {
-                const float xb = Xt[k + kr][dw_ct * 32 + c];
+                float xb = Xt[k + kr][dw_ct * 32 + c];
+                if (RED) xb = fmaxf(__builtin_fmaf(xb, wsc, wsh), 0.f);
 #pragma unroll
                 for (int u = 0; u < NDW; ++u) {
                     const int ot = (COUT == 64) ? dw_ot0 : u;
                     acc_dw[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[k + kr][ot * 32 + c], xb, acc_dw[u], 0, 0, 0);
                 }
             }
+        }
+    }
+    if (RED) {
+        // the two half-waves hold the same channel at different positions; then the waves that share an input tile
+        __syncthreads();
+        float* rs = &Gt[0][0];                                // [4 waves][2][32]
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (does_dx && kr == 0) { rs[(wave * 2 + 0) * 32 + c] = s1; rs[(wave * 2 + 1) * 32 + c] = s2; }
+        __syncthreads();
+        if (tid < CIN) {
+            const int ct = tid >> 5, cc = tid & 31;
+            float t1, t2;
+            if (COUT == 64) {                                 // waves ct and ct + 2 own input tile ct
+                t1 = rs[(ct * 2 + 0) * 32 + cc] + rs[((ct + 2) * 2 + 0) * 32 + cc];
+                t2 = rs[(ct * 2 + 1) * 32 + cc] + rs[((ct + 2) * 2 + 1) * 32 + cc];
+            } else {                                          // wave ct alone
+                t1 = rs[(ct * 2 + 0) * 32 + cc];
+                t2 = rs[(ct * 2 + 1) * 32 + cc];
+            }
+            const long long nblk = (long long)a.nb * a.segs;
+            a.red[(long long)blockIdx.x * CIN + tid] = t1;
+            a.red[(nblk + blockIdx.x) * CIN + tid] = t2;
         }
     }
     if (does_dw) {
@@ -194,11 +239,21 @@ extern "C" int usip_mlp_narrow_backward_supported(int Cin, int Cout, int P)
 // with dY = BatchNorm'(ReLU'(dZ)) rebuilt from (dZ, Y, coef4) as in usip_mlp_gemm_f32 (pro = 2) and
 // act(X) = relu(X * xcoef[0] + xcoef[1]) (xcoef may be NULL: X is used as is).  X points at the first of the 64 input
 // rows inside a [nb][x_rows][P] tensor, dX likewise inside [nb][dx_rows][P]; all pointers 16-B aligned.
+// red_partial (may be NULL; needs xcoef = the producing layer's [4][64] forward coefficients): receives
+// [2][usip_mlp_narrow_backward_blocks(P, nb)][64] partial BatchNorm-backward sums of dX against X (see RED above).
+extern "C" int usip_mlp_narrow_backward_blocks(int P, int nb)
+{
+    int seglen, segs;
+    narrow_plan(P, nb, &seglen, &segs);
+    return nb * segs;
+}
+
 extern "C" int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, const float* coef4, const float* X,
                                             int x_rows, const float* xcoef, const float* W, int ldw, float* dX,
-                                            int dx_rows, float* workspace, float* dW, int lddw, int Cin, int Cout,
-                                            int P, int nb, void* stream)
+                                            int dx_rows, float* workspace, float* dW, int lddw, float* red_partial,
+                                            int Cin, int Cout, int P, int nb, void* stream)
 {
+    if (red_partial && !xcoef) return USIP_EINVAL;
     if (!usip_mlp_narrow_backward_supported(Cin, Cout, P) || nb < 1 || x_rows < Cin || dx_rows < Cin || ldw < Cin ||
         lddw < Cin)
         return USIP_EINVAL;
@@ -208,15 +263,17 @@ extern "C" int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, con
         return USIP_EINVAL;
     int seglen, segs;
     narrow_plan(P, nb, &seglen, &segs);
-    NarrowArgs a{dZ, Y, coef4, X, xcoef, W, ldw, dX, dx_rows, workspace, x_rows, P, nb, seglen, segs};
+    NarrowArgs a{dZ, Y, coef4, X, xcoef, W, ldw, dX, dx_rows, workspace, x_rows, P, nb, seglen, segs, red_partial};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(nb * segs)), block(256);
     if (Cout == 64) {
-        if (xcoef) USIP_LAUNCH((narrow_bwd_kernel<64, true>), grid, block, 0, st, a);
-        else USIP_LAUNCH((narrow_bwd_kernel<64, false>), grid, block, 0, st, a);
+        if (red_partial) USIP_LAUNCH((narrow_bwd_kernel<64, true, true>), grid, block, 0, st, a);
+        else if (xcoef) USIP_LAUNCH((narrow_bwd_kernel<64, true, false>), grid, block, 0, st, a);
+        else USIP_LAUNCH((narrow_bwd_kernel<64, false, false>), grid, block, 0, st, a);
     } else {
-        if (xcoef) USIP_LAUNCH((narrow_bwd_kernel<128, true>), grid, block, 0, st, a);
-        else USIP_LAUNCH((narrow_bwd_kernel<128, false>), grid, block, 0, st, a);
+        if (red_partial) USIP_LAUNCH((narrow_bwd_kernel<128, true, true>), grid, block, 0, st, a);
+        else if (xcoef) USIP_LAUNCH((narrow_bwd_kernel<128, true, false>), grid, block, 0, st, a);
+        else USIP_LAUNCH((narrow_bwd_kernel<128, false, false>), grid, block, 0, st, a);
     }
     USIP_LAUNCH_CHECK();
     return usip_mlp::launch_wgrad_reduce(workspace, dW, (long long)Cout * Cin, nb * segs, Cin, lddw, 0, st);

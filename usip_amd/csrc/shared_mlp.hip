@@ -685,6 +685,50 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
     (void)gamma;
 }
 
+// The same finalisation for partial sums with MANY rows per channel (one row per workgroup of the fused narrow
+// backward: ~1000): 16 row groups x 64 channels per workgroup, every thread sums its rows in double with four
+// independent chains, the 16 group sums are combined in a fixed order.  (bn_bwd_finalize_kernel walks the rows with one
+// thread per channel: 283 us for 1024 rows.)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
+    const float* __restrict__ partial, int rows, int C, double count, const float* __restrict__ coef_fwd,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, float* __restrict__ coef4)
+{
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + cl;
+    const long long plane = (long long)rows * C;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    if (ch < C) {
+        const int per = (rows + 15) / 16, r0 = grp * per, r1 = min(rows, r0 + per);
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            a0 += (double)partial[(long long)r * C + ch];           b0 += (double)partial[plane + (long long)r * C + ch];
+            a1 += (double)partial[(long long)(r + 1) * C + ch];     b1 += (double)partial[plane + (long long)(r + 1) * C + ch];
+            a2 += (double)partial[(long long)(r + 2) * C + ch];     b2 += (double)partial[plane + (long long)(r + 2) * C + ch];
+            a3 += (double)partial[(long long)(r + 3) * C + ch];     b3 += (double)partial[plane + (long long)(r + 3) * C + ch];
+        }
+        for (; r < r1; ++r) { a0 += (double)partial[(long long)r * C + ch]; b0 += (double)partial[plane + (long long)r * C + ch]; }
+    }
+    red[0][grp][cl] = (a0 + a1) + (a2 + a3);
+    red[1][grp][cl] = (b0 + b1) + (b2 + b3);
+    __syncthreads();
+    if (grp == 0 && ch < C) {
+        double s1 = 0, s2 = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) { s1 += red[0][g][cl]; s2 += red[1][g][cl]; }
+        if (dbeta) dbeta[ch] = (float)s1;
+        if (dgamma) dgamma[ch] = (float)s2;
+        const float a1f = coef_fwd[ch], a0f = coef_fwd[C + ch];
+        const float is = invstd[ch], mu = mean[ch];
+        const float c1m = (float)(s1 / count), c2m = (float)(s2 / count);
+        coef4[ch] = a1f;
+        coef4[C + ch] = a0f;
+        coef4[2 * C + ch] = -a1f * c2m * is;
+        coef4[3 * C + ch] = a1f * (c2m * is * mu - c1m);
+    }
+}
+
 }  // namespace
 
 // fixed-order sum of weight-gradient partial tiles, for the other translation units of the shared MLP
@@ -998,8 +1042,23 @@ extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int3
     USIP_LAUNCH(bn_bwd_pool_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dpooled, arg, Y, coef_fwd, mean,
                 invstd, partial, relu, C, M, K, (int)rows);
     USIP_LAUNCH_CHECK();
+    if (!dgamma && !dbeta && !coef4) return USIP_OK;          // partial sums only (combined by usip_bn_backward_finalize_f32)
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
                 (double)nb * (double)M * (double)K, gamma, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+// dgamma, dbeta and the BatchNorm-backward coefficients from partial sums produced elsewhere (the fused narrow
+// backward, usip_bn_pool_backward_reduce_f32 with NULL outputs): partial = [2][rows][C] (s1 rows, then s2 rows), summed
+// over `rows` in order, in double.  count = elements per channel the statistics were taken over.
+extern "C" int usip_bn_backward_finalize_f32(const float* partial, int rows, int C, long long count,
+                                             const float* coef_fwd, const float* mean, const float* invstd,
+                                             float* dgamma, float* dbeta, float* coef4, void* stream)
+{
+    if (!partial || rows < 1 || C < 1 || count < 1 || !coef_fwd || !mean || !invstd || !coef4) return USIP_EINVAL;
+    USIP_LAUNCH(bn_bwd_finalize_rows_kernel, dim3(usip_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial,
+                rows, C, (double)count, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

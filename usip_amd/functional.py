@@ -25,6 +25,13 @@ DEFER_BN_COUNTERS = False
 # Narrow layers (64 inputs, 64 / 128 outputs) run their backward as ONE fused kernel (csrc/narrow_bwd.hip) instead of a
 # data-gradient and a weight-gradient GEMM that each re-read (dZ, Y).  Same arithmetic class (exact fp32 MFMA).
 FUSED_NARROW_BWD = True
+# ... and take the BatchNorm-backward sums of the layer that produced their input on the way out (PRE_BN_SUMS below)
+FUSED_NARROW_RED = True
+import os as _os                                             # noqa: E402
+if _os.environ.get("USIP_NARROW_BWD") is not None:           # A/B measurement switches (tools/)
+    FUSED_NARROW_BWD = _os.environ["USIP_NARROW_BWD"] not in ("0", "off")
+if _os.environ.get("USIP_NARROW_RED") is not None:
+    FUSED_NARROW_RED = _os.environ["USIP_NARROW_RED"] not in ("0", "off")
 
 
 # Set by the training step for the duration of forward + backward: {weight.data_ptr(): K-major copy [Cin, Cout]}
@@ -242,11 +249,23 @@ def as_tensor(x):
     return x.materialize() if isinstance(x, LazyAct) else x
 
 
+# BatchNorm-backward partial sums that the kernel PRODUCING a gradient tensor already took (the fused narrow backward
+# has the tile of dX in registers and the tile of the producing layer's pre-BN output in LDS):
+#   {dz.data_ptr(): (shape of dz, [partials [2, rows, C], ...])}
+# The layer that receives that tensor as its incoming gradient then skips its own pass over (dZ, Y).  Entries are
+# consumed by the receiver; the training step clears the table at the start of every step.
+PRE_BN_SUMS = {}
+
+
 def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
-    """(dgamma, dbeta, coef4[, gsum]) of this layer by the stand-alone reduction pass over (dZ, y).
-    (Folding these sums into the consuming layer's data-gradient GEMM epilogue was implemented and measured
-    slower -- the dgrad GEMMs are MFMA-bound and their epilogue is not overlapped -- and removed)"""
+    """(dgamma, dbeta, coef4[, gsum]) of this layer: from partial sums its gradient's producer already took
+    (PRE_BN_SUMS), else by the stand-alone reduction pass over (dZ, y).
+    (Folding these sums into the consuming layer's data-gradient GEMM epilogue for the MFMA-bound layers was
+    implemented and measured slower -- their epilogue is not overlapped -- and removed)"""
     go, bo = (sink[2], sink[3]) if sink else (None, None)
+    pre = PRE_BN_SUMS.pop(dz.data_ptr(), None) if (group == 0 and relu) else None
+    if pre is not None and pre[0] == tuple(dz.shape):
+        return ops.bn_backward_from_partials(pre[1], dz.shape[0] * dz.shape[2], coef, mean, invstd, go, bo)
     dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, relu, group=group,
                                                         dgamma_out=go, dbeta_out=bo)
     return (dgamma, dbeta, coef4, gsum) if group else (dgamma, dbeta, coef4)
@@ -338,8 +357,12 @@ class _SharedMLPLayer(torch.autograd.Function):
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
         if (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
                 and ops.narrow_backward_supported(x.shape[1], w2.shape[0], x.shape[2])):
-            dx, dw = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
-                                             dw_out=sink[0].view(w2.shape) if sink else None)
+            red = FUSED_NARROW_RED and xcoef is not None and xcoef.shape[0] >= 4   # input = lazy activation of a train-mode BN layer
+            res = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
+                                          dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
+            dx, dw = res[0], res[1]
+            if red:
+                PRE_BN_SUMS[dx.data_ptr()] = (tuple(dx.shape), [res[2]])
             db = torch.zeros_like(gamma) if (ctx.needs_input_grad[3] and not sink) else None
             if sink:
                 dw = db = dgamma = dbeta = None
@@ -502,8 +525,11 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
                  and ops.narrow_backward_supported(Ch, Cout, M * K))
         if fused:                                           # data and weight gradient of the feature half in one pass
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
-            dh, _ = ops.mlp_narrow_backward(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch)
-            dh = dh.view(ctx.h_shape)
+            red = FUSED_NARROW_RED and hcoef is not None and hcoef.shape[0] >= 4
+            res = ops.mlp_narrow_backward(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch, want_red=red)
+            if red:
+                PRE_BN_SUMS[res[0].data_ptr()] = (tuple(res[0].shape), [res[2]])
+            dh = res[0].view(ctx.h_shape)
             ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
         if ctx.needs_input_grad[0] and not fused:
             dh = _dgrad(h3, w2c, dz, pro=2, X2=y, coef=coef4, M=Ch, a_offset=hoff).view(ctx.h_shape)
@@ -622,23 +648,32 @@ class _GroupMaxActFork(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y4, coef, relu):
         pooled, arg = _pooled_act(y4.contiguous(), coef, relu)
-        ctx.save_for_backward(arg)
+        ctx.save_for_backward(arg, y4, coef)
         ctx.K = y4.shape[3]
+        ctx.relu = bool(relu)
         ctx.set_materialize_grads(False)
         return pooled, y4.view_as(y4)
 
     @staticmethod
     def backward(ctx, dpooled, dy):
-        (arg,) = ctx.saved_tensors
+        arg, y4, coef = ctx.saved_tensors
         if dpooled is None:
             return dy, None, None
         if dy is None:
             return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K), None, None
+        pre = PRE_BN_SUMS.pop(dy.data_ptr(), None)            # sums the producer of dy took for the dense part
         # Inside the training step (GRAD_SINK: no hooks, no retained graph, one consumer) dy is the data gradient the
         # consuming layer just produced for this node alone, so it is updated in place; anywhere else autograd may
         # share that buffer (retain_grad, hooks, a second consumer), so the sum goes into a private copy
         dy = dy.contiguous() if GRAD_SINK else dy.clone(memory_format=torch.contiguous_format)
-        return ops.group_max_backward_add_(dy, dpooled.contiguous(), arg), None, None
+        dpooled = dpooled.contiguous()
+        out = ops.group_max_backward_add_(dy, dpooled, arg)
+        if pre is not None and coef.shape[0] >= 4 and pre[0][0] == y4.shape[0] and pre[0][1] == y4.shape[1]:
+            # the sums are linear in the gradient: add those of the sparse pooling part (B*C*M elements)
+            sparse = ops.bn_pool_backward_partials(dpooled, arg, y4, coef, coef[2], coef[3], ctx.relu)
+            B, C, M, K = y4.shape
+            PRE_BN_SUMS[out.data_ptr()] = ((B, C, M * K), pre[1] + [sparse])
+        return out, None, None
 
 
 def group_max_fork(z):

@@ -451,10 +451,12 @@ def narrow_backward_supported(Cin: int, Cout: int, P: int) -> bool:
     return _matmul_mode != "bf16" and bool(_lib.lib().usip_mlp_narrow_backward_supported(int(Cin), int(Cout), int(P)))
 
 
-def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64):
-    """Fused backward of a narrow layer (csrc/narrow_bwd.hip): -> (dx [nb,Cin,P], dW).
+def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64, want_red: bool = False):
+    """Fused backward of a narrow layer (csrc/narrow_bwd.hip): -> (dx [nb,Cin,P], dW[, red]).
     dz, y [nb,Cout,P]; x [nb,Cin,P]; w2 [Cout, Ctot] contiguous, the layer's inputs are its columns [wcol, wcol+Cin);
-    dw_out ([Cout, Ctot] contiguous) receives the weight gradient in the same columns."""
+    dw_out ([Cout, Ctot] contiguous) receives the weight gradient in the same columns.
+    want_red (xcoef = the producing layer's [4,Cin] forward coefficients): also returns red [2, blocks, Cin], partial
+    BatchNorm-backward sums of the producing layer against dx (see bn_backward_from_partials)."""
     nb, Cout, P = dz.shape
     dev = dz.device
     for t, n in ((dz, "dz"), (y, "y"), (x, "x"), (w2, "w2"), (coef4, "coef4")):
@@ -463,6 +465,11 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
     dW = dw_out if dw_out is not None else torch.empty_like(w2)
     dx = torch.empty((nb, Cin, P), dtype=torch.float32, device=dev)
     ws = torch.empty(int(_lib.lib().usip_mlp_narrow_backward_workspace(Cout, P, nb)), dtype=torch.float32, device=dev)
+    red = None
+    if want_red:
+        if xcoef is None or xcoef.shape[0] < 4:
+            raise RuntimeError("mlp_narrow_backward: want_red needs the producing layer's [4, Cin] coefficients")
+        red = torch.empty((2, int(_lib.lib().usip_mlp_narrow_backward_blocks(P, nb)), Cin), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("shared_mlp_narrow_bwd %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * (2 * Cout + 2 * Cin), 4.0 * Cout * Cin * nb * P,
                                              rocprof_key="narrow_bwd_kernel<%d, %s> |wg=%d" % (
@@ -470,9 +477,39 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
         _lib.check(_lib.lib().usip_mlp_narrow_backward_f32(
             _ptr(dz), _ptr(y), _ptr(coef4), _ptr(x), int(x.shape[1]), _opt(xcoef),
             ctypes.c_void_p(w2.data_ptr() + 4 * int(wcol)), int(ldw), _ptr(dx), Cin, _ptr(ws),
-            ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)), int(dW.shape[1]), Cin, Cout, P, nb, _stream(dz)),
+            ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)), int(dW.shape[1]), _opt(red), Cin, Cout, P, nb, _stream(dz)),
             "usip_mlp_narrow_backward_f32")
-    return dx, dW
+    return (dx, dW, red) if want_red else (dx, dW)
+
+
+def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bool):
+    """Partial BatchNorm-backward sums [2, nb, C] of a gradient that is dpooled at the arg-max positions and zero
+    elsewhere (the sparse half of a layer output that feeds a max-pool AND another layer)."""
+    nb, C, M, K = Y4.shape
+    partial = torch.empty((2, nb, C), dtype=torch.float32, device=Y4.device)
+    with torch.cuda.device(Y4.device), prof.kernel("bn_backward_reduce_pooled", 4.0 * nb * C * M * 3):
+        _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _ptr(coef_fwd),
+                                                               _ptr(mean), _ptr(invstd), None, int(bool(relu)),
+                                                               _ptr(partial), None, None, None, nb, C, M, K,
+                                                               _stream(Y4)), "usip_bn_pool_backward_reduce_f32")
+    return partial
+
+
+def bn_backward_from_partials(partials, count: int, coef_fwd, mean, invstd, dgamma_out=None, dbeta_out=None):
+    """(dgamma, dbeta, coef4) from partial sums [2, rows, C] (one tensor or a list of them: all are summed)."""
+    if isinstance(partials, (list, tuple)):
+        partials = torch.cat(list(partials), dim=1).contiguous() if len(partials) > 1 else partials[0]
+    _, rows, C = partials.shape
+    dev = partials.device
+    dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
+    coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev), prof.kernel("bn_backward_finalize", 8.0 * rows * C):
+        _lib.check(_lib.lib().usip_bn_backward_finalize_f32(_ptr(partials), int(rows), int(C), int(count), _ptr(coef_fwd),
+                                                            _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta),
+                                                            _ptr(coef4), _stream(partials)),
+                   "usip_bn_backward_finalize_f32")
+    return dgamma, dbeta, coef4
 
 
 # --------------------------------------------------------------------------- grouping / pooling

@@ -140,6 +140,7 @@ class _GraphedStep:
                 ops.multi_transpose(self.bucket.flat_param.data, flat_wt, table, tiles)
                 Fh.WT_CACHE = views
             ops.PLANES_CACHE = {}                             # f32x3 mode: every weight operand is split once per step
+            Fh.PRE_BN_SUMS.clear()
             loss = self.forward_losses(batch, epoch)
             loss.backward()
         finally:
