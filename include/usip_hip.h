@@ -227,7 +227,9 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
 /* usip_bn_backward_reduce_f32 for a layer whose output fed ONLY a max over K neighbours: the incoming
  * gradient is (k == arg) ? dpooled : 0, so the sums run over B*C*M arg-max elements instead of B*C*M*K.
  * dpooled f32 / arg i32 [nb][C][M], Y [nb][C][M][K]; outputs as usip_bn_backward_reduce_f32. */
-int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int32_t* arg, const float* Y,
+/* yarg (may be NULL): Y at the arg-max as usip_group_max_act_f32 returned it -- replaces one gathered 4-B read per
+ * neighbourhood; dgamma / dbeta / coef4 all NULL: only the partial sums [2][nb][C] are produced. */
+int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int32_t* arg, const float* Y, const float* yarg,
                                      const float* coef_fwd, const float* mean, const float* invstd,
                                      const float* gamma, int relu, float* partial, float* dgamma, float* dbeta,
                                      float* coef4, int nb, int C, int M, int K, void* stream);
@@ -296,7 +298,8 @@ int usip_group_gather_backward_f32(const float* dout, const int32_t* idx, float*
 int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, long long rows, int K, void* stream);
 /* The same pooling applied to relu?(y*coef[0][c] + coef[1][c]) formed on the fly from a layer's pre-BatchNorm
  * output y [B][C][M][K] (K % 4 == 0, K/4 a power of two <= 64): BN-apply + ReLU + max in ONE pass over y. */
-int usip_group_max_act_f32(const float* y, const float* coef, int relu, float* pooled, int32_t* arg,
+/* yarg (may be NULL): [B][C][M], receives y at the arg-max (the pre-BN value the pooled layer's backward needs). */
+int usip_group_max_act_f32(const float* y, const float* coef, int relu, float* pooled, int32_t* arg, float* yarg,
                            int B, int C, int M, int K, void* stream);
 int usip_group_max_backward_f32(const float* dpooled, const int32_t* arg, float* dz,
                                 long long rows, int K, void* stream);

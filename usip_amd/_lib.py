@@ -49,8 +49,8 @@ SIGNATURES = {
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3_used": ([_int, _int, _int, _int], _int),
     "usip_mlp_wgrad_f32x3_blocks": ([_int, _int, _int, _int], _int),
-    "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p,
-                                          _f32p, _int, _int, _int, _int, _stream], _int),
+    "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
+                                          _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _flt, _flt, _f32p, _f32p, _f32p,
                               _f32p, _f32p, _stream], _int),
     "usip_bn_apply_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
@@ -71,7 +71,7 @@ SIGNATURES = {
                                       _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_backward_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,
                                        _stream], _int),
-    "usip_group_max_act_f32": ([_f32p, _f32p, _int, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
+    "usip_group_max_act_f32": ([_f32p, _f32p, _int, _f32p, _i32p, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_group_gather_f32": ([_f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _int,
                                _stream], _int),
     "usip_group_gather_backward_f32": ([_f32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _int, _stream], _int),

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void group_max_kernel(
 template <int L>
 __global__ __launch_bounds__(256) void group_max4_kernel(
     const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows,
-    const float* __restrict__ coef, int relu, int C, int M)
+    const float* __restrict__ coef, int relu, int C, int M, float* __restrict__ zarg)
 {
     constexpr int RPB = 256 / L, RPT = 4;
     const int sub = threadIdx.x % L;
@@ -104,18 +104,23 @@ __global__ __launch_bounds__(256) void group_max4_kernel(
             w.z = __builtin_fmaf(w.z, s0, s1); w.w = __builtin_fmaf(w.w, s0, s1);
             if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
         }
-        float best = w.x;
-        int bk = sub * 4;
-        if (w.y > best) { best = w.y; bk = sub * 4 + 1; }
-        if (w.z > best) { best = w.z; bk = sub * 4 + 2; }
-        if (w.w > best) { best = w.w; bk = sub * 4 + 3; }
+        float best = w.x, braw = v[j].x;                  // braw: the INPUT value at the arg-max (the pre-BN output when
+        int bk = sub * 4;                                 // coef is given): the pooled layer's backward needs exactly it
+        if (w.y > best) { best = w.y; bk = sub * 4 + 1; braw = v[j].y; }
+        if (w.z > best) { best = w.z; bk = sub * 4 + 2; braw = v[j].z; }
+        if (w.w > best) { best = w.w; bk = sub * 4 + 3; braw = v[j].w; }
 #pragma unroll
         for (int off = L / 2; off > 0; off >>= 1) {
             const float ov = __shfl_xor(best, off);
             const int ok = __shfl_xor(bk, off);
-            if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+            const float orw = __shfl_xor(braw, off);
+            if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
         }
-        if (sub == 0 && row < rows) { pooled[row] = best; arg[row] = bk; }
+        if (sub == 0 && row < rows) {
+            pooled[row] = best;
+            arg[row] = bk;
+            if (zarg) zarg[row] = braw;
+        }
     }
 }
 
@@ -269,7 +274,7 @@ extern "C" int usip_group_gather_backward_f32(const float* dout, const int32_t* 
 }
 
 extern "C" int usip_group_max_act_f32(const float* y, const float* coef, int relu, float* pooled, int32_t* arg,
-                                      int B, int C, int M, int K, void* stream)
+                                      float* yarg, int B, int C, int M, int K, void* stream)
 {
     const long long rows = (long long)B * C * M;
     const int L4 = K / 4;
@@ -282,7 +287,7 @@ extern "C" int usip_group_max_act_f32(const float* y, const float* coef, int rel
         const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));                 \
         if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                           \
         USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, y, pooled, arg, rows, \
-                    coef, relu, C, M);                                                           \
+                    coef, relu, C, M, yarg);                                                     \
     }
     USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
 #undef USIP_GM4
@@ -304,7 +309,7 @@ extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, l
             const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));             \
             if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                       \
             USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows, \
-                        (const float*)nullptr, 0, 1, 1);                                         \
+                        (const float*)nullptr, 0, 1, 1, (float*)nullptr);                        \
         }
         USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
 #undef USIP_GM4

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
     float wsc = 1.f, wsh = 0.f, rsc = 1.f, rsh = 0.f, rmu = 0.f, ris = 0.f, s1 = 0.f, s2 = 0.f;
     if (RED) {
         wsc = a.xcoef[dw_ct * 32 + c]; wsh = a.xcoef[CIN + dw_ct * 32 + c];
-        const int ci = dx_ct * 32 + c;
+        const int ci = (dx_ct & 1) * 32 + c;                  // waves without a dX tile (COUT = 128: 2, 3) stay in range
         rsc = a.xcoef[ci]; rsh = a.xcoef[CIN + ci]; rmu = a.xcoef[2 * CIN + ci]; ris = a.xcoef[3 * CIN + ci];
     }
     if (ntile > 0) load_tile(0);

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(
     const float* __restrict__ dpooled, const int* __restrict__ arg, const float* __restrict__ Y,
     const float* __restrict__ coef, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ partial, int relu, int C, int M, int K, int nrows)
+    float* __restrict__ partial, int relu, int C, int M, int K, int nrows, const float* __restrict__ yarg)
 {
     __shared__ float red[2][4];
     const long long rowid = blockIdx.x;
@@ -641,7 +641,8 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(
     const float* y = Y + rowid * M * K;
     float s1 = 0.f, s2 = 0.f;
     for (int m = threadIdx.x; m < M; m += 256) {
-        const float yv = y[(long long)m * K + arg[rowid * M + m]];
+        // yarg: y at the arg-max, kept by the forward pooling pass (otherwise one 128-B line fetched per 4-B value)
+        const float yv = yarg ? yarg[rowid * M + m] : y[(long long)m * K + arg[rowid * M + m]];
         const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dpooled[rowid * M + m] : 0.f;
         s1 += d;
         s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
@@ -1030,9 +1031,10 @@ extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, cons
 }
 
 extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int32_t* arg, const float* Y,
-                                                const float* coef_fwd, const float* mean, const float* invstd,
-                                                const float* gamma, int relu, float* partial, float* dgamma,
-                                                float* dbeta, float* coef4, int nb, int C, int M, int K, void* stream)
+                                                const float* yarg, const float* coef_fwd, const float* mean,
+                                                const float* invstd, const float* gamma, int relu, float* partial,
+                                                float* dgamma, float* dbeta, float* coef4, int nb, int C, int M,
+                                                int K, void* stream)
 {
     if (nb < 1 || C < 1 || M < 1 || K < 1 || !dpooled || !arg || !Y || !coef_fwd || !mean || !invstd || !partial)
         return USIP_EINVAL;
@@ -1040,7 +1042,7 @@ extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int3
     const long long rows = (long long)nb * C;
     if (rows > 0x7fffffffLL) return USIP_EINVAL;
     USIP_LAUNCH(bn_bwd_pool_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dpooled, arg, Y, coef_fwd, mean,
-                invstd, partial, relu, C, M, K, (int)rows);
+                invstd, partial, relu, C, M, K, (int)rows, yarg);
     USIP_LAUNCH_CHECK();
     if (!dgamma && !dbeta && !coef4) return USIP_OK;          // partial sums only (combined by usip_bn_backward_finalize_f32)
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     //   LDS image of stage kt+1 into the other buffer, (b) re-issues the loads for stage kt+2 into the same
     //   registers.  In-order issue lets ~5 other instructions slip between two 32-cycle MFMAs, so the operand
     //   preparation overlaps the matrix pipe; hipcc interleaves the two streams on its own (pinning the order with
-    //   sched_group_barrier was measured 8-25 % slower and removed).  (Measured by
+    //   sched_group_barrier was measured 8-25 % slower and removed; s_setprio(1) around the MFMAs: no change).  (Measured by
     //   ablation before this structure: MFMA + fragment reads 290 us, + global loads 145 us, + split/LDS writes
     //   110 us -- the three added up, 562-634 us for the 512 x 512 forward.)
     const int c = lane & 31, kh = lane >> 5;

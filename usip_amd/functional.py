@@ -48,9 +48,14 @@ WT_CACHE = None
 PIN_POOL_ARGS = None
 
 
-def _pooled_act(y4, coef, relu):
-    """(max over K of the lazily activated y4 [B,C,M,K], arg-max i32 [B,C,M]); coef None: y4 is already activated."""
-    pooled, arg = ops.group_max_act(y4, coef, relu) if coef is not None else ops.group_max(y4)
+def _pooled_act(y4, coef, relu, want_yarg=False):
+    """(max over K of the lazily activated y4 [B,C,M,K], arg-max i32 [B,C,M][, y4 at the arg-max]); coef None: y4 is
+    already activated."""
+    yarg = None
+    if coef is not None and want_yarg:
+        pooled, arg, yarg = ops.group_max_act(y4, coef, relu, want_yarg=True)
+    else:
+        pooled, arg = ops.group_max_act(y4, coef, relu) if coef is not None else ops.group_max(y4)
     if PIN_POOL_ARGS is not None:
         arg = PIN_POOL_ARGS.pop(0).to(device=y4.device, dtype=torch.int32).contiguous()
         if tuple(arg.shape) != tuple(y4.shape[:3]):
@@ -58,7 +63,9 @@ def _pooled_act(y4, coef, relu):
         B, C, M, K = y4.shape
         act = ops.bn_apply(y4.view(B, C, M * K), coef, relu).view(B, C, M, K) if coef is not None else y4
         pooled = act.gather(3, arg.long().unsqueeze(3)).squeeze(3).contiguous()
-    return pooled, arg
+        if want_yarg:
+            yarg = y4.gather(3, arg.long().unsqueeze(3)).squeeze(3).contiguous()
+    return (pooled, arg, yarg) if want_yarg else (pooled, arg)
 
 
 # Second test hook, same purpose: ReLU decisions.  A pre-activation within rounding distance of zero is "on" in one
@@ -408,20 +415,20 @@ class _SharedMLPLayerMax(torch.autograd.Function):
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum, running_mean, running_var)
         if PIN_RELU_FIX is not None:
             y = _align_relu_decisions(y, coef)
-        pooled, arg = _pooled_act(y.view(B, Cout, M, K), coef, True)
-        ctx.save_for_backward(x3, xcoef, w2, y, coef, mean, invstd, gamma, arg)
+        pooled, arg, yarg = _pooled_act(y.view(B, Cout, M, K), coef, True, want_yarg=True)
+        ctx.save_for_backward(x3, xcoef, w2, y, coef, mean, invstd, gamma, arg, yarg)
         ctx.dims, ctx.sink, ctx.x_shape = (B, Cin, Cout, M, K), sink, tuple(x.shape)
         return pooled
 
     @staticmethod
     def backward(ctx, dpooled):
-        x3, xcoef, w2, y, coef, mean, invstd, gamma, arg = ctx.saved_tensors
+        x3, xcoef, w2, y, coef, mean, invstd, gamma, arg, yarg = ctx.saved_tensors
         B, Cin, Cout, M, K = ctx.dims
         sink = ctx.sink
         dpooled = dpooled.contiguous()
         dgamma, dbeta, coef4 = ops.bn_pool_backward_reduce(dpooled, arg, y.view(B, Cout, M, K), coef, mean, invstd,
                                                            gamma, True, dgamma_out=sink[2] if sink else None,
-                                                           dbeta_out=sink[3] if sink else None)
+                                                           dbeta_out=sink[3] if sink else None, yarg=yarg)
         pool = (dpooled, arg, K)
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -647,8 +654,8 @@ class _GroupMaxActFork(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y4, coef, relu):
-        pooled, arg = _pooled_act(y4.contiguous(), coef, relu)
-        ctx.save_for_backward(arg, y4, coef)
+        pooled, arg, yarg = _pooled_act(y4.contiguous(), coef, relu, want_yarg=True)
+        ctx.save_for_backward(arg, y4, coef, yarg)
         ctx.K = y4.shape[3]
         ctx.relu = bool(relu)
         ctx.set_materialize_grads(False)
@@ -656,7 +663,7 @@ class _GroupMaxActFork(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpooled, dy):
-        arg, y4, coef = ctx.saved_tensors
+        arg, y4, coef, yarg = ctx.saved_tensors
         if dpooled is None:
             return dy, None, None
         if dy is None:
@@ -670,7 +677,7 @@ class _GroupMaxActFork(torch.autograd.Function):
         out = ops.group_max_backward_add_(dy, dpooled, arg)
         if pre is not None and coef.shape[0] >= 4 and pre[0][0] == y4.shape[0] and pre[0][1] == y4.shape[1]:
             # the sums are linear in the gradient: add those of the sparse pooling part (B*C*M elements)
-            sparse = ops.bn_pool_backward_partials(dpooled, arg, y4, coef, coef[2], coef[3], ctx.relu)
+            sparse = ops.bn_pool_backward_partials(dpooled, arg, y4, coef, coef[2], coef[3], ctx.relu, yarg=yarg)
             B, C, M, K = y4.shape
             PRE_BN_SUMS[out.data_ptr()] = ((B, C, M * K), pre[1] + [sparse])
         return out, None, None

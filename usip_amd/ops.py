@@ -389,8 +389,9 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
 
 
 def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, relu: bool,
-                            dgamma_out=None, dbeta_out=None):
-    """BN(+ReLU) backward sums for a layer that fed only a max over K: -> (dgamma, dbeta, coef4)."""
+                            dgamma_out=None, dbeta_out=None, yarg=None):
+    """BN(+ReLU) backward sums for a layer that fed only a max over K: -> (dgamma, dbeta, coef4).
+    yarg: Y4 at the arg-max as group_max_act(..., want_yarg=True) returned it (saves the gathers)."""
     nb, C, M, K = Y4.shape
     dev = Y4.device
     partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
@@ -398,10 +399,10 @@ def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, rel
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
     coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("bn_backward_reduce_pooled", 4.0 * nb * C * M * 3):
-        _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _ptr(coef_fwd),
-                                                               _ptr(mean), _ptr(invstd), _opt(gamma), int(bool(relu)),
-                                                               _ptr(partial), _ptr(dgamma), _ptr(dbeta), _ptr(coef4),
-                                                               nb, C, M, K, _stream(Y4)),
+        _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _opt(yarg),
+                                                               _ptr(coef_fwd), _ptr(mean), _ptr(invstd), _opt(gamma),
+                                                               int(bool(relu)), _ptr(partial), _ptr(dgamma), _ptr(dbeta),
+                                                               _ptr(coef4), nb, C, M, K, _stream(Y4)),
                    "usip_bn_pool_backward_reduce_f32")
     return dgamma, dbeta, coef4
 
@@ -482,16 +483,16 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
     return (dx, dW, red) if want_red else (dx, dW)
 
 
-def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bool):
+def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bool, yarg=None):
     """Partial BatchNorm-backward sums [2, nb, C] of a gradient that is dpooled at the arg-max positions and zero
     elsewhere (the sparse half of a layer output that feeds a max-pool AND another layer)."""
     nb, C, M, K = Y4.shape
     partial = torch.empty((2, nb, C), dtype=torch.float32, device=Y4.device)
     with torch.cuda.device(Y4.device), prof.kernel("bn_backward_reduce_pooled", 4.0 * nb * C * M * 3):
-        _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _ptr(coef_fwd),
-                                                               _ptr(mean), _ptr(invstd), None, int(bool(relu)),
-                                                               _ptr(partial), None, None, None, nb, C, M, K,
-                                                               _stream(Y4)), "usip_bn_pool_backward_reduce_f32")
+        _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _opt(yarg),
+                                                               _ptr(coef_fwd), _ptr(mean), _ptr(invstd), None,
+                                                               int(bool(relu)), _ptr(partial), None, None, None, nb, C,
+                                                               M, K, _stream(Y4)), "usip_bn_pool_backward_reduce_f32")
     return partial
 
 
@@ -553,16 +554,18 @@ def group_max(z):
     return pooled, arg
 
 
-def group_max_act(y4, coef, relu: bool):
-    """max_k relu?(y*coef[0]+coef[1]) straight from a layer's pre-BN output y4 [B,C,M,K] -> (pooled, arg)."""
+def group_max_act(y4, coef, relu: bool, want_yarg: bool = False):
+    """max_k relu?(y*coef[0]+coef[1]) straight from a layer's pre-BN output y4 [B,C,M,K] -> (pooled, arg[, yarg]);
+    yarg = y4 at the arg-max."""
     _need(y4, "y", torch.float32)
     B, C, M, K = y4.shape
     pooled = torch.empty((B, C, M), dtype=torch.float32, device=y4.device)
     arg = torch.empty((B, C, M), dtype=torch.int32, device=y4.device)
+    yarg = torch.empty((B, C, M), dtype=torch.float32, device=y4.device) if want_yarg else None
     with torch.cuda.device(y4.device), prof.kernel("group_max", 4.0 * B * C * M * (K + 2)):
         _lib.check(_lib.lib().usip_group_max_act_f32(_ptr(y4), _ptr(coef), int(bool(relu)), _ptr(pooled), _ptr(arg),
-                                                     B, C, M, K, _stream(y4)), "usip_group_max_act_f32")
-    return pooled, arg
+                                                     _opt(yarg), B, C, M, K, _stream(y4)), "usip_group_max_act_f32")
+    return (pooled, arg, yarg) if want_yarg else (pooled, arg)
 
 
 def group_max_backward(dpooled, arg, K: int):
