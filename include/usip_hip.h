@@ -256,13 +256,13 @@ int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int p
  *   (xcoef NULL: X as is).  X / dX point at the first of the 64 rows inside [nb][x_rows][P] / [nb][dx_rows][P].
  * workspace: usip_mlp_narrow_backward_workspace(Cout, P, nb) floats.
  * red_partial (may be NULL; then xcoef must be the PRODUCING layer's full [4][64] forward coefficients -- scale, shift,
- *   mean, invstd): [2][usip_mlp_narrow_backward_blocks(P, nb)][64] partial BatchNorm-backward sums of that layer
+ *   mean, invstd): [2][usip_mlp_narrow_backward_blocks(Cout, P, nb)][64] partial BatchNorm-backward sums of that layer
  *   (sum dX*[relu on], sum dX*[relu on]*xhat), taken while the dX tile is in registers; usip_bn_backward_finalize_f32
  *   turns partial sums (these, plus usip_bn_pool_backward_reduce_f32's when a max-pool also feeds that layer) into
  *   dgamma / dbeta / coef4 -- the separate reduction pass over (dZ, Y) of that layer disappears. */
 int usip_mlp_narrow_backward_supported(int Cin, int Cout, int P);
 long long usip_mlp_narrow_backward_workspace(int Cout, int P, int nb);
-int usip_mlp_narrow_backward_blocks(int P, int nb);
+int usip_mlp_narrow_backward_blocks(int Cout, int P, int nb);
 int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, const float* coef4, const float* X, int x_rows,
                                  const float* xcoef, const float* W, int ldw, float* dX, int dx_rows,
                                  float* workspace, float* dW, int lddw, float* red_partial, int Cin, int Cout,

@@ -66,7 +66,7 @@ SIGNATURES = {
                               _int, _int, _int, _int, _stream], _int),
     "usip_mlp_narrow_backward_supported": ([_int, _int, _int], _int),
     "usip_mlp_narrow_backward_workspace": ([_int, _int, _int], ctypes.c_longlong),
-    "usip_mlp_narrow_backward_blocks": ([_int, _int], _int),
+    "usip_mlp_narrow_backward_blocks": ([_int, _int, _int], _int),
     "usip_mlp_narrow_backward_f32": ([_f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p,
                                       _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_backward_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,

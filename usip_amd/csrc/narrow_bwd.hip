@@ -211,21 +211,25 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
 
 }  // namespace
 
-// Position segments per cloud of the fused narrow backward (a multiple of 64 positions each).
-static void narrow_plan(int P, int nb, int* seglen, int* segs)
+// Position segments per cloud of the fused narrow backward (a multiple of 64 positions each): as many workgroups as
+// the chip holds AT ONCE (3 per CU at 64 outputs, 2 at 128: LDS), so that the launch is a single round -- with 1024
+// workgroups on 768 slots the second round ran a third full and cost 20 % (MFMA pipe 48 % busy).
+static void narrow_plan(int Cout, int P, int nb, int* seglen, int* segs)
 {
-    long long per_cloud = (1024 + nb - 1) / nb;               // ~4 workgroups per CU
-    long long sl = (P + per_cloud - 1) / per_cloud;
-    sl = ((sl + 63) / 64) * 64;
-    if (sl < 256) sl = 256;
-    *seglen = (int)sl;
-    *segs = (int)((P + sl - 1) / sl);
+    const long long slots = (Cout == 64) ? 768 : 512;
+    long long per_cloud = slots / nb;
+    if (per_cloud < 1) per_cloud = 1;
+    const long long tiles = (P + 63) / 64;
+    long long tps = (tiles + per_cloud - 1) / per_cloud;      // 64-position tiles per segment
+    if (tps < 4) tps = 4;
+    *seglen = (int)(tps * 64);
+    *segs = (int)((P + *seglen - 1) / *seglen);
 }
 
 extern "C" long long usip_mlp_narrow_backward_workspace(int Cout, int P, int nb)
 {
     int seglen, segs;
-    narrow_plan(P, nb, &seglen, &segs);
+    narrow_plan(Cout, P, nb, &seglen, &segs);
     return (long long)nb * segs * Cout * 64;
 }
 
@@ -240,11 +244,11 @@ extern "C" int usip_mlp_narrow_backward_supported(int Cin, int Cout, int P)
 // act(X) = relu(X * xcoef[0] + xcoef[1]) (xcoef may be NULL: X is used as is).  X points at the first of the 64 input
 // rows inside a [nb][x_rows][P] tensor, dX likewise inside [nb][dx_rows][P]; all pointers 16-B aligned.
 // red_partial (may be NULL; needs xcoef = the producing layer's [4][64] forward coefficients): receives
-// [2][usip_mlp_narrow_backward_blocks(P, nb)][64] partial BatchNorm-backward sums of dX against X (see RED above).
-extern "C" int usip_mlp_narrow_backward_blocks(int P, int nb)
+// [2][usip_mlp_narrow_backward_blocks(Cout, P, nb)][64] partial BatchNorm-backward sums of dX against X (see RED above).
+extern "C" int usip_mlp_narrow_backward_blocks(int Cout, int P, int nb)
 {
     int seglen, segs;
-    narrow_plan(P, nb, &seglen, &segs);
+    narrow_plan(Cout, P, nb, &seglen, &segs);
     return nb * segs;
 }
 
@@ -262,7 +266,7 @@ extern "C" int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, con
          reinterpret_cast<uintptr_t>(dX)) & 15u)
         return USIP_EINVAL;
     int seglen, segs;
-    narrow_plan(P, nb, &seglen, &segs);
+    narrow_plan(Cout, P, nb, &seglen, &segs);
     NarrowArgs a{dZ, Y, coef4, X, xcoef, W, ldw, dX, dx_rows, workspace, x_rows, P, nb, seglen, segs, red_partial};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)(nb * segs)), block(256);

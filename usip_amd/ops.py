@@ -470,11 +470,12 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
     if want_red:
         if xcoef is None or xcoef.shape[0] < 4:
             raise RuntimeError("mlp_narrow_backward: want_red needs the producing layer's [4, Cin] coefficients")
-        red = torch.empty((2, int(_lib.lib().usip_mlp_narrow_backward_blocks(P, nb)), Cin), dtype=torch.float32, device=dev)
+        red = torch.empty((2, int(_lib.lib().usip_mlp_narrow_backward_blocks(Cout, P, nb)), Cin), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("shared_mlp_narrow_bwd %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * (2 * Cout + 2 * Cin), 4.0 * Cout * Cin * nb * P,
-                                             rocprof_key="narrow_bwd_kernel<%d, %s> |wg=%d" % (
-                                                 Cout, "true" if xcoef is not None else "false", ws.numel() // (Cout * 64))):
+                                             rocprof_key="narrow_bwd_kernel<%d, %s, %s> |wg=%d" % (
+                                                 Cout, "true" if xcoef is not None else "false",
+                                                 "true" if want_red else "false", ws.numel() // (Cout * 64))):
         _lib.check(_lib.lib().usip_mlp_narrow_backward_f32(
             _ptr(dz), _ptr(y), _ptr(coef4), _ptr(x), int(x.shape[1]), _opt(xcoef),
             ctypes.c_void_p(w2.data_ptr() + 4 * int(wcol)), int(ldw), _ptr(dx), Cin, _ptr(ws),
