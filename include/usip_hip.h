@@ -183,6 +183,8 @@ int usip_mlp_gemm_f32x3_used(int M, int K, int P, int nb);
  * zero padded -- usip_mlp_split3_bytes(M, K) bytes, 16-B aligned.  usip_mlp_gemm_x3p_f32 then has the contract of
  * usip_mlp_gemm_f32 with `planes` in place of (At, lda); K <= 640. */
 int usip_mlp_x3p_tile_rows(int M);                 /* rows per tile (128 or 256): profiling aid */
+/* Positions per tile the same kernel uses for this launch: 128 (256 only under the x3_gemm_tile measurement knob). */
+int usip_mlp_x3p_tile_cols(int M, int P, int nb, int pro, int with_stats);
 long long usip_mlp_split3_bytes(int M, int K);
 int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream);
 int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,

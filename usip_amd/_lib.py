@@ -43,6 +43,7 @@ SIGNATURES = {
                              _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_f32x3_used": ([_int, _int, _int, _int], _int),
     "usip_mlp_x3p_tile_rows": ([_int], _int),
+    "usip_mlp_x3p_tile_cols": ([_int, _int, _int, _int, _int], _int),
     "usip_mlp_split3_bytes": ([_int, _int], ctypes.c_longlong),
     "usip_mlp_split3_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
     "usip_mlp_gemm_x3p_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
@@ -113,6 +114,11 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
+        # measurement knobs for same-box A/B runs: USIP_TUNE="x3_gemm_tile=3,index_max_ch=4" (include/usip_hip.h)
+        for item in filter(None, os.environ.get("USIP_TUNE", "").split(",")):
+            name, _, value = item.partition("=")
+            if l.usip_set_tuning(name.strip().encode(), int(value)) != 0:
+                raise RuntimeError("usip_amd: USIP_TUNE names an unknown knob or value: %r" % item)
         _lib = l
     return _lib
 

@@ -487,6 +487,14 @@ static int launch_x3p(const GemmArgs& a, const uint4* pl, int pro, hipStream_t s
 
 // Y[b] = A . pro(X[b]) + bias (+ rowbias) with A given as the split image of usip_mlp_split3_f32 (same M, K).
 // Contract of usip_mlp_gemm_f32 otherwise; K <= 640, P % 4 == 0 not required.
+extern "C" int usip_mlp_x3p_tile_cols(int M, int P, int nb, int pro, int with_stats)
+{
+    if (usip_mlp_x3p_tile_rows(M) == 128 || with_stats) return 128;
+    const int knob = usip_tuning_value(USIP_TUNE_X3_GEMM_TILE);
+    const long long wide_tiles = (long long)((M + 255) / 256) * ((P + 255) / 256) * nb;
+    return (knob == 4 || (knob == 5 && pro >= 2 && wide_tiles >= 256)) ? 256 : 128;
+}
+
 extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
                                      const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
                                      const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
@@ -508,8 +516,12 @@ extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const f
     hipStream_t st = (hipStream_t)stream;
     const uint4* pl = reinterpret_cast<const uint4*>(planes);
     if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2>(a, pl, pro, st);
-    // measurement only (256-position tiles change the layout of the statistics partials): launches without them
-    if (usip_tuning_value(USIP_TUNE_X3_GEMM_TILE) == 4 && !stats) return launch_x3p<4, 4>(a, pl, pro, st);
+    // 256 x 256 tiles (8 waves, one workgroup per CU) are a measurement option (knob 4: every launch without
+    // statistics -- their partial layout is per 128 positions; 5: data-gradient launches only).  r02r: alone on the
+    // GPU the data-gradient launches gain 8 % (123 -> 113 us at 256 x 256 x 131072), inside the step the same choice
+    // costs 1 % (6.50 vs 6.43 ms, same box, twice) -- half as many, longer workgroups drain worse behind the
+    // neighbouring launches.  8-wave 256 x 128 and 128 x 256 variants (four waves per SIMD) measured equal to this one.
+    if (usip_mlp_x3p_tile_cols(M, P, nb, pro, stats != nullptr) == 256) return launch_x3p<4, 4>(a, pl, pro, st);
     return launch_x3p<4, 2>(a, pl, pro, st);
 }
 

@@ -311,7 +311,9 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
             return "gemm_bf16_kernel<%d, %d, 16, %d, %d, 1> |wg=%d" % (wm, wn, pro, e, tiles * ((M + wm * 64 - 1) // (wm * 64)))
         if x3p:
             bm = _lib.lib().usip_mlp_x3p_tile_rows(M)
-            return "gemm_x3p_kernel<%d, %d, %d, 2> |wg=%d" % (pro, e, bm // 64, nb * ((P + 127) // 128) * ((M + bm - 1) // bm))
+            bn = _lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), e)
+            return "gemm_x3p_kernel<%d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64,
+                                                               nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
         if x3:
             return "gemm_bf16_kernel<2, 2, 16, %d, %d, 3> |wg=%d" % (pro, e, nb * ((P + 127) // 128) * ((M + 127) // 128))
         # csrc/shared_mlp.hip mlp_gemm_impl: 32 rows per wave when 128-row tiles would not fill the chip
