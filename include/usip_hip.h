@@ -91,6 +91,40 @@ int usip_som_assign_f32(const float* x, const float* node, int32_t* min_idx,
  * (networks.py:103-107).  Deterministic (fixed-order) summation. */
 int usip_som_cluster_f32(const float* x, const int32_t* min_idx, float* cluster_mean,
                          int32_t* count, float* x_decentered, int B, int N, int M, void* stream);
+/* The same outputs from min_idx sorted by node (usip_csr_by_index_i32 below with P = N points, N = M nodes):
+ * O(N) per cloud instead of every node scanning all assignments. */
+int usip_som_cluster_csr_f32(const float* x, const int32_t* min_idx, const int32_t* start, const int32_t* perm,
+                             float* cluster_mean, int32_t* count, float* x_decentered, int B, int N, int M,
+                             void* stream);
+
+/* index_max together with what the reference does with its result (models/networks.py:117-118, :130-131:
+ * torch.gather at the arg-max, times mask_row_max): max_val[b,c,k] = count[b,k] > 0 ? data[b,c,max_idx[b,c,k]] : 0
+ * (count NULL: every node counts as populated).  data is the channel slice [0, C) of a [B][Ctot][N] tensor.
+ * max_idx as usip_index_max_f32, bit for bit (same kernel). */
+int usip_index_max_values_f32(const float* data, const int32_t* index, const int32_t* count, int32_t* max_idx,
+                              float* max_val, int B, int C, int Ctot, int N, int K, void* stream);
+/* Backward of that gather + mask, ADDED into an existing dense gradient: ddata[b][coff+c][max_idx[b,c,k]] += g[b,c,k]
+ * for populated nodes.  ddata [B][Ctot][N]. */
+int usip_index_max_values_backward_add_f32(const float* g, const int32_t* max_idx, const int32_t* count, float* ddata,
+                                           int B, int C, int Ctot, int coff, int N, int K, void* stream);
+/* The same gradient as one dense, contiguous tensor: dz[b][c][n] = (src ? src[b][soff+c][n] : 0) + that scatter term,
+ * every element written once (index = the assignment index_max was given; src [B][Csrc][N] or NULL; K <= 8192). */
+int usip_index_max_values_backward_f32(const float* g, const int32_t* max_idx, const int32_t* count,
+                                       const int32_t* index, const float* src, int Csrc, int soff, float* dz,
+                                       int B, int C, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------ a-4 / a-12  index tensors sorted by destination
+ * idx i32 [B][P] with values in [0, N) -> start i32 [B][N+1], perm i32 [B][P]: perm[b][start[b][n] .. start[b][n+1])
+ * are the positions p with idx[b][p] == n (values outside [0, N) are left out; start[b][N] = number placed).
+ * One counting sort per cloud; N <= 1820.  Every scatter-add of the path (torch.gather's backward in
+ * models/layers.py:422-426 and networks.py:119-125, the cluster sums of networks.py:87-107) becomes a gather over
+ * these segments: no float atomics, a fixed summation order. */
+int usip_csr_by_index_i32(const int32_t* idx, int32_t* start, int32_t* perm, int B, int P, int N, void* stream);
+/* dx[b][c][n] = sum_{j in segment n} src[b][coff+c][perm[b][j]]; src [B][Ctot][P], dx [B][C][N] (fully written).
+ * P <= 16384 (a source row is staged in LDS): usip_segment_sum_supported. */
+int usip_segment_sum_supported(int N, int P);
+int usip_segment_sum_f32(const float* src, const int32_t* start, const int32_t* perm, float* dx,
+                         int B, int C, int N, int P, int Ctot, int coff, void* stream);
 
 /* ------------------------------------------------------------------ a-9 / a-10  chamfer core
  * min_d[b,i] = min_j |a[b,:,i] - b[b,:,j]|_2 and arg[b,i] = FIRST j attaining it, exactly what

@@ -26,6 +26,15 @@ SIGNATURES = {
     "usip_pairwise_dist_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
     "usip_som_assign_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_som_cluster_f32": ([_f32p, _i32p, _f32p, _i32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_som_cluster_csr_f32": ([_f32p, _i32p, _i32p, _i32p, _f32p, _i32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_index_max_values_f32": ([_f32p, _i32p, _i32p, _i32p, _f32p, _int, _int, _int, _int, _int, _stream], _int),
+    "usip_index_max_values_backward_add_f32": ([_f32p, _i32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int,
+                                                _stream], _int),
+    "usip_index_max_values_backward_f32": ([_f32p, _i32p, _i32p, _i32p, _f32p, _int, _int, _f32p, _int, _int, _int, _int,
+                                            _stream], _int),
+    "usip_csr_by_index_i32": ([_i32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
+    "usip_segment_sum_supported": ([_int, _int], _int),
+    "usip_segment_sum_f32": ([_f32p, _i32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _stream], _int),
     "usip_nearest_backward_f32": ([_f32p, _f32p, _f32p, _i32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream],
                                   _int),
     "usip_nearest_nd_f32": ([_f32p, _f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),

@@ -13,6 +13,9 @@
 
 namespace {
 
+// (Four points per lane with the nodes read four at a time (ds_read_b128) was tried to cut the LDS reads: 66 us
+// instead of 50 -- the loop is bound by VALU issue (11 instructions per point-node pair, ~43 us at full rate), not by
+// LDS, and one workgroup per CU hides less latency.)
 // One lane per point; the cloud's nodes sit in LDS and are broadcast to all lanes.
 __global__ __launch_bounds__(256) void som_assign_kernel(
     const float* __restrict__ x, const float* __restrict__ node, int32_t* __restrict__ min_idx,
@@ -95,6 +98,40 @@ __global__ __launch_bounds__(256) void som_cluster_kernel(
     }
 }
 
+// cluster_mean / count from the segments of min_idx (networks.py:87-107): one wave per (cloud, node) -- the lanes read
+// the segment's positions coalesced, gather their points, and the wave adds up in double, so the mean is the correctly
+// rounded exact mean whatever the order.
+__global__ __launch_bounds__(256) void som_cluster_csr_kernel(
+    const float* __restrict__ x, const int32_t* __restrict__ start, const int32_t* __restrict__ perm,
+    float* __restrict__ cluster_mean, int32_t* __restrict__ count, int N, int M)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int32_t* st = start + (long long)b * (M + 1);
+    const int32_t* pm = perm + (long long)b * N;
+    const float* xb = x + (long long)b * 3 * N;
+    const int s0 = st[m], s1 = st[m + 1];
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (int j = s0 + lane; j < s1; j += 64) {
+        const int p = pm[j];
+        sx += xb[p]; sy += xb[N + p]; sz += xb[2 * N + p];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_down(sx, off);
+        sy += __shfl_down(sy, off);
+        sz += __shfl_down(sz, off);
+    }
+    if (lane == 0) {
+        const int c = s1 - s0;
+        const float denom = (float)c + 1e-5f;                            // networks.py:95-96
+        float* cm = cluster_mean + (long long)b * 3 * M;
+        cm[m] = (float)sx / denom; cm[M + m] = (float)sy / denom; cm[2 * M + m] = (float)sz / denom;
+        count[(long long)b * M + m] = c;
+    }
+}
+
 __global__ __launch_bounds__(256) void som_decenter_kernel(
     const float* __restrict__ x, const int32_t* __restrict__ min_idx,
     const float* __restrict__ cluster_mean, float* __restrict__ out, int N, int M)
@@ -141,6 +178,28 @@ extern "C" int usip_som_cluster_f32(const float* x, const int32_t* min_idx, floa
     if (x_decentered && N > 0) {
         USIP_LAUNCH(som_decenter_kernel, dim3(usip_ceil_div(N, 256), B), dim3(256), 0, st,
                            x, min_idx, cluster_mean, x_decentered, N, M);
+        USIP_LAUNCH_CHECK();
+    }
+    return USIP_OK;
+}
+
+// The same outputs from the destination-sorted form of min_idx (usip_csr_by_index_i32, csrc/segment.hip): O(N) instead
+// of every node scanning all N assignments.  min_idx is still needed for the decentering.
+extern "C" int usip_som_cluster_csr_f32(const float* x, const int32_t* min_idx, const int32_t* start,
+                                        const int32_t* perm, float* cluster_mean, int32_t* count,
+                                        float* x_decentered, int B, int N, int M, void* stream)
+{
+    if (B < 0 || N < 0 || M < 0) return USIP_EINVAL;
+    if ((long long)B * M == 0) return USIP_OK;
+    if (!start || !perm || !cluster_mean || !count || (N > 0 && !x) || B > 65535) return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    USIP_LAUNCH(som_cluster_csr_kernel, dim3(usip_ceil_div(M, 4), B), dim3(256), 0, st,
+                x, start, perm, cluster_mean, count, N, M);
+    USIP_LAUNCH_CHECK();
+    if (x_decentered && N > 0) {
+        if (!min_idx) return USIP_EINVAL;
+        USIP_LAUNCH(som_decenter_kernel, dim3(usip_ceil_div(N, 256), B), dim3(256), 0, st,
+                    x, min_idx, cluster_mean, x_decentered, N, M);
         USIP_LAUNCH_CHECK();
     }
     return USIP_OK;

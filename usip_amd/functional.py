@@ -34,6 +34,11 @@ if _os.environ.get("USIP_NARROW_RED") is not None:
     FUSED_NARROW_RED = _os.environ["USIP_NARROW_RED"] not in ("0", "off")
 
 
+# Scatter-add backwards (torch.gather's) as sums over destination-sorted segments (csrc/segment.hip) instead of LDS
+# float atomics; USIP_SEGMENT_BWD=0 restores the round-1 kernels for A/B runs.
+SEGMENT_BACKWARD = _os.environ.get("USIP_SEGMENT_BWD", "1") not in ("0", "off")
+
+
 # Set by the training step for the duration of forward + backward: {weight.data_ptr(): K-major copy [Cin, Cout]}
 # made for ALL layers by one launch (ops.multi_transpose) after the last parameter update.  None: every layer
 # transposes its own weight (any caller outside the step).
@@ -714,14 +719,21 @@ class _KnnGroup(torch.autograd.Function):
         out = torch.empty((B, 3 + C, M, K), dtype=torch.float32, device=feat.device)
         ops.group_gather(database.contiguous(), idx32, sub=query.contiguous(), out=out, coff=0)
         ops.group_gather(feat.contiguous(), idx32, out=out, coff=3)
-        ctx.save_for_backward(idx32)
         ctx.dims = (C, N)
+        ctx.csr = SEGMENT_BACKWARD and feat.requires_grad and ops.segment_sum_supported(N, M * K)
+        if ctx.csr:                            # the neighbour lists sorted by the node they point at, for the backward
+            ctx.save_for_backward(*ops.csr_by_index(idx32.view(B, M * K), N))
+        else:
+            ctx.save_for_backward(idx32)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (idx32,) = ctx.saved_tensors
         C, N = ctx.dims
+        if ctx.csr:
+            start, perm = ctx.saved_tensors
+            return ops.segment_sum(dout.contiguous(), start, perm, C, coff=3), None, None, None
+        (idx32,) = ctx.saved_tensors
         return ops.group_gather_backward(dout.contiguous(), idx32, C, N, coff=3), None, None, None
 
 
@@ -731,25 +743,109 @@ class _ClusterBroadcast(torch.autograd.Function):
     through the reproducible LDS scatter of csrc/group.hip instead of ATen's float atomics."""
 
     @staticmethod
-    def forward(ctx, x, idx32):
+    def forward(ctx, x, idx32, start, perm):
         B, C, M = x.shape
         N = idx32.shape[1]
-        ctx.save_for_backward(idx32)
+        ctx.csr = start is not None
+        ctx.save_for_backward(*((start, perm) if ctx.csr else (idx32,)))
         ctx.dims = (C, M)
         return ops.group_gather(x.contiguous(), idx32.view(B, N, 1)).view(B, C, N)
 
     @staticmethod
     def backward(ctx, dout):
-        (idx32,) = ctx.saved_tensors
         C, M = ctx.dims
         B, _, N = dout.shape
-        return ops.group_gather_backward(dout.contiguous().view(B, C, N, 1), idx32.view(B, N, 1), C, M), None
+        if ctx.csr:
+            start, perm = ctx.saved_tensors
+            return ops.segment_sum(dout.contiguous(), start, perm, C), None, None, None
+        (idx32,) = ctx.saved_tensors
+        return ops.group_gather_backward(dout.contiguous().view(B, C, N, 1), idx32.view(B, N, 1), C, M), None, None, None
 
 
-def cluster_broadcast(x, idx32):
-    """x [B,C,M] node features, idx32 i32 [B,N] node of every point -> [B,C,N]."""
+def cluster_broadcast(x, idx32, csr=None):
+    """x [B,C,M] node features, idx32 i32 [B,N] node of every point -> [B,C,N].  csr: (start, perm) of idx32
+    (ops.csr_by_index) when the caller has it -- the backward then sums sorted segments."""
     require_device(x, "cluster_broadcast")
-    return _ClusterBroadcast.apply(x, idx32)
+    if csr is None and SEGMENT_BACKWARD and x.requires_grad and ops.segment_sum_supported(x.shape[2], idx32.shape[1]):
+        csr = ops.csr_by_index(idx32, x.shape[2])
+    start, perm = csr if csr is not None else (None, None)
+    return _ClusterBroadcast.apply(x, idx32, start, perm)
+
+
+class _SomPoolLayer(torch.autograd.Function):
+    """The plain (no BatchNorm, no ReLU) last layer of a SOM PointNet together with what the reference does to its
+    output (models/networks.py:114-133):
+
+        y = conv1x1(x);  idx = index_max(y, min_idx);  y_max = gather(y, idx) * mask_row_max
+        concat:  out = cat(y, gather(y_max, min_idx))          [B, 2C, N]     (first PointNet, :117-125)
+        else  :  out = y_max                                   [B, C, M]      (second PointNet, :130-133)
+
+    as one autograd node: the GEMM writes y into the top rows of the concatenated tensor, index_max emits the masked
+    values with the indices (the winning key already holds the value), the broadcast fills the bottom rows -- no
+    torch.gather, mask multiply or torch.cat launches.  Backward: the broadcast's gradient is a sum over sorted
+    segments (csrc/segment.hip), the gather's gradient is B*C*M elements added INTO the dense gradient of y (for the
+    second PointNet: into zeros), and the layer's own data/weight/bias gradients follow from that tensor."""
+
+    @staticmethod
+    def forward(ctx, x, xcoef, w2, bias, min_idx32, count, start, perm, M, concat, sink):
+        x = x.contiguous()
+        nb, _, N = x.shape
+        C = w2.shape[0]
+        wt = _kmajor(w2)
+        pro = 0 if xcoef is None else 1
+        ctx.set_materialize_grads(False)
+        if concat:
+            out = torch.empty((nb, 2 * C, N), dtype=torch.float32, device=x.device)
+            ops.mlp_gemm(wt, x, bias, pro=pro, coef=xcoef, out=out, out_row_offset=0)
+            idx, val = ops.index_max_values(out, min_idx32, count, M, C=C)
+            ops.group_gather(val, min_idx32.view(nb, N, 1), out=out.view(nb, 2 * C, N, 1), coff=C)
+        else:
+            y, _ = ops.mlp_gemm(wt, x, bias, pro=pro, coef=xcoef)
+            idx, out = ops.index_max_values(y, min_idx32, count, M)
+        ctx.save_for_backward(x, xcoef, w2, idx, count, start, perm, min_idx32)
+        ctx.dims, ctx.concat, ctx.sink = (nb, C, N, int(M)), bool(concat), sink
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, dout, _didx):
+        if dout is None:
+            return (None,) * 11
+        x, xcoef, w2, idx, count, start, perm, min_idx32 = ctx.saved_tensors
+        nb, C, N, M = ctx.dims
+        sink = ctx.sink
+        dout = dout.contiguous()
+        if ctx.concat:
+            g = ops.segment_sum(dout, start, perm, C, coff=C)            # d(y_max): empty nodes have empty segments
+            # dy = the top rows of dout + the gather's scatter term, as the contiguous tensor the GEMMs below read
+            dz = ops.index_max_values_backward(g, idx, count, min_idx32, N, src=dout, soff=0)
+        else:
+            dz = ops.index_max_values_backward(dout, idx, count, min_idx32, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(x, w2.contiguous(), dz, pro=0)
+        if ctx.needs_input_grad[2]:
+            dw = ops.mlp_wgrad(dz, x, xcoef=xcoef, out=sink[0].view(w2.shape) if sink else None)
+        if ctx.needs_input_grad[3]:
+            db = ops.bn_backward_reduce(dz, None, None, None, None, None, False, dbeta_out=sink[1] if sink else None)[1]
+        if sink:
+            dw = db = None
+        return (dx, None, dw, db) + (None,) * 7
+
+
+def som_pool_layer(x, weight, bias, min_idx32, count, csr, M: int, concat: bool):
+    """x [B,Cin,N] (tensor or LazyAct) -> (cat(y, broadcast(y_max)) [B,2C,N] or y_max [B,C,M], index_max i32 [B,C,M])
+    for y = conv1x1(x); see _SomPoolLayer.  csr = ops.csr_by_index(min_idx32, M)."""
+    xcoef = None
+    if isinstance(x, LazyAct):
+        if not x.relu:
+            x = x.materialize()
+        else:
+            x, xcoef = x.y, x.coef
+    require_device(x, "the SOM pooling layer")
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    return _SomPoolLayer.apply(x, xcoef, w2, bias, min_idx32, count, csr[0], csr[1], int(M), bool(concat),
+                               _sink(weight, bias))
 
 
 def knn_group(feat, database, query, idx32):

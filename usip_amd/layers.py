@@ -167,6 +167,18 @@ class PointNet(nn.Module):
             x = layer(x, epoch, defer=True)
         return Fh.as_tensor(x)
 
+    def forward_som_pooled(self, x, epoch, min_idx32, count, csr, M, concat):
+        """The SOM detector's use of a PointNet (models/networks.py:114-133): its output goes through index_max,
+        gather and mask, and (first PointNet) is concatenated with the broadcast maxima.  The plain last layer and
+        those steps run as one node (functional._SomPoolLayer).
+        -> (cat(out, broadcast(out_max)) [B,2C,N] if concat else out_max [B,C,M], index_max i32 [B,C,M])."""
+        for layer in list(self.layers)[:-1]:
+            x = layer(x, epoch, defer=True)
+        last = self.layers[-1]
+        if getattr(last, "norm", None) is not None or last.activation is not None:
+            raise NotImplementedError("usip_amd: forward_som_pooled expects a plain last layer (layers.py:524-544)")
+        return Fh.som_pool_layer(x, last.conv.weight, last.conv.bias, min_idx32, count, csr, M, concat)
+
 
 class GeneralKNNFusionModule(nn.Module):
     """query -> database KNN, gather, shared MLP, max over K, concat, shared MLP, max over K

@@ -73,10 +73,21 @@ class RPN_Detector(_DetectorTail):
         M = node.shape[2]
         x = x.contiguous()
         min_idx32 = ops.som_assign(x, node.contiguous())                  # som.py:31-39
-        cluster_mean, count, x_dec = ops.som_cluster(x, min_idx32, M)     # networks.py:87-107
-        has_pts = (count > 0).to(x.dtype).unsqueeze(1)                    # mask_row_max
+        # the assignment sorted by node, once: cluster sums, and every "sum over a node's points" of the backward
+        csr = ops.csr_by_index(min_idx32, M) if (Fh.SEGMENT_BACKWARD and ops.segment_sum_supported(M, N)) else None
+        cluster_mean, count, x_dec = ops.som_cluster(x, min_idx32, M, csr=csr)   # networks.py:87-107
         self.last_indices = dict(min_idx=min_idx32)
         feat_in = torch.cat((x_dec, sn), dim=1) if self.opt.surface_normal_len >= 1 else x_dec
+        if csr is not None:
+            # PointNet -> index_max -> gather * mask -> broadcast -> cat as one node per PointNet (networks.py:114-133)
+            both, first_idx = self.first_pointnet.forward_som_pooled(feat_in, epoch, min_idx32, count, csr, M, True)
+            second_max, second_idx = self.second_pointnet.forward_som_pooled(both, epoch, min_idx32, count, csr, M,
+                                                                             False)
+            self.last_indices.update(first_idx=first_idx.long(), second_idx=second_idx.long())
+            keypoints, sigmas = self._tail(cluster_mean, second_max, epoch)
+            self.last_indices["knn_I"] = self.knnlayer_1.last_knn_I
+            return cluster_mean, keypoints, sigmas, None
+        has_pts = (count > 0).to(x.dtype).unsqueeze(1)                    # mask_row_max
         first = self.first_pointnet(feat_in, epoch)
         first_idx = ops.index_max(first.detach().contiguous(), min_idx32, M).long()   # networks.py:117-118
         first_max = first.gather(2, first_idx) * has_pts

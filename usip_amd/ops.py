@@ -49,6 +49,86 @@ def index_max(data: torch.Tensor, index: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
+def index_max_values(data: torch.Tensor, index: torch.Tensor, count, K: int, C: Optional[int] = None):
+    """index_max plus the gather + mask the reference applies to it (networks.py:117-118): -> (max_idx i32 [B,C,K],
+    data[b,c,max_idx] * (count > 0) f32 [B,C,K]).  data [B,Ctot,N]; C: use only the first C channels."""
+    K = int(K)
+    _need(data, "data", torch.float32)
+    _need(index, "index", torch.int32)
+    if data.dim() != 3 or index.dim() != 2 or index.shape[0] != data.shape[0] or index.shape[1] != data.shape[2]:
+        raise RuntimeError("index_max_values: expected data [B,C,N] and index [B,N]")
+    B, Ctot, N = data.shape
+    C = Ctot if C is None else int(C)
+    if count is not None:
+        _need(count, "count", torch.int32)
+        if tuple(count.shape) != (B, K):
+            raise RuntimeError("index_max_values: count must be [B,K]")
+    idx = torch.empty((B, C, K), dtype=torch.int32, device=data.device)
+    val = torch.empty((B, C, K), dtype=torch.float32, device=data.device)
+    with torch.cuda.device(data.device), prof.kernel("index_max", 4.0 * (B * C * N + B * N + 2 * B * C * K)):
+        _lib.check(_lib.lib().usip_index_max_values_f32(_ptr(data), _ptr(index), _opt(count), _ptr(idx), _ptr(val),
+                                                        B, C, Ctot, N, K, _stream(data)), "usip_index_max_values_f32")
+    return idx, val
+
+
+def index_max_values_backward_add_(ddata, g, max_idx, count, coff: int = 0):
+    """ddata[b, coff+c, max_idx[b,c,k]] += g[b,c,k] (populated nodes), in place; ddata [B,Ctot,N]."""
+    _need(ddata, "ddata", torch.float32)
+    _need(g, "g", torch.float32)
+    B, Ctot, N = ddata.shape
+    _, C, K = g.shape
+    with torch.cuda.device(g.device), prof.kernel("index_max_bwd", 16.0 * B * C * K):
+        _lib.check(_lib.lib().usip_index_max_values_backward_add_f32(_ptr(g), _ptr(max_idx), _opt(count), _ptr(ddata),
+                                                                     B, C, Ctot, int(coff), N, K, _stream(g)),
+                   "usip_index_max_values_backward_add_f32")
+    return ddata
+
+
+def index_max_values_backward(g, max_idx, count, index, N: int, src=None, soff: int = 0):
+    """dz [B,C,N] = (src[:, soff:soff+C] if src is given else 0) + scatter of g [B,C,K] to max_idx (populated nodes):
+    the gradient of index_max_values' masked values as one dense pass."""
+    _need(g, "g", torch.float32)
+    B, C, K = g.shape
+    dz = torch.empty((B, C, int(N)), dtype=torch.float32, device=g.device)
+    if src is not None:
+        _need(src, "src", torch.float32)
+    with torch.cuda.device(g.device), prof.kernel("index_max_bwd", 4.0 * B * C * N * (2 if src is not None else 1) + 4.0 * B * N):
+        _lib.check(_lib.lib().usip_index_max_values_backward_f32(_ptr(g), _ptr(max_idx), _opt(count), _ptr(index),
+                                                                 _opt(src), src.shape[1] if src is not None else 0,
+                                                                 int(soff), _ptr(dz), B, C, int(N), K, _stream(g)),
+                   "usip_index_max_values_backward_f32")
+    return dz
+
+
+def csr_by_index(idx32: torch.Tensor, N: int):
+    """idx i32 [B,P] (values in [0,N)) -> (start i32 [B,N+1], perm i32 [B,P]): the positions sorted by destination."""
+    _need(idx32, "idx", torch.int32)
+    B, P = idx32.shape
+    start = torch.empty((B, int(N) + 1), dtype=torch.int32, device=idx32.device)
+    perm = torch.empty((B, P), dtype=torch.int32, device=idx32.device)
+    with torch.cuda.device(idx32.device), prof.kernel("csr_by_index", 12.0 * B * P):
+        _lib.check(_lib.lib().usip_csr_by_index_i32(_ptr(idx32), _ptr(start), _ptr(perm), B, P, int(N),
+                                                    _stream(idx32)), "usip_csr_by_index_i32")
+    return start, perm
+
+
+def segment_sum_supported(N: int, P: int) -> bool:
+    return bool(_lib.lib().usip_segment_sum_supported(int(N), int(P))) and int(N) <= 1820
+
+
+def segment_sum(src, start, perm, C: int, coff: int = 0):
+    """dx[b,c,n] = sum over segment n of src[b, coff+c, perm[b,j]]; src [B,Ctot,P] (any trailing shape) -> [B,C,N]."""
+    _need(src, "src", torch.float32)
+    B, Ctot = src.shape[0], src.shape[1]
+    P = perm.shape[1]
+    N = start.shape[1] - 1
+    dx = torch.empty((B, int(C), N), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device), prof.kernel("segment_sum", 4.0 * B * (C * (P + N) + P)):
+        _lib.check(_lib.lib().usip_segment_sum_f32(_ptr(src), _ptr(start), _ptr(perm), _ptr(dx), B, int(C), N, P,
+                                                   Ctot, int(coff), _stream(src)), "usip_segment_sum_f32")
+    return dx
+
+
 def index_max_geometry(B: int, C: int, N: int, K: int):
     """(channel rows per workgroup, prefetch depth, threads) usip_index_max_f32 picks for this shape
     (csrc/index_max.hip); lets a profiler name the launch."""
@@ -135,8 +215,9 @@ def som_assign(x: torch.Tensor, node: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def som_cluster(x: torch.Tensor, min_idx: torch.Tensor, M: int, decenter: bool = True):
-    """a-4: (cluster_mean f32 [B,3,M], count i32 [B,M], x_decentered f32 [B,3,N] or None)."""
+def som_cluster(x: torch.Tensor, min_idx: torch.Tensor, M: int, decenter: bool = True, csr=None):
+    """a-4: (cluster_mean f32 [B,3,M], count i32 [B,M], x_decentered f32 [B,3,N] or None).  csr = (start, perm) of
+    min_idx from csr_by_index: the cluster sums walk the sorted segments instead of scanning all assignments."""
     _need_pts(x, "x")
     _need(min_idx, "min_idx", torch.int32)
     B, _, N = x.shape
@@ -145,6 +226,12 @@ def som_cluster(x: torch.Tensor, min_idx: torch.Tensor, M: int, decenter: bool =
     mean = torch.empty((B, 3, int(M)), dtype=torch.float32, device=x.device)
     count = torch.empty((B, int(M)), dtype=torch.int32, device=x.device)
     dec = torch.empty_like(x) if decenter else None
+    if csr is not None:
+        with torch.cuda.device(x.device), prof.kernel("som_cluster", 4.0 * (8 * B * N + 5 * B * M)):
+            _lib.check(_lib.lib().usip_som_cluster_csr_f32(_ptr(x), _ptr(min_idx), _ptr(csr[0]), _ptr(csr[1]), _ptr(mean),
+                                                           _ptr(count), _ptr(dec) if decenter else None, B, N, int(M),
+                                                           _stream(x)), "usip_som_cluster_csr_f32")
+        return mean, count, dec
     with torch.cuda.device(x.device), prof.kernel("som_cluster", 4.0 * (7 * B * N + 4 * B * M)):
         _lib.check(_lib.lib().usip_som_cluster_f32(_ptr(x), _ptr(min_idx), _ptr(mean), _ptr(count),
                                                    _ptr(dec) if decenter else None, B, N, int(M), _stream(x)),
