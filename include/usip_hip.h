@@ -211,6 +211,15 @@ int usip_mlp_gemm_f32x3(const float* At, int lda, const float* X, const float* X
                        const float* pool_dp, const int32_t* pool_arg, int pool_group,
                         float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
 int usip_mlp_gemm_f32x3_used(int M, int K, int P, int nb);
+/* Streaming forward kernel for the narrow layers (K = 64 inputs, M = 64 or 128 outputs; csrc/narrow_fwd.hip): the
+ * contract of usip_mlp_gemm_f32 (pro 0 or 1, bias, rowbias with rb_group % 32 == 0, y_rows) for P % 4 == 0 and a
+ * 16-B aligned X.  Persistent workgroups: `stats` has usip_mlp_narrow_forward_blocks(M, K, P, nb) partials per channel
+ * ([2][M][blocks]); that function returns 0 for shapes the kernel does not take (callers use usip_mlp_gemm_f32). */
+int usip_mlp_narrow_forward_blocks(int M, int K, int P, int nb);
+int usip_mlp_narrow_forward_f32(const float* At, int lda, const float* X, const float* coef, int pro,
+                                const float* bias, const float* rowbias, int rb_group, float* Y, int y_rows,
+                                float* stats, int M, int K, int P, int nb, void* stream);
+
 /* The same f32x3 product with the MATRIX operand split ahead of time (once per optimizer step instead of once per
  * workgroup and stage): usip_mlp_split3_f32 turns the K-major operand At (A[m][k] = At[k*lda + m], M x K) into the
  * image the kernel copies straight into LDS -- per (128-row tile, 16-k stage) three contiguous 4 KiB bf16 planes,

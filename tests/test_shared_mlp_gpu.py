@@ -292,3 +292,53 @@ def test_narrow_chain_gradients_do_not_depend_on_the_fused_backward():
     for a_, b_ in zip(run(True), run(False)):
         if float(b_.abs().max()) > 0:
             assert _rel(a_, b_) < 2e-5
+
+
+# ------------------------------------------------------------------ streaming forward kernel of the narrow layers
+@pytest.mark.parametrize("M", [64, 128])
+@pytest.mark.parametrize("P,nb", [(32768, 16), (8192, 16), (16644, 16), (40000, 8)])
+@pytest.mark.parametrize("variant", ["plain", "bnrelu", "rowbias", "into_wider"])
+def test_narrow_forward_streaming_kernel_matches_generic(M, P, nb, variant):
+    """csrc/narrow_fwd.hip against the generic tile kernel on the same inputs (same fp32 MFMA arithmetic, another
+    summation order over k): outputs to 2e-6 of the output scale, BatchNorm sums (partials added up in double) to
+    1e-6 of the magnitude they add up; ragged last tiles (P not a multiple of 256 / 128), a row bias per 64-position group, and a
+    result written into the rows of a wider tensor."""
+    from usip_amd import ops
+    K = 64
+    if ops._lib.lib().usip_mlp_narrow_forward_blocks(M, K, P, nb) == 0:
+        pytest.skip("too few tiles for the persistent workgroups: this shape runs the generic kernel")
+    g = torch.Generator(device="cpu").manual_seed(M + P)
+    At = (torch.randn(K, M + 8, generator=g) / 8).to(DEV)                 # lda > M: a column slice of a wider matrix
+    X = torch.randn(nb, K, P, generator=g).to(DEV)
+    bias = torch.randn(M, generator=g).to(DEV)
+    kw = dict(M=M, a_offset=4)
+    if variant in ("bnrelu", "rowbias"):
+        coef = torch.stack([1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)]).to(DEV).contiguous()
+        kw.update(pro=1, coef=coef)
+    if variant == "rowbias":
+        if P % 64:
+            pytest.skip("row-bias groups of 64 positions need P % 64 == 0")
+        kw.update(rowbias=torch.randn(nb, M, P // 64, generator=g).to(DEV), rb_group=64)
+    outs = []
+    for streaming in (True, False):
+        ops.NARROW_FWD = streaming
+        try:
+            if variant == "into_wider":
+                out = torch.full((nb, M + 5, P), 7.0, device=DEV)
+                y, st = ops.mlp_gemm(At, X, bias, want_stats=True, out=out, out_row_offset=3, **kw)
+                assert float((out[:, :3] - 7.0).abs().max()) == 0.0 and float((out[:, 3 + M:] - 7.0).abs().max()) == 0.0
+                y = out[:, 3:3 + M]
+            else:
+                y, st = ops.mlp_gemm(At, X, bias, want_stats=True, **kw)
+        finally:
+            ops.NARROW_FWD = True
+        outs.append((y, st.double().sum(dim=2)))
+    (y1, s1), (y0, s0) = outs
+    scale = float(y0.abs().max())
+    assert float((y1 - y0).abs().max()) <= 2e-6 * scale
+    # sums against what they add up: sum |y| per channel for the plain sums (they cancel), the sum itself for squares
+    mag = torch.stack((y0.double().abs().sum(dim=(0, 2)), s0[1]))
+    assert float(((s1 - s0).abs() / mag).max()) <= 1e-6
+    # ... and without statistics
+    y2, st2 = ops.mlp_gemm(At, X, bias, **kw)
+    assert st2 is None and torch.equal(y2, y1 if variant != "into_wider" else y2)

@@ -32,6 +32,9 @@ SIGNATURES = {
                                                 _stream], _int),
     "usip_index_max_values_backward_f32": ([_f32p, _i32p, _i32p, _i32p, _f32p, _int, _int, _f32p, _int, _int, _int, _int,
                                             _stream], _int),
+    "usip_mlp_narrow_forward_blocks": ([_int, _int, _int, _int], _int),
+    "usip_mlp_narrow_forward_f32": ([_f32p, _int, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _int, _int,
+                                     _int, _int, _stream], _int),
     "usip_csr_by_index_i32": ([_i32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_segment_sum_supported": ([_int, _int], _int),
     "usip_segment_sum_f32": ([_f32p, _i32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _stream], _int),

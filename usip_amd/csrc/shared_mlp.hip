@@ -439,18 +439,21 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradArgs a)
     wgrad_store_partial<TM, TN>(a, acc, slice, m0, n0, wm, wn, lane);
 }
 
-// dW[e] = sum over slices, in a fixed order: 64 elements x 4 slice lanes per block, every lane sums
-// its quarter of the slices (4 independent chains), the quarters are combined through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
-                                                           float* __restrict__ dW, long long elems, int slices,
-                                                           int N, int ldw, int coloff)
+// dW[e] = sum over slices, in a fixed order: 64 elements x Q slice lanes per block, every lane sums its share of the
+// slices (4 independent chains), the shares are combined through LDS in a fixed order.  Q = 16 for the launches with
+// many slices (one tile of 64 x 7 .. 128 x 128 outputs cut into ~1024 position slices): with Q = 4 every lane walked
+// 256 slices and the kernel was that chain of dependent loads (23 us for 1.8 MB at 64 x 7, 31 us at 128 x 128).
+template <int Q>
+__global__ __launch_bounds__(64 * Q) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                              float* __restrict__ dW, long long elems, int slices,
+                                                              int N, int ldw, int coloff)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[Q][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
     const long long i = (long long)blockIdx.x * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < elems) {
-        const int per = (slices + 3) / 4, k0 = q * per, k1 = min(slices, k0 + per);
+        const int per = (slices + Q - 1) / Q, k0 = q * per, k1 = min(slices, k0 + per);
         int k = k0;
         for (; k + 3 < k1; k += 4) {
             s0 += part[(long long)k * elems + i];
@@ -462,8 +465,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
     red[q][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (q == 0 && i < elems)
-        dW[(i / N) * ldw + coloff + (i % N)] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (q == 0 && i < elems) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < Q; g += 4) t += (red[g][e] + red[g + 1][e]) + (red[g + 2][e] + red[g + 3][e]);
+        dW[(i / N) * ldw + coloff + (i % N)] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -736,8 +743,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
 int usip_mlp::launch_wgrad_reduce(const float* part, float* dW, long long elems, int slices, int N, int ldw, int coloff,
                                   hipStream_t st)
 {
-    USIP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st, part, dW, elems, slices, N,
-                ldw, coloff);
+    if (slices > 64)
+        USIP_LAUNCH(wgrad_reduce_kernel<16>, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, part, dW, elems,
+                    slices, N, ldw, coloff);
+    else
+        USIP_LAUNCH(wgrad_reduce_kernel<4>, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st, part, dW, elems,
+                    slices, N, ldw, coloff);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
@@ -934,10 +945,7 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
 #undef USIP_WGRAD_CASES
 #undef USIP_WGRAD_CASE
     const long long elems = (long long)M * N;
-    USIP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((elems + 63) / 64)), dim3(256), 0, st,
-                workspace, dW, elems, nb * segs, N, ldw, coloff);
-    USIP_LAUNCH_CHECK();
-    return USIP_OK;
+    return usip_mlp::launch_wgrad_reduce(workspace, dW, elems, nb * segs, N, ldw, coloff, st);
 }
 
 #define USIP_WGRAD_PARAMS                                                                                      \

@@ -343,6 +343,11 @@ def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int) -> torch.Tens
     return planes
 
 
+# The narrow forward layers run the streaming kernel; USIP_NARROW_FWD=0 sends them through the generic tile kernel
+# again (A/B measurement, tools/ab_env.sh).
+NARROW_FWD = _os.environ.get("USIP_NARROW_FWD", "1") not in ("0", "off")
+
+
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
              M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, out=None,
@@ -380,11 +385,29 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                % (tuple(out.shape), out_row_offset, out_row_offset + M, nb, P))
         Y, y_rows = out, out.shape[1]
         y_ptr = ctypes.c_void_p(out.data_ptr() + 4 * int(out_row_offset) * P)
+    a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
+    # narrow layers (64 inputs, 64 / 128 outputs) at many positions: the streaming kernel (csrc/narrow_fwd.hip)
+    nf_blocks = 0
+    if (NARROW_FWD and _matmul_mode != "bf16" and not a_trans and pool is None and X2 is None and pro in (0, 1)
+            and K == 64 and M in (64, 128) and X.data_ptr() % 16 == 0
+            and (rowbias is None or (rb_group % 32 == 0 and P % rb_group == 0))):
+        nf_blocks = int(_lib.lib().usip_mlp_narrow_forward_blocks(M, K, P, nb))
+    if nf_blocks:
+        stats = torch.empty((2, M, nf_blocks), dtype=torch.float32, device=X.device) if want_stats else None
+        with torch.cuda.device(X.device), prof.kernel(
+                "shared_mlp_gemm_%s %dx%d" % (tag, M, K), 4.0 * nb * P * (K + M), 2.0 * M * K * nb * P,
+                rocprof_key="narrow_fwd_kernel<%d, %s, %s, %s> |wg=%d" % (
+                    M // 32, "true" if pro else "false", "true" if want_stats else "false",
+                    "true" if rowbias is not None else "false", nf_blocks)):
+            _lib.check(_lib.lib().usip_mlp_narrow_forward_f32(a_ptr, lda, _ptr(X), _opt(coef), int(pro), _opt(bias),
+                                                              _opt(rowbias), int(rb_group), y_ptr, int(y_rows),
+                                                              _opt(stats), M, K, P, nb, _stream(X)),
+                       "usip_mlp_narrow_forward_f32")
+        return Y, stats
     stats = None
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
-    a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
     bf16 = _matmul_mode == "bf16"
     fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
     x3 = _matmul_mode == "f32x3" and bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb))
