@@ -143,6 +143,25 @@ int usip_nearest_f32(const float* a, const float* b, float* min_d, int32_t* arg,
 int usip_nearest_backward_f32(const float* a, const float* b, const float* d, const int32_t* arg,
                               const float* gd, float* ga, float* gb, int B, int C, int Ma, int Nb, void* stream);
 
+/* a-8 / a-11: the element-wise tail of the step, one launch each way per line of the reference (csrc/head.hip).
+ * keypoints[b][:][m] = ks[b][0:3][m] + centre[b][:][m];  sigmas[b][m] = softplus(ks[b][3][m]) + sigma_lower_bound
+ * (models/networks.py:150-154; torch.nn.Softplus defaults).  ks [B][4][M], centre [B][3][M]. */
+int usip_detector_head_f32(const float* ks, const float* centre, float sigma_lower_bound, float* keypoints,
+                           float* sigmas, int B, int M, void* stream);
+/* g_ks [B][4][M] from g_keypoints [B][3][M] and g_sigmas [B][M] (either may be NULL = zero). */
+int usip_detector_head_backward_f32(const float* g_keypoints, const float* g_sigmas, const float* ks, float* g_ks,
+                                    int B, int M, void* stream);
+/* out[b] = (R[b] * scale[b]) . x[b] + shift[b]  (models/keypoint_detector.py:182-184: R.kp*s + t), x/out [B][3][M],
+ * R [B][3][3], scale [B], shift [B][3].  transpose != 0: out[b] = (R[b] * scale[b])^T . x[b] (its backward; shift unused). */
+int usip_rigid_transform_f32(const float* x, const float* R, const float* scale, const float* shift, float* out,
+                             int transpose, int B, int M, void* stream);
+/* out3 = (chamfer[0] + alpha * (mean(d[0:half]) + mean(d[half:2*half])), alpha * mean(first), alpha * mean(second)):
+ * the sum of the step's losses (keypoint_detector.py:196-204); means in double. */
+int usip_detector_loss_combine_f32(const float* d, const float* chamfer, float alpha, float* out3, long long half,
+                                   void* stream);
+/* out[0:n] = g[0] * factor (the gradient of a mean). */
+int usip_fill_scaled_f32(const float* g, float factor, float* out, long long n, void* stream);
+
 /* a-10: the sigma arithmetic of ChamferLoss_Brute after the two min / arg-min reductions
  * (models/losses.py:82-99) as one launch.  a [B][M], J i32 [B][M] = row minima / arg-minima (src -> dst),
  * c [B][N], I i32 [B][N] = column minima (dst -> src), sigma_src [B][M], sigma_dst [B][N].

@@ -356,3 +356,44 @@ def test_index_max_launch_geometries_agree():
         lib.usip_set_tuning(b"index_max_unroll", 0)
         lib.usip_set_tuning(b"index_max_threads", 0)
     assert lib.usip_set_tuning(b"no_such_knob", 1) != 0
+
+
+def test_detector_tail_elementwise_ops_match_torch():
+    """csrc/head.hip against the ATen composition it replaces (models/networks.py:150-154,
+    keypoint_detector.py:182-184, :196-204), values and gradients, incl. softplus beyond its threshold of 20."""
+    from usip_amd import functional as Fh
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, M = 6, 333
+    ks0 = torch.randn(B, 4, M, generator=g)
+    ks0[0, 3, :5] = torch.tensor([25.0, 19.999, 20.001, -30.0, 0.0])
+    centre = torch.randn(B, 3, M, generator=g).to(DEV)
+    R = torch.linalg.qr(torch.randn(B // 2, 3, 3, generator=g))[0].to(DEV)
+    scale = (0.5 + torch.rand(B // 2, generator=g)).to(DEV)
+    shift = torch.randn(B // 2, 3, 1, generator=g).to(DEV)
+    pc_d = torch.rand(B, M, generator=g).to(DEV)                          # stands for the keypoint-to-cloud distances
+    wk, ws, wt = (torch.randn(s, generator=g).to(DEV) for s in ((B, 3, M), (B, M), (B // 2, 3, M)))
+
+    def run(fused):
+        ks = ks0.to(DEV).clone().requires_grad_(True)
+        d = pc_d.clone().requires_grad_(True)
+        if fused:
+            kp, sg = Fh.detector_head(ks, centre, 0.001)
+            kp_t = Fh.rigid_transform(kp[:B // 2], R, scale, shift)
+        else:
+            off, raw = torch.split(ks, [3, 1], dim=1)
+            kp = off + centre
+            sg = torch.nn.functional.softplus(raw.squeeze(1)) + 0.001
+            kp_t = torch.baddbmm(shift, R * scale.view(-1, 1, 1), kp[:B // 2])
+        chamfer = (kp * wk).sum() + (sg * ws).sum() + (kp_t * wt).sum()
+        if fused:
+            loss, on_src, on_dst = Fh.detector_loss_combine(d, chamfer, 0.7)
+        else:
+            on = d.view(2, -1).mean(dim=1) * 0.7
+            on_src, on_dst = on[0], on[1]
+            loss = chamfer + on.sum()
+        loss.backward()
+        return [t.detach() for t in (kp, sg, kp_t, loss, on_src, on_dst, ks.grad, d.grad)]
+
+    for a, b, name in zip(run(True), run(False), ("kp", "sigma", "kp_t", "loss", "on_src", "on_dst", "dks", "dd")):
+        scale_ = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, scale_), name

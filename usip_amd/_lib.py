@@ -35,6 +35,11 @@ SIGNATURES = {
     "usip_mlp_narrow_forward_blocks": ([_int, _int, _int, _int], _int),
     "usip_mlp_narrow_forward_f32": ([_f32p, _int, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _int, _int,
                                      _int, _int, _stream], _int),
+    "usip_detector_head_f32": ([_f32p, _f32p, _flt, _f32p, _f32p, _int, _int, _stream], _int),
+    "usip_detector_head_backward_f32": ([_f32p, _f32p, _f32p, _f32p, _int, _int, _stream], _int),
+    "usip_rigid_transform_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
+    "usip_detector_loss_combine_f32": ([_f32p, _f32p, _flt, _f32p, ctypes.c_longlong, _stream], _int),
+    "usip_fill_scaled_f32": ([_f32p, _flt, _f32p, ctypes.c_longlong, _stream], _int),
     "usip_csr_by_index_i32": ([_i32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_segment_sum_supported": ([_int, _int], _int),
     "usip_segment_sum_f32": ([_f32p, _i32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _stream], _int),

@@ -1,0 +1,162 @@
+// usip_amd/csrc/head.hip -- the element-wise tail of the detector step as three small kernels (gfx950).
+//
+// Between the last shared-MLP layer and the nearest-neighbour reductions the reference runs a dozen element-wise ATen
+// launches over B x 4 x M values forward and as many backward -- split, add, softplus, add, the scaled rigid transform
+// (mul + baddbmm), means, a sum -- each ~5 us of launch latency inside the captured step:
+//     keypoints = mlp3[:, :3] + centre,  sigmas = softplus(mlp3[:, 3]) + lower_bound        (models/networks.py:150-154)
+//     kp_t = (R * scale) . keypoints_src + shift                                             (keypoint_detector.py:182-184)
+//     loss = loss_chamfer + alpha * (mean(d_src) + mean(d_dst))                               (keypoint_detector.py:196-204)
+// Same arithmetic, one launch each way per line.
+#include "common.h"
+
+namespace {
+
+constexpr float SOFTPLUS_THRESHOLD = 20.0f;                   // torch.nn.Softplus default (beta = 1)
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(
+    const float* __restrict__ ks, const float* __restrict__ centre, float lower, float* __restrict__ kp,
+    float* __restrict__ sigma, int M)
+{
+    const int b = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float* k = ks + (long long)b * 4 * M;
+    const float* c = centre + (long long)b * 3 * M;
+    float* o = kp + (long long)b * 3 * M;
+    o[m] = k[m] + c[m];
+    o[M + m] = k[M + m] + c[M + m];
+    o[2 * M + m] = k[2 * M + m] + c[2 * M + m];
+    const float x = k[3 * M + m];
+    sigma[(long long)b * M + m] = (x > SOFTPLUS_THRESHOLD ? x : log1pf(expf(x))) + lower;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_kernel(
+    const float* __restrict__ gkp, const float* __restrict__ gsigma, const float* __restrict__ ks,
+    float* __restrict__ gks, int M)
+{
+    const int b = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float* o = gks + (long long)b * 4 * M;
+    const float* g = gkp ? gkp + (long long)b * 3 * M : nullptr;
+    o[m] = g ? g[m] : 0.f;
+    o[M + m] = g ? g[M + m] : 0.f;
+    o[2 * M + m] = g ? g[2 * M + m] : 0.f;
+    float gs = 0.f;
+    if (gsigma) {
+        const float x = ks[(long long)b * 4 * M + 3 * M + m];
+        const float z = expf(x);                              // softplus_backward: grad * z / (z + 1)
+        gs = gsigma[(long long)b * M + m] * (x > SOFTPLUS_THRESHOLD ? 1.0f : z / (z + 1.0f));
+    }
+    o[3 * M + m] = gs;
+}
+
+// out[b][i][m] = shift[b][i] + sum_j (R[b][i][j] * scale[b]) * x[b][j][m]        (TRANSPOSE: R^T, no shift -- the backward)
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void rigid_kernel(
+    const float* __restrict__ x, const float* __restrict__ R, const float* __restrict__ scale,
+    const float* __restrict__ shift, float* __restrict__ out, int M)
+{
+    const int b = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const float s = scale[b];
+    const float* r = R + b * 9;
+    const float* xb = x + (long long)b * 3 * M;
+    const float x0 = xb[m], x1 = xb[M + m], x2 = xb[2 * M + m];
+    float* o = out + (long long)b * 3 * M;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float a0 = (TRANSPOSE ? r[i] : r[3 * i]) * s, a1 = (TRANSPOSE ? r[3 + i] : r[3 * i + 1]) * s,
+                    a2 = (TRANSPOSE ? r[6 + i] : r[3 * i + 2]) * s;
+        float t = a0 * x0;
+        t = __builtin_fmaf(a1, x1, t);
+        t = __builtin_fmaf(a2, x2, t);
+        o[i * M + m] = TRANSPOSE ? t : shift[b * 3 + i] + t;
+    }
+}
+
+// out3 = (chamfer + alpha * (mean(d[0:half]) + mean(d[half:])), alpha * mean(d[0:half]), alpha * mean(d[half:]))
+__global__ __launch_bounds__(1024) void loss_combine_kernel(
+    const float* __restrict__ d, const float* __restrict__ chamfer, float alpha, float* __restrict__ out3,
+    long long half)
+{
+    __shared__ double red[2][16];
+    double s0 = 0.0, s1 = 0.0;
+    for (long long e = threadIdx.x; e < half; e += 1024) { s0 += (double)d[e]; s1 += (double)d[half + e]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off); s1 += __shfl_down(s1, off); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int w = 0; w < 16; ++w) { t0 += red[0][w]; t1 += red[1][w]; }
+        const float m0 = (float)(t0 / (double)half) * alpha, m1 = (float)(t1 / (double)half) * alpha;
+        out3[1] = m0;
+        out3[2] = m1;
+        out3[0] = chamfer[0] + (m0 + m1);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restrict__ g, float factor,
+                                                          float* __restrict__ out, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = g[0] * factor;
+}
+
+}  // namespace
+
+extern "C" int usip_detector_head_f32(const float* ks, const float* centre, float sigma_lower_bound, float* keypoints,
+                                      float* sigmas, int B, int M, void* stream)
+{
+    if (B < 0 || M < 0) return USIP_EINVAL;
+    if ((long long)B * M == 0) return USIP_OK;
+    if (!ks || !centre || !keypoints || !sigmas || B > 65535) return USIP_EINVAL;
+    USIP_LAUNCH(head_fwd_kernel, dim3(usip_ceil_div(M, 256), B), dim3(256), 0, (hipStream_t)stream,
+                ks, centre, sigma_lower_bound, keypoints, sigmas, M);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_detector_head_backward_f32(const float* g_keypoints, const float* g_sigmas, const float* ks,
+                                               float* g_ks, int B, int M, void* stream)
+{
+    if (B < 0 || M < 0) return USIP_EINVAL;
+    if ((long long)B * M == 0) return USIP_OK;
+    if (!ks || !g_ks || B > 65535) return USIP_EINVAL;
+    USIP_LAUNCH(head_bwd_kernel, dim3(usip_ceil_div(M, 256), B), dim3(256), 0, (hipStream_t)stream,
+                g_keypoints, g_sigmas, ks, g_ks, M);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_rigid_transform_f32(const float* x, const float* R, const float* scale, const float* shift,
+                                        float* out, int transpose, int B, int M, void* stream)
+{
+    if (B < 0 || M < 0) return USIP_EINVAL;
+    if ((long long)B * M == 0) return USIP_OK;
+    if (!x || !R || !scale || !out || (!transpose && !shift) || B > 65535) return USIP_EINVAL;
+    const dim3 grid(usip_ceil_div(M, 256), B), block(256);
+    if (transpose) USIP_LAUNCH(rigid_kernel<true>, grid, block, 0, (hipStream_t)stream, x, R, scale, shift, out, M);
+    else USIP_LAUNCH(rigid_kernel<false>, grid, block, 0, (hipStream_t)stream, x, R, scale, shift, out, M);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_detector_loss_combine_f32(const float* d, const float* chamfer, float alpha, float* out3,
+                                              long long half, void* stream)
+{
+    if (half < 1 || !d || !chamfer || !out3) return USIP_EINVAL;
+    USIP_LAUNCH(loss_combine_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d, chamfer, alpha, out3, half);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_fill_scaled_f32(const float* g, float factor, float* out, long long n, void* stream)
+{
+    if (n < 0) return USIP_EINVAL;
+    if (n == 0) return USIP_OK;
+    if (!g || !out || (n + 255) / 256 > 0x7fffffffLL) return USIP_EINVAL;
+    USIP_LAUNCH(fill_scaled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, factor,
+                out, n);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}

@@ -203,6 +203,83 @@ def chamfer_prob(a, J32, c, I32, sigma_src, sigma_dst):
     return _ChamferProb.apply(a, J32, c, I32, sigma_src, sigma_dst)
 
 
+class _DetectorHead(torch.autograd.Function):
+    """keypoints = ks[:, :3] + centre, sigmas = softplus(ks[:, 3]) + lower bound (models/networks.py:150-154) as one
+    launch each way instead of split / add / softplus / add and their five backward launches."""
+
+    @staticmethod
+    def forward(ctx, ks, centre, lower):
+        ks = ks.contiguous()
+        kp, sg = ops.detector_head(ks, centre.contiguous(), lower)
+        ctx.save_for_backward(ks)
+        ctx.set_materialize_grads(False)
+        return kp, sg
+
+    @staticmethod
+    def backward(ctx, g_kp, g_sg):
+        (ks,) = ctx.saved_tensors
+        if g_kp is None and g_sg is None:
+            return None, None, None
+        return ops.detector_head_backward(None if g_kp is None else g_kp.contiguous(),
+                                          None if g_sg is None else g_sg.contiguous(), ks), None, None
+
+
+def detector_head(ks, centre, sigma_lower_bound: float):
+    """ks [B,4,M] -> (keypoints [B,3,M], sigmas [B,M]); centre carries no gradient (it does not in the reference:
+    nodes / cluster means are inputs)."""
+    require_device(ks, "detector_head")
+    return _DetectorHead.apply(ks, centre.detach(), float(sigma_lower_bound))
+
+
+class _RigidTransform(torch.autograd.Function):
+    """(R * scale) . x + shift per cloud (models/keypoint_detector.py:182-184); R, scale, shift are inputs."""
+
+    @staticmethod
+    def forward(ctx, x, R, scale, shift):
+        R, scale = R.contiguous(), scale.contiguous()
+        ctx.save_for_backward(R, scale)
+        return ops.rigid_transform(x.contiguous(), R, scale, shift.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        R, scale = ctx.saved_tensors
+        return ops.rigid_transform(g.contiguous(), R, scale, None, transpose=True), None, None, None
+
+
+def rigid_transform(x, R, scale, shift):
+    require_device(x, "rigid_transform")
+    return _RigidTransform.apply(x, R, scale.reshape(-1), shift.reshape(shift.shape[0], 3))
+
+
+class _DetectorLossCombine(torch.autograd.Function):
+    """loss = loss_chamfer + alpha * (mean(d_src) + mean(d_dst)) (models/keypoint_detector.py:196-204), d [2B,M] the
+    keypoint-to-cloud distances with the src rows first.  -> (loss, alpha*mean(d_src), alpha*mean(d_dst)); the last
+    two are for logging."""
+
+    @staticmethod
+    def forward(ctx, d, chamfer, alpha):
+        d = d.contiguous()
+        out = ops.detector_loss_combine(d, chamfer.reshape(1), alpha)
+        ctx.shape, ctx.alpha = tuple(d.shape), float(alpha)
+        loss, on_src, on_dst = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(on_src, on_dst)
+        return loss, on_src, on_dst
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g2):
+        if gloss is None:
+            return None, None, None
+        gloss = gloss.contiguous().reshape(1)
+        n = 1
+        for v in ctx.shape:
+            n *= v
+        return ops.fill_scaled(gloss, ctx.alpha / (n // 2), ctx.shape), gloss.reshape(()), None
+
+
+def detector_loss_combine(d, chamfer, alpha: float):
+    return _DetectorLossCombine.apply(d, chamfer, float(alpha))
+
+
 def nearest_distance(a: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """a [B,C,Ma], b [B,C,Nb] -> (min distance [B,Ma], arg-min int64 [B,Ma] as torch.min returns it).  C == 3:
     coordinates (exact oracle arithmetic); any other C: descriptors (Nb <= 1024)."""

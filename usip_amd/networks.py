@@ -44,10 +44,8 @@ class _DetectorTail(nn.Module):
         agg = torch.cat((node_feature, knn_feature), dim=1)
         y = self.mlp2(self.mlp1(agg, defer=True), defer=True)            # no epoch: networks.py:147-148
         ks = self.mlp3(y)
-        offset, raw_sigma = torch.split(ks, [3, 1], dim=1)     # one SplitBackward instead of two zero-filled slices
-        keypoints = offset + centre
-        sigmas = self.softplus(raw_sigma.squeeze(1)) + self.opt.loss_sigma_lower_bound
-        return keypoints, sigmas
+        # offset + centre, softplus(raw sigma) + lower bound (networks.py:150-154): one launch each way
+        return Fh.detector_head(ks, centre, self.opt.loss_sigma_lower_bound)
 
 
 class RPN_Detector(_DetectorTail):

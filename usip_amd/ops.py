@@ -290,6 +290,61 @@ def chamfer_prob_backward(gloss, a, J, c, I, sigma_src, sigma_dst):
     return da, dc, dss, dsd
 
 
+def detector_head(ks, centre, sigma_lower_bound: float):
+    """ks [B,4,M] (mlp3 output), centre [B,3,M] -> (keypoints [B,3,M], sigmas [B,M]) (networks.py:150-154)."""
+    _need(ks, "ks", torch.float32)
+    _need(centre, "centre", torch.float32)
+    B, _, M = ks.shape
+    kp = torch.empty((B, 3, M), dtype=torch.float32, device=ks.device)
+    sg = torch.empty((B, M), dtype=torch.float32, device=ks.device)
+    with torch.cuda.device(ks.device), prof.kernel("head", 4.0 * 11 * B * M):
+        _lib.check(_lib.lib().usip_detector_head_f32(_ptr(ks), _ptr(centre), float(sigma_lower_bound), _ptr(kp), _ptr(sg),
+                                                     B, M, _stream(ks)), "usip_detector_head_f32")
+    return kp, sg
+
+
+def detector_head_backward(g_kp, g_sg, ks):
+    B, _, M = ks.shape
+    g = torch.empty_like(ks)
+    with torch.cuda.device(ks.device), prof.kernel("head_bwd", 4.0 * 9 * B * M):
+        _lib.check(_lib.lib().usip_detector_head_backward_f32(_opt(g_kp), _opt(g_sg), _ptr(ks), _ptr(g), B, M,
+                                                              _stream(ks)), "usip_detector_head_backward_f32")
+    return g
+
+
+def rigid_transform(x, R, scale, shift, transpose: bool = False):
+    """(R*scale) . x + shift per cloud (keypoint_detector.py:182-184); transpose: (R*scale)^T . x (the backward)."""
+    _need(x, "x", torch.float32)
+    B, _, M = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device), prof.kernel("rigid_transform", 4.0 * 6 * B * M):
+        _lib.check(_lib.lib().usip_rigid_transform_f32(_ptr(x), _ptr(R), _ptr(scale), _opt(shift), _ptr(out),
+                                                       int(bool(transpose)), B, M, _stream(x)),
+                   "usip_rigid_transform_f32")
+    return out
+
+
+def detector_loss_combine(d, chamfer, alpha: float):
+    """d [2B,M] keypoint-to-cloud distances (src rows first), chamfer: 0-dim/1-element loss tensor ->
+    3-vector (loss, alpha*mean(d_src), alpha*mean(d_dst)) (keypoint_detector.py:196-204)."""
+    _need(d, "d", torch.float32)
+    out = torch.empty(3, dtype=torch.float32, device=d.device)
+    with torch.cuda.device(d.device), prof.kernel("loss_combine", 4.0 * d.numel()):
+        _lib.check(_lib.lib().usip_detector_loss_combine_f32(_ptr(d), _ptr(chamfer), float(alpha), _ptr(out),
+                                                             d.numel() // 2, _stream(d)),
+                   "usip_detector_loss_combine_f32")
+    return out
+
+
+def fill_scaled(g, factor: float, shape):
+    """A tensor of `shape` filled with g[0] * factor (g: device scalar)."""
+    out = torch.empty(shape, dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device), prof.kernel("fill_scaled", 4.0 * out.numel()):
+        _lib.check(_lib.lib().usip_fill_scaled_f32(_ptr(g), float(factor), _ptr(out), out.numel(), _stream(g)),
+                   "usip_fill_scaled_f32")
+    return out
+
+
 # --------------------------------------------------------------------------- shared MLP
 def _opt(t):
     return _ptr(t) if t is not None else None

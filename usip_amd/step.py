@@ -15,6 +15,7 @@ from typing import Dict, Optional
 import torch
 import torch.distributed as dist
 
+from . import functional as Fh
 from .losses import ChamferLoss_Brute, KeypointOnPCLoss
 from .networks import build_detector
 
@@ -263,14 +264,13 @@ class DetectorStep(_GraphedStep):
         kp_src, kp_dst = torch.split(kp, B, dim=0)            # :147-149 (split: one backward node, no zero fills)
         sg_src, sg_dst = torch.split(sg, B, dim=0)
         # :182-184  R.kp*s + t  as one batched GEMM with the scale folded into R (inputs, no gradient)
-        kp_t = torch.baddbmm(batch["shift"], batch["R"] * batch["scale"].view(-1, 1, 1), kp_src)
+        kp_t = Fh.rigid_transform(kp_src, batch["R"], batch["scale"], batch["shift"])
         loss_chamfer, pure, weighted = self.chamfer_criteria(kp_t, kp_dst, sg_src, sg_dst)
         alpha = self.opt.keypoint_on_pc_alpha
         # :196-203  keypoint-on-pc for src and dst: both clouds of every pair in ONE nearest-neighbour launch
         # (rows [0,B) = src, [B,2B) = dst; every cloud is independent, so the values are the reference's)
-        on_pc = self.keypoint_on_pc_criteria(kp, pc, None).view(2, -1).mean(dim=1) * alpha
-        on_src, on_dst = on_pc[0], on_pc[1]
-        loss = loss_chamfer + on_pc.sum()                     # :204
+        loss, on_src, on_dst = Fh.detector_loss_combine(self.keypoint_on_pc_criteria(kp, pc, None), loss_chamfer,
+                                                        alpha)   # :204
         self.last = dict(node=nodes, keypoints=kp, sigmas=sg, loss=loss, loss_chamfer=loss_chamfer,
                          chamfer_pure=pure, chamfer_weighted=weighted, loss_on_pc_src=on_src,
                          loss_on_pc_dst=on_dst)
