@@ -162,6 +162,12 @@ int usip_detector_loss_combine_f32(const float* d, const float* chamfer, float a
 /* out[0:n] = g[0] * factor (the gradient of a mean). */
 int usip_fill_scaled_f32(const float* g, float factor, float* out, long long n, void* stream);
 
+/* Pooled-concat layers (a-6 / a-7 row-bias rewrite): the sum over each neighbourhood's K positions of the layer's
+ * dY, from the per-neighbourhood sums of the BatchNorm-backward reduction: out[b][c][g] = K * coef4[3][c]
+ * + coef4[0][c] * gsum0[b][c][g] + coef4[2][c] * gsum1[b][c][g].  gsum0/1, out [nb][C][G], coef4 [4][C]. */
+int usip_bn_group_dy_sum_f32(const float* gsum0, const float* gsum1, const float* coef4, float* out,
+                             int nb, int C, int G, int K, void* stream);
+
 /* a-10: the sigma arithmetic of ChamferLoss_Brute after the two min / arg-min reductions
  * (models/losses.py:82-99) as one launch.  a [B][M], J i32 [B][M] = row minima / arg-minima (src -> dst),
  * c [B][N], I i32 [B][N] = column minima (dst -> src), sigma_src [B][M], sigma_dst [B][N].
@@ -245,6 +251,14 @@ int usip_mlp_narrow_forward_f32(const float* At, int lda, const float* X, const 
  * zero padded -- usip_mlp_split3_bytes(M, K) bytes, 16-B aligned.  usip_mlp_gemm_x3p_f32 then has the contract of
  * usip_mlp_gemm_f32 with `planes` in place of (At, lda); K <= 640. */
 int usip_mlp_x3p_tile_rows(int M);                 /* rows per tile (128 or 256): profiling aid */
+/* All weight operands of a step in one launch: descs (DEVICE memory, n entries, At / planes as for
+ * usip_mlp_split3_f32) with first_block = running sum of usip_mlp_split3_blocks(M, K) over the entries before. */
+typedef struct usip_split3_desc {
+    const float* At; void* planes; int32_t lda, M, K, first_block;
+    int32_t tile_rows, reserved;                      /* usip_mlp_x3p_tile_rows(M) */
+} usip_split3_desc;
+int usip_mlp_split3_blocks(int M, int K);
+int usip_mlp_split3_multi_f32(const usip_split3_desc* descs_device, int n, int total_blocks, void* stream);
 /* Positions per tile the same kernel uses for this launch: 128 (256 only under the x3_gemm_tile measurement knob). */
 int usip_mlp_x3p_tile_cols(int M, int P, int nb, int pro, int with_stats);
 long long usip_mlp_split3_bytes(int M, int K);

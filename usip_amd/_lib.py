@@ -40,6 +40,9 @@ SIGNATURES = {
     "usip_rigid_transform_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
     "usip_detector_loss_combine_f32": ([_f32p, _f32p, _flt, _f32p, ctypes.c_longlong, _stream], _int),
     "usip_fill_scaled_f32": ([_f32p, _flt, _f32p, ctypes.c_longlong, _stream], _int),
+    "usip_mlp_split3_blocks": ([_int, _int], _int),
+    "usip_mlp_split3_multi_f32": ([ctypes.c_void_p, _int, _int, _stream], _int),
+    "usip_bn_group_dy_sum_f32": ([_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_csr_by_index_i32": ([_i32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_segment_sum_supported": ([_int, _int], _int),
     "usip_segment_sum_f32": ([_f32p, _i32p, _i32p, _f32p, _int, _int, _int, _int, _int, _int, _stream], _int),

@@ -102,7 +102,33 @@ __global__ __launch_bounds__(256) void fill_scaled_kernel(const float* __restric
     if (i < n) out[i] = g[0] * factor;
 }
 
+// sum over the K neighbours of dY = a1 * dYhat + q1 * y + q0 from the per-neighbourhood sums the BatchNorm-backward
+// reduction took (gsum[0] = sum dYhat, gsum[1] = sum y): out = K * q0 + a1 * gsum[0] + q1 * gsum[1], per channel.
+__global__ __launch_bounds__(256) void group_dy_sum_kernel(
+    const float* __restrict__ g0, const float* __restrict__ g1, const float* __restrict__ coef4,
+    float* __restrict__ out, long long total, int C, int G, float K)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / G) % C);
+    const float t = K * coef4[3 * C + c];
+    out[i] = (t + coef4[c] * g0[i]) + coef4[2 * C + c] * g1[i];
+}
+
 }  // namespace
+
+extern "C" int usip_bn_group_dy_sum_f32(const float* gsum0, const float* gsum1, const float* coef4, float* out,
+                                        int nb, int C, int G, int K, void* stream)
+{
+    if (nb < 0 || C < 1 || G < 0 || K < 1) return USIP_EINVAL;
+    const long long total = (long long)nb * C * G;
+    if (total == 0) return USIP_OK;
+    if (!gsum0 || !gsum1 || !coef4 || !out || (total + 255) / 256 > 0x7fffffffLL) return USIP_EINVAL;
+    USIP_LAUNCH(group_dy_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                gsum0, gsum1, coef4, out, total, C, G, (float)K);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
 
 extern "C" int usip_detector_head_f32(const float* ks, const float* centre, float sigma_lower_bound, float* keypoints,
                                       float* sigmas, int B, int M, void* stream)

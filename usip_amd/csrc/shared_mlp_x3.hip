@@ -74,6 +74,34 @@ __global__ __launch_bounds__(512) void split3_tiles_kernel(const float* __restri
         stage[s * (bm * 2) + row * 2 + ((half ^ (row >> 3)) & 1)] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
 }
 
+// The same for ALL weight operands of a step in one launch (a dozen 5-us launches otherwise): descs[i] names operand i
+// and the first workgroup of its range.
+__global__ __launch_bounds__(512) void split3_multi_kernel(const usip_split3_desc* __restrict__ descs, int n)
+{
+    int i = 0;
+    while (i + 1 < n && (int)blockIdx.x >= descs[i + 1].first_block) ++i;
+    const usip_split3_desc d = descs[i];
+    const int bm = d.tile_rows;
+    if ((int)threadIdx.x >= 2 * bm) return;
+    const int ksteps = (d.K + XBK - 1) / XBK, blk = blockIdx.x - d.first_block;
+    const int ks = blk % ksteps, mt = blk / ksteps;
+    const int row = threadIdx.x % bm, half = threadIdx.x / bm;
+    const int m = mt * bm + row;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = ks * XBK + half * 8 + j;
+        v[j] = (m < d.M && k < d.K) ? d.At[(long long)k * d.lda + m] : 0.0f;
+    }
+    unsigned p[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    uint4* stage = reinterpret_cast<uint4*>(d.planes) + (long long)blk * (3 * bm * 2);
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        stage[s * (bm * 2) + row * 2 + ((half ^ (row >> 3)) & 1)] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // amdgpu_waves_per_eu(2, 2): LDS already limits the kernel to two workgroups per CU; telling the register allocator
 // so stops it from aiming at three waves per SIMD and spilling the staged A planes to scratch around the MFMAs.
@@ -456,6 +484,23 @@ extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void*
     const int ksteps = (K + XBK - 1) / XBK, mts = (M + bm - 1) / bm;
     USIP_LAUNCH(split3_tiles_kernel, dim3((unsigned)(mts * ksteps)), dim3(2 * bm), 0, (hipStream_t)stream, At, lda, M, K,
                 reinterpret_cast<uint4*>(planes), ksteps, bm);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+extern "C" int usip_mlp_split3_blocks(int M, int K)
+{
+    if (M < 1 || K < 1) return 0;
+    const int bm = usip_mlp_x3p_tile_rows(M);
+    return ((M + bm - 1) / bm) * ((K + XBK - 1) / XBK);
+}
+
+extern "C" int usip_mlp_split3_multi_f32(const usip_split3_desc* descs_device, int n, int total_blocks, void* stream)
+{
+    if (n < 0 || total_blocks < 0) return USIP_EINVAL;
+    if (n == 0 || total_blocks == 0) return USIP_OK;
+    if (!descs_device) return USIP_EINVAL;
+    USIP_LAUNCH(split3_multi_kernel, dim3((unsigned)total_blocks), dim3(512), 0, (hipStream_t)stream, descs_device, n);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

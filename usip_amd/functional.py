@@ -604,8 +604,7 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         # this layer needs the per-neighbourhood sums as well, which only the stand-alone pass produces
         dgamma, dbeta, coef4, gsum = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink, group=K)
         # sum over the K neighbours of dY = a1*dYhat + q1*y + q0
-        sdy = torch.addcmul(torch.addcmul(float(K) * coef4[3].view(1, -1, 1), coef4[0].view(1, -1, 1), gsum[0]),
-                            coef4[2].view(1, -1, 1), gsum[1]).contiguous()
+        sdy = ops.bn_group_dy_sum(gsum, coef4, K)
         w2c = w2.contiguous()
         dpooled = dh = dw = None
         if ctx.needs_input_grad[3]:

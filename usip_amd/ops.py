@@ -290,6 +290,17 @@ def chamfer_prob_backward(gloss, a, J, c, I, sigma_src, sigma_dst):
     return da, dc, dss, dsd
 
 
+def bn_group_dy_sum(gsum, coef4, K: int):
+    """sum over each neighbourhood's K positions of dY, [nb,C,G], from gsum = (sum dYhat, sum y) (each [nb,C,G])."""
+    g0, g1 = gsum[0], gsum[1]
+    nb, C, G = g0.shape
+    out = torch.empty_like(g0)
+    with torch.cuda.device(g0.device), prof.kernel("bn_group_dy_sum", 12.0 * g0.numel()):
+        _lib.check(_lib.lib().usip_bn_group_dy_sum_f32(_ptr(g0), _ptr(g1), _ptr(coef4), _ptr(out), nb, C, G, int(K),
+                                                       _stream(g0)), "usip_bn_group_dy_sum_f32")
+    return out
+
+
 def detector_head(ks, centre, sigma_lower_bound: float):
     """ks [B,4,M] (mlp3 output), centre [B,3,M] -> (keypoints [B,3,M], sigmas [B,M]) (networks.py:150-154)."""
     _need(ks, "ks", torch.float32)
@@ -396,6 +407,39 @@ def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int) -> torch.Tens
     if PLANES_CACHE is not None:
         PLANES_CACHE[key] = (At, planes)      # holding At keeps its storage (the key) from being reused meanwhile
     return planes
+
+
+class PlanesPlan:
+    """The weight operands a step asks weight_planes() for, with persistent split images, refreshed by ONE launch at
+    the start of the step (twelve 5-us launches otherwise).  Built from the PLANES_CACHE of a completed step; only
+    operands inside the given persistent storages (parameters, their K-major copies) qualify -- their addresses are
+    the cache keys, and a temporary's address could be handed out again."""
+
+    def __init__(self, cache, storages):
+        import numpy as np
+        spans = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in storages if t is not None]
+        self.entries, rows, blocks = {}, [], 0
+        for key, (At, planes) in cache.items():
+            ptr, lda, off, M, K = key
+            if not any(lo <= ptr < hi for lo, hi in spans):
+                continue
+            self.entries[key] = (At, planes)
+            rows.append((ptr + 4 * off, planes.data_ptr(), lda, M, K, blocks, int(_lib.lib().usip_mlp_x3p_tile_rows(M)), 0))
+            blocks += int(_lib.lib().usip_mlp_split3_blocks(M, K))
+        self.blocks = blocks
+        dt = np.dtype([("At", "<u8"), ("planes", "<u8"), ("lda", "<i4"), ("M", "<i4"), ("K", "<i4"), ("first", "<i4"),
+                       ("tile_rows", "<i4"), ("reserved", "<i4")])
+        table = np.array(rows, dtype=dt) if rows else np.zeros(0, dtype=dt)
+        dev = next(iter(self.entries.values()))[1].device if rows else None
+        self.table = torch.from_numpy(table.view(np.uint8).copy()).to(dev) if rows else None
+
+    def refresh(self):
+        """Split every operand of the plan now; -> a PLANES_CACHE holding the fresh images."""
+        if self.table is not None:
+            with torch.cuda.device(self.table.device), prof.kernel("weight_split3", 0.0):
+                _lib.check(_lib.lib().usip_mlp_split3_multi_f32(_ptr(self.table), len(self.entries), self.blocks,
+                                                                _stream(self.table)), "usip_mlp_split3_multi_f32")
+        return dict(self.entries)
 
 
 # The narrow forward layers run the streaming kernel; USIP_NARROW_FWD=0 sends them through the generic tile kernel

@@ -126,6 +126,11 @@ class _GraphedStep:
         """Hook: host-side inputs the step adds to the batch (the descriptor's point permutation)."""
         return batch
 
+    def _static_from(self, batch):
+        """Hook: the persistent input buffers a captured graph reads (the caller's tensors are copied into them before
+        every replay)."""
+        return {k: v.clone() for k, v in batch.items()}
+
     def forward_losses(self, batch, epoch=None):
         raise NotImplementedError
 
@@ -140,10 +145,16 @@ class _GraphedStep:
                 flat_wt, table, tiles, views = self._wt
                 ops.multi_transpose(self.bucket.flat_param.data, flat_wt, table, tiles)
                 Fh.WT_CACHE = views
-            ops.PLANES_CACHE = {}                             # f32x3 mode: every weight operand is split once per step
+            # f32x3 mode: every weight operand is split into its bf16 planes once per step -- by one launch for all of
+            # them once a completed step has shown which operands are asked for
+            plan = getattr(self, "_planes_plan", None)
+            ops.PLANES_CACHE = plan.refresh() if plan is not None else {}
             Fh.PRE_BN_SUMS.clear()
             loss = self.forward_losses(batch, epoch)
             loss.backward()
+            if plan is None and ops.PLANES_CACHE and not torch.cuda.is_current_stream_capturing():
+                self._planes_plan = ops.PlanesPlan(ops.PLANES_CACHE, [self.bucket.flat_param,
+                                                                      self._wt[0] if self._wt is not None else None])
         finally:
             Fh.GRAD_SINK = False
             Fh.DEFER_BN_COUNTERS = False
@@ -196,7 +207,7 @@ class _GraphedStep:
             if self._eager_calls < 2:                         # allocator, rocBLAS handles, lazily built state
                 self._eager_calls += 1
                 return self._step_eager(batch, epoch, group)
-            static = {k: v.clone() for k, v in batch.items()}
+            static = self._static_from(batch)
             torch.cuda.synchronize(self.device)
             try:
                 # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
@@ -254,13 +265,24 @@ class DetectorStep(_GraphedStep):
         self.keypoint_on_pc_criteria = KeypointOnPCLoss(opt)
         self._setup(self.detector, opt, device, with_optimizer, graph)
 
+    _SIAMESE = (("src_pc", "dst_pc", "_cat_pc"), ("src_sn", "dst_sn", "_cat_sn"), ("src_node", "dst_node", "_cat_node"))
+
+    def _static_from(self, batch):
+        # src and dst halves as views of ONE buffer each: the siamese concatenation (keypoint_detector.py:141-146) then
+        # exists already when the captured step starts -- three torch.cat launches fewer per replay
+        static = {k: v.clone() for k, v in batch.items() if not any(k in t[:2] for t in self._SIAMESE)}
+        for a, b, both in self._SIAMESE:
+            cat = torch.cat((batch[a], batch[b]), 0)
+            n = batch[a].shape[0]
+            static[a], static[b], static[both] = cat[:n], cat[n:], cat
+        return static
+
     def forward_losses(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None):
         B = batch["src_pc"].shape[0]
         self.detector.train()                                 # keypoint_detector.py:171
-        pc = torch.cat((batch["src_pc"], batch["dst_pc"]), 0)
-        nodes, kp, sg, _ = self.detector(pc, torch.cat((batch["src_sn"], batch["dst_sn"]), 0),
-                                         torch.cat((batch["src_node"], batch["dst_node"]), 0),
-                                         True, epoch)         # forward_siamese :141-156
+        pc, sn, node = (batch[both] if both in batch else torch.cat((batch[a], batch[b]), 0)
+                        for a, b, both in self._SIAMESE)
+        nodes, kp, sg, _ = self.detector(pc, sn, node, True, epoch)   # forward_siamese :141-156
         kp_src, kp_dst = torch.split(kp, B, dim=0)            # :147-149 (split: one backward node, no zero fills)
         sg_src, sg_dst = torch.split(sg, B, dim=0)
         # :182-184  R.kp*s + t  as one batched GEMM with the scale folded into R (inputs, no gradient)
