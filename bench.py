@@ -89,7 +89,7 @@ def load_traffic_db(precision):
             src.append(os.path.basename(f))
         except (OSError, ValueError):
             pass
-    return db, (src[-1] if src else None)
+    return db, (", ".join(src[-3:]) if src else None)
 
 
 def kernel_leg(dev, traffic_db, iters=12):
@@ -350,6 +350,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": ("KITTI descriptor head N=%d, 256 keypoints, K=64, batch=%d pairs/GPU (BASELINE "
                                     "configs[4])" % (args.n, args.pairs)) if args.model == "descriptor" else
+                                   ("ModelNet40-shaped detector N=%d M=%d batch=%d pairs/GPU (BASELINE configs[1])"
+                                    % (args.n, args.m, args.pairs)) if (args.n, args.m) == (5000, 64) else
                                    ("KITTI detector N=%d M=%d K=64 batch=%d pairs/GPU (BASELINE configs[2])"
                                     % (args.n, args.m, args.pairs)),
                        "detector": {"ball": "RPN_Detector_Ball", "som": "RPN_Detector",
