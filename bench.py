@@ -24,8 +24,12 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails with
+# "hipIpcGetMemHandle: invalid argument" (already exported on the GPU boxes; kept here for any other launcher)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch                     # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -380,10 +384,15 @@ def main():
             kernels = []
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
-                ach = r["TFLOPs"] if mfma else r["GBps"]
                 # a split-product launch does six bf16 matrix products per fp32 product: its ceiling in fp32-equivalent
                 # flops is the dense bf16 peak / 6
-                peak = (PEAK_BF16_TFLOPS / 6.0 if is_x3(r) else mfma_peak) if mfma else PEAK_HBM_GBPS
+                mm_peak = PEAK_BF16_TFLOPS / 6.0 if is_x3(r) else mfma_peak
+                # the roofline that binds a shared-MLP launch is the one whose floor is higher: the narrow layers
+                # (64 inputs, 16 flop/B) are HBM-bound, the wide ones matrix-bound
+                if mfma and r["bytes_per_call"] / (PEAK_HBM_GBPS * 1e9) > r["flops_per_call"] / (mm_peak * 1e12):
+                    mfma = False
+                ach = r["TFLOPs"] if mfma else r["GBps"]
+                peak = mm_peak if mfma else PEAK_HBM_GBPS
                 kernels.append({"kernel": name, "calls_per_step": r["calls"] / timed_steps_sampled,
                                 "avg_us": round(r["avg_us"], 2),
                                 "share_of_step": round(r["total_ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
