@@ -86,10 +86,14 @@ __global__ __launch_bounds__(256) void ball_query_coords_kernel(
                 }
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    unsigned h = (usip_sqdist(ax[r], ay[r], az[r], px.x, py.x, pz.x) <= T ? 1u : 0u) |
-                                 (usip_sqdist(ax[r], ay[r], az[r], px.y, py.y, pz.y) <= T ? 2u : 0u) |
-                                 (usip_sqdist(ax[r], ay[r], az[r], px.z, py.z, pz.z) <= T ? 4u : 0u) |
-                                 (usip_sqdist(ax[r], ay[r], az[r], px.w, py.w, pz.w) <= T ? 8u : 0u);
+                    // two points per packed instruction (same arithmetic, bit for bit)
+                    const usip_f32x2 rx = {ax[r], ax[r]}, ry = {ay[r], ay[r]}, rz = {az[r], az[r]};
+                    const usip_f32x2 s01 = usip_sqdist2(rx, ry, rz, usip_f32x2{px.x, px.y}, usip_f32x2{py.x, py.y},
+                                                        usip_f32x2{pz.x, pz.y});
+                    const usip_f32x2 s23 = usip_sqdist2(rx, ry, rz, usip_f32x2{px.z, px.w}, usip_f32x2{py.z, py.w},
+                                                        usip_f32x2{pz.z, pz.w});
+                    unsigned h = (s01.x <= T ? 1u : 0u) | (s01.y <= T ? 2u : 0u) | (s23.x <= T ? 4u : 0u) |
+                                 (s23.y <= T ? 8u : 0u);
                     bits[r] = (ok && count[r] < K) ? h : 0u;
                     any |= bits[r];
                 }

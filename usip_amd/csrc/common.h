@@ -39,6 +39,18 @@ __device__ __forceinline__ float usip_sqdist(float ax, float ay, float az, float
     s = __builtin_fmaf(dz, dz, s);
     return s;
 }
+// Two of them at once on the packed-fp32 VALU (v_pk_add/mul/fma_f32: two IEEE operations per lane and instruction,
+// each rounded exactly like its scalar twin, in the same order) -- the brute-force distance loops are VALU-issue bound.
+typedef float usip_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ usip_f32x2 usip_sqdist2(usip_f32x2 ax, usip_f32x2 ay, usip_f32x2 az,
+                                                  usip_f32x2 bx, usip_f32x2 by, usip_f32x2 bz)
+{
+    const usip_f32x2 dx = ax - bx, dy = ay - by, dz = az - bz;
+    usip_f32x2 s = dx * dx;
+    s = __builtin_elementwise_fma(dy, dy, s);
+    s = __builtin_elementwise_fma(dz, dz, s);
+    return s;
+}
 __device__ __forceinline__ float usip_dist(float ax, float ay, float az, float bx, float by, float bz)
 {
     // sqrtf is the correctly rounded IEEE sqrt under hipcc's default

@@ -42,15 +42,29 @@ __global__ __launch_bounds__(256) void nearest_kernel(
         ax[r] = ab[i]; ay[r] = ab[Ma + i]; az[r] = ab[2 * Ma + i];
         best_s[r] = __builtin_inff(); best_d[r] = __builtin_inff(); best_j[r] = 0x7fffffff;
     }
+    static_assert(R % 2 == 0, "queries are processed in pairs");
+    usip_f32x2 qx[R / 2], qy[R / 2], qz[R / 2];
+#pragma unroll
+    for (int r = 0; r < R / 2; ++r) {
+        qx[r] = usip_f32x2{ax[2 * r], ax[2 * r + 1]};
+        qy[r] = usip_f32x2{ay[2 * r], ay[2 * r + 1]};
+        qz[r] = usip_f32x2{az[2 * r], az[2 * r + 1]};
+    }
     for (int j = jbeg + lane; j < jend; j += 64) {
         const float bx = bb[j], by = bb[Nb + j], bz = bb[2 * Nb + j];
+        const usip_f32x2 cx = {bx, bx}, cy = {by, by}, cz = {bz, bz};
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float s = usip_sqdist(ax[r], ay[r], az[r], bx, by, bz);
-            if (s < best_s[r]) {
-                best_s[r] = s;
-                const float d = sqrtf(s);
-                if (d < best_d[r]) { best_d[r] = d; best_j[r] = j; }
+        for (int r2 = 0; r2 < R / 2; ++r2) {
+            const usip_f32x2 s2 = usip_sqdist2(qx[r2], qy[r2], qz[r2], cx, cy, cz);   // two queries per packed instruction
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * r2 + h;
+                const float s = h ? s2.y : s2.x;
+                if (s < best_s[r]) {
+                    best_s[r] = s;
+                    const float d = sqrtf(s);
+                    if (d < best_d[r]) { best_d[r] = d; best_j[r] = j; }
+                }
             }
         }
     }

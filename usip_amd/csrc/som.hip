@@ -32,10 +32,22 @@ __global__ __launch_bounds__(256) void som_assign_kernel(
     const float px = xb[n], py = xb[N + n], pz = xb[2 * N + n];
     float best = __builtin_inff();
     int arg = 0;
-    for (int m = 0; m < M; ++m) {
+    // two nodes per packed instruction (v_pk_add/mul_f32: the same roundings in the same order), then the two
+    // comparisons in node order
+    const usip_f32x2 qx = {px, px}, qy = {py, py}, qz = {pz, pz};
+    int m = 0;
+    for (; m + 1 < M; m += 2) {
+        const usip_f32x2 dx = qx - usip_f32x2{nodes[m], nodes[m + 1]};
+        const usip_f32x2 dy = qy - usip_f32x2{nodes[M + m], nodes[M + m + 1]};
+        const usip_f32x2 dz = qz - usip_f32x2{nodes[2 * M + m], nodes[2 * M + m + 1]};
+        const usip_f32x2 d2 = (dx * dx + dy * dy) + dz * dz;             // contraction is off
+        if (d2.x < best) { best = d2.x; arg = m; }                       // first minimum wins
+        if (d2.y < best) { best = d2.y; arg = m + 1; }
+    }
+    if (m < M) {
         const float dx = px - nodes[m], dy = py - nodes[M + m], dz = pz - nodes[2 * M + m];
-        const float d2 = (dx * dx + dy * dy) + dz * dz;                  // contraction is off
-        if (d2 < best) { best = d2; arg = m; }                           // first minimum wins
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        if (d2 < best) { best = d2; arg = m; }
     }
     min_idx[(long long)b * N + n] = arg;
 }
