@@ -83,17 +83,37 @@ def load_traffic_db(precision):
     --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this same command; FETCH_SIZE doubled per MI355X_MICROARCH.md).
     Keyed by kernel template + workgroup count; a key shared by several layer shapes carries their average."""
     import glob
+    import re
+    # one file per (round tag, mode): rNNx_traffic_<mode>.json (older rounds: _traffic.json = f32x3 default run,
+    # _traffic_f32mode.json, _traffic_bf16.json).  Only files of THIS mode are read, and only the newest round tag
+    # that has one -- rows never mix modes or rounds.
+    def mode_of(name):
+        if "bf16" in name:
+            return "bf16"
+        if "f32mode" in name or "_f32." in name:
+            return "f32"
+        if "som" in name or "desc" in name:
+            return None
+        return "f32x3"
+    cands = []
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*traffic*.json")):
+        name = os.path.basename(f)
+        m = re.match(r"(r\d+[a-z]*)_", name)
+        if m and mode_of(name) == precision:
+            cands.append((m.group(1), f))
+    if not cands:
+        return {}, None
+    tag = max(t for t, _ in cands)
     db, src = {}, []
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
-        if ("bf16" in os.path.basename(f)) != (precision == "bf16"):
-            continue                               # the bf16 perf mode has its own kernels and PMC passes (f32 and
-            #                                        f32x3 kernels have distinct names and share one database)
+    for t, f in sorted(cands):
+        if t != tag:
+            continue
         try:
-            db.update(json.load(open(f)))          # later rounds override earlier ones key by key
+            db.update(json.load(open(f)))
             src.append(os.path.basename(f))
         except (OSError, ValueError):
             pass
-    return db, (", ".join(src[-3:]) if src else None)
+    return db, (", ".join(src) if src else None)
 
 
 def kernel_leg(dev, traffic_db, iters=12):
@@ -199,13 +219,33 @@ def cpu_baseline(args, model):
                                                      res[me]["s_per_step"]))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same
+    command line under torch.distributed.run on 127.0.0.1 with a free port) and pass rank 0's JSON line through.
+    Replaces nn.DataParallel's in-process replication (models/keypoint_detector.py:35-37)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, USIP_BENCH_SPAWNED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        # a launcher started another number of ranks than --gpus says: the line must not claim N it did not run
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
     # One process per GPU over RCCL ("nccl" IS RCCL on ROCm).  USIP_DIST_BACKEND=gloo + USIP_SHARE_DEVICE=1 is a
     # debugging aid only: it lets the N>1 code path run with several ranks on ONE GPU (RCCL refuses that).
     backend = os.environ.get("USIP_DIST_BACKEND", "nccl")
@@ -231,8 +271,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from usip_amd import functional as Fh
     from usip_amd import ops, prof, synth
     from usip_amd.networks import DetectorOptions
+    assert not Fh.pins_active(), "bench.py never runs with the decision-pinning test hooks"
     if args.only_kernels:
         print(json.dumps({"kernels": kernel_leg(dev, load_traffic_db(args.precision)[0])}), flush=True)
         return
@@ -280,6 +322,8 @@ def main():
         st.step(batch)
     torch.cuda.synchronize()
     barrier()
+    if world > 1:
+        st.allreduce_events = []                           # two HIP events around every gradient all-reduce
     # Per-kernel HIP events cost ~3 us of stream bubble each (~0.7 ms per step for ~220 of them): they are
     # recorded on every 4th step (1-GPU eager runs) or on one middle step only (graph replay, multi-GPU), which keeps the headline
     # number within ~1.5 % of an uninstrumented run while the kernel durations still come from inside the
@@ -319,6 +363,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(st.last["loss"].item())
+    census = None
+    if world > 1:
+        # who took part: every rank reports its device; all-reduce durations (max over ranks per percentile) and the
+        # per-rank step time, so that the line shows that RCCL saw N ranks on N devices and what the exchange cost
+        ar_events, st.allreduce_events = st.allreduce_events[:args.steps], None
+        ar = sorted(s.elapsed_time(e) * 1e3 for s, e in ar_events)
+        props = torch.cuda.get_device_properties(dev)
+        mine = dict(rank=rank, local_rank=local_rank, device_index=dev.index, pid=os.getpid(),
+                    device_name=props.name, device_uuid=str(getattr(props, "uuid", "")),
+                    pci_bus_id=int(getattr(props, "pci_bus_id", -1)), step_ms_wall=elapsed / args.steps * 1e3,
+                    allreduce_us_p50=ar[len(ar) // 2] if ar else None,
+                    allreduce_us_p90=ar[min(len(ar) - 1, int(0.9 * len(ar)))] if ar else None,
+                    allreduce_calls=len(ar), loss=loss_val)
+        census = [None] * world
+        dist.all_gather_object(census, mine)
     summ = None
     if not args.no_kernel_timing:
         summ = prof.summary()
@@ -369,6 +428,26 @@ def main():
                        "parallelism": "dp%d" % world},
             "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,
         }
+        if census is not None:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:                              # noqa: BLE001  (gloo debugging runs have no RCCL)
+                rccl = None
+            out["ranks_seen"] = [{k: c[k] for k in ("rank", "local_rank", "device_index", "device_uuid", "pci_bus_id",
+                                                    "device_name", "pid")} for c in census]
+            out["distributed"] = {
+                "backend": backend, "rccl_version": rccl if backend == "nccl" else None, "world_size": world,
+                "distinct_devices": len({(c["device_index"], c["device_uuid"], c["pci_bus_id"]) for c in census}),
+                "bucket_bytes": int(st.bucket.flat.numel() * 4), "allreduce_per_step": 1,
+                "allreduce_us": {"p50": max(c["allreduce_us_p50"] or 0.0 for c in census),
+                                 "p90": max(c["allreduce_us_p90"] or 0.0 for c in census),
+                                 "calls_timed_per_rank": min(c["allreduce_calls"] for c in census),
+                                 "how": "HIP events on the launch stream around all_reduce(SUM) + 1/world scale, every "
+                                        "step of the timed region, max over ranks of each rank's percentile"},
+                "step_ms_per_rank": [round(c["step_ms_wall"], 4) for c in census],
+                "loss_per_rank": [c["loss"] for c in census],
+                "launcher": "self-spawned torch.distributed.run" if os.environ.get("USIP_BENCH_SPAWNED") else
+                            "external launcher"}
         raw_steps = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         per_step = sorted(raw_steps)
         if per_step:

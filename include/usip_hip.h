@@ -394,6 +394,14 @@ int usip_group_max_backward_add_f32(const float* dpooled, const int32_t* arg, fl
 int usip_knn_f32(const float* query, const float* database, int32_t* idx,
                  int B, int M, int N, int K, void* stream);
 
+/* ------------------------------------------------------------------ (judge row) RPN_Detector_KNN front end
+ * idx[b][m][0..K) = the K cloud points nearest to node m, nearest first, ties towards the lower index:
+ * torch.norm(node - x) over B x M x N followed by torch.topk(k=64, largest=False, sorted=False) of
+ * models/networks.py:576-581 without the matrix.  topk(sorted=False) leaves the order of the picks unspecified;
+ * the SET is the reference's, the order is that of a stable sort of the reference's distance row.
+ * node f32 [B][3][M], x f32 [B][3][N], K <= min(N, 256), N <= 16384. */
+int usip_knn_points_f32(const float* node, const float* x, int32_t* idx, int B, int M, int N, int K, void* stream);
+
 /* ------------------------------------------------------------------ f-3  farthest-point sampling of nodes
  * Replaces FarthestSampler.sample (data/kitti_detector_loader.py:69-83; also oxford_detector_loader.py,
  * modelnet_shrec_loader.py): out_idx[b][0] = first_idx[b], then k-1 times the first arg-max of the running

@@ -268,6 +268,39 @@ def rpn_detector_ball_forward(P: Params, bufs, x, sn, node, node_knn_k: int,
     return dict(node=node, keypoints=keypoints, sigmas=sigmas, ball_idx=ball_idx, knn_I=knn_I, pool_args=pools)
 
 
+def knn_rows_canonical(dist: torch.Tensor, k: int) -> torch.Tensor:
+    """The k nearest columns of every row of dist [B,M,N], nearest first, ties towards the lower index.
+    torch.topk(sorted=False) (networks.py:581) leaves the ORDER of the k picks unspecified and nothing downstream
+    depends on it (the neighbours are max-pooled; BatchNorm statistics are sums), so the decision that is pinned
+    is the SET, written in this canonical order."""
+    order = torch.sort(dist, dim=2, stable=True)[1]
+    return order[:, :, :k].contiguous()
+
+
+def rpn_detector_knn_forward(P: Params, bufs, x, sn, node, node_knn_k: int,
+                             sigma_lower_bound: float, train: bool = True, k: int = 64):
+    """RPN_Detector_KNN.forward (networks.py:563-608): the Ball detector with the ball query replaced by the
+    k = 64 nearest points of every node (k hard-coded at :574, topk(sorted=False) at :581)."""
+    x_aug = torch.cat((x, sn), dim=1)
+    dist = pairwise_norm(node, x)                           # B,M,N
+    nn_idx = _decide("nn", lambda: knn_rows_canonical(dist.detach(), k))
+    g = gather_neighbours(x_aug, nn_idx)
+    g = torch.cat((g[:, 0:3] - node.unsqueeze(3), g[:, 3:]), dim=1)   # in-place at :587
+    h = g
+    for name in ("conv1", "conv2", "conv3"):
+        h = shared_mlp(h, P, bufs, name, train)
+    pools = []
+    pooled = _max_over_k(h, True, pools)
+    h = torch.cat((h, pooled.expand_as(h)), dim=1)          # (features, max) :593
+    for name in ("conv4", "conv5"):
+        h = shared_mlp(h, P, bufs, name, train)
+    second_max = _max_over_k(h, False, pools)
+    knn_feat, knn_I = knn_fusion(P, bufs, "knnlayer_1", node, node, second_max, node_knn_k, train, pools)
+    agg = torch.cat((second_max, knn_feat), dim=1)
+    keypoints, sigmas = head(P, bufs, agg, node, sigma_lower_bound, train)
+    return dict(node=node, keypoints=keypoints, sigmas=sigmas, nn_idx=nn_idx, knn_I=knn_I, pool_args=pools)
+
+
 # --------------------------------------------------------------------------- losses
 def chamfer_prob(src, dst, sigma_src, sigma_dst):
     """ChamferLoss_Brute.forward with both sigmas given (losses.py:59-99).
@@ -299,7 +332,10 @@ def detector_step(P: Params, bufs, batch: Dict[str, torch.Tensor], model: str, n
     siamese forward on cat(src, dst), rigid transform of the src keypoints, probabilistic
     chamfer + 2x keypoint-on-pc, backward.  P tensors must have requires_grad=True;
     gradients land in P[k].grad.  Returns a dict of every observable of the step."""
-    fwd = rpn_detector_ball_forward if model == "ball" else rpn_detector_forward
+    # "lite" (RPN_DetectorLite, networks.py:165-307) is RPN_Detector at half the widths: the same restatement, the
+    # widths come with the parameter shapes
+    fwd = {"ball": rpn_detector_ball_forward, "knn": rpn_detector_knn_forward,
+           "som": rpn_detector_forward, "lite": rpn_detector_forward}[model]
     B = batch["src_pc"].shape[0]
     out = fwd(P, bufs,
               torch.cat((batch["src_pc"], batch["dst_pc"]), 0),
@@ -336,24 +372,27 @@ def descriptor_forward(P: Params, bufs, x, sn, keypoints, perm, radius: float, K
     h = g
     for name in ("conv1", "conv2", "conv3"):
         h = shared_mlp(h, P, bufs, name, train)
-    pooled, _ = torch.max(h, dim=3, keepdim=True)
+    pools = []
+    pooled = _max_over_k(h, True, pools)
     h = torch.cat((h, pooled.expand_as(h)), dim=1)
     h = shared_mlp(h, P, bufs, "conv4", train)
     h = shared_mlp(h, P, bufs, "conv5", train)              # no norm parameters -> plain conv
-    d, _ = torch.max(h, dim=3, keepdim=False)
+    d = _max_over_k(h, False, pools)
     d = d / (torch.norm(d, dim=1, keepdim=True) + 1e-5)
     return d, g, ball_idx
 
 
 def desc_pair_scan_loss(anc, pos, neg, anc_sigmas, gamma: float, sigma_max: float):
     """DescPairScanLoss.forward (losses.py:200-237)."""
-    d_pos, _ = torch.min(torch.norm(anc.unsqueeze(3) - pos.unsqueeze(2), dim=1), dim=2)
-    d_neg, _ = torch.min(torch.norm(anc.unsqueeze(3) - neg.unsqueeze(2), dim=1), dim=2)
+    d_pos, J_pos = _min_over(torch.norm(anc.unsqueeze(3) - pos.unsqueeze(2), dim=1), 2)
+    d_neg, J_neg = _min_over(torch.norm(anc.unsqueeze(3) - neg.unsqueeze(2), dim=1), 2)
     before = d_pos - d_neg + gamma
-    active = torch.mean((before > 0).float(), dim=1)
+    on = _decide("hinge", lambda: (before > 0).detach())     # clamp(min=0): the term is active or not
+    active = torch.mean(on.float(), dim=1)
     w = torch.clamp(sigma_max - anc_sigmas, min=0)
     w = (w / torch.mean(w, dim=1, keepdim=True)).detach()
-    return w * torch.clamp(before, min=0), active
+    hinge = torch.clamp(before, min=0) if TAPE is None else torch.where(on, before, torch.zeros_like(before))
+    return w * hinge, active, (J_pos, J_neg)
 
 
 def descriptor_step(P: Params, bufs, batch, perm, radius=2, K=64, gamma=0.5, sigma_max=3.0):
@@ -363,11 +402,12 @@ def descriptor_step(P: Params, bufs, batch, perm, radius=2, K=64, gamma=0.5, sig
         P, bufs, torch.cat((batch["anc_pc"], batch["pos_pc"]), 0), torch.cat((batch["anc_sn"], batch["pos_sn"]), 0),
         torch.cat((batch["anc_kp"], batch["pos_kp"]), 0), perm, radius, K, True)
     anc, pos = desc[:B], desc[B:]
-    trip, active = desc_pair_scan_loss(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"], gamma, sigma_max)
+    trip, active, (J_pos, J_neg) = desc_pair_scan_loss(anc, pos, anc[batch["neg_idx"], :, :], batch["anc_sigmas"],
+                                                       gamma, sigma_max)
     loss = torch.mean(trip)
     loss.backward()
     return dict(descriptors=desc, x_features=feat, ball_idx=ball_idx, triplet=trip, active=active,
-                loss=loss.detach())
+                loss=loss.detach(), nn_pos=J_pos, nn_neg=J_neg)
 
 
 def to_numpy(d):

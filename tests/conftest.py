@@ -49,3 +49,28 @@ def assert_close(actual, expected, rel=1e-5, name=""):
     err = float(np.abs(actual - expected).max()) / scale if expected.size else 0.0
     assert err <= rel, "%s: max err / scale = %.3e > %.1e" % (name, err, rel)
     return err
+
+
+@pytest.fixture(params=["f32", "f32x3"])
+def matmul_mode(request):
+    """The two fp32-accurate arithmetic modes of the shared-MLP kernels: "f32" = fp32 MFMA everywhere, "f32x3" = the
+    mode bench.py times by default (six bf16-plane products per fp32 product).  The fixtures are small, and at small
+    sizes the f32x3 dispatcher hands most launches to the fp32 kernel (it only takes matrix-bound launches that fill
+    the chip), so here the split-product kernels are FORCED wherever their tile applies -- the test then exercises
+    the arithmetic the full-size step runs, not a mode switch that changes nothing."""
+    from usip_amd import _lib, ops
+    prev = ops.set_matmul_mode(request.param)
+    if request.param == "f32x3":
+        _lib.lib().usip_set_tuning(b"gemm_split3", 2)
+    yield request.param
+    _lib.lib().usip_set_tuning(b"gemm_split3", 0)
+    ops.set_matmul_mode(prev)
+
+
+@pytest.fixture(params=["f32", "f32x3"])
+def matmul_mode_natural(request):
+    """The same two modes with the dispatcher's own choice of kernel per launch: for tests at bench.py's full size."""
+    from usip_amd import ops
+    prev = ops.set_matmul_mode(request.param)
+    yield request.param
+    ops.set_matmul_mode(prev)

@@ -390,6 +390,17 @@ def capture_indices(networks_mod, som_mod):
         r = orig_topk(*a, **kw)
         if kw.get("sorted", True) and kw.get("largest", True) is False:
             rec["knn_I"] = r[1].numpy().astype(np.int32).copy()
+        elif kw.get("largest", True) is False and kw.get("k", 1) > 1 and a[0].dim() == 3:
+            # RPN_Detector_KNN's point neighbourhoods (networks.py:581): topk(sorted=False) leaves the ORDER of the
+            # k picks unspecified, so the fixture pins the SET, written nearest first with ties towards the lower
+            # index; `_nn_pos` maps a position in the reference's order to the position in that canonical order
+            # (used below to re-express the reference's max-pool / ReLU decisions, which are positions in ITS order)
+            k = kw["k"]
+            canon = torch.sort(a[0], dim=2, stable=True)[1][:, :, :k]
+            ref = r[1]
+            assert torch.equal(torch.sort(ref, dim=2)[0], torch.sort(canon, dim=2)[0]), "tie at the k-th distance"
+            rec["nn_idx"] = canon.numpy().astype(np.int32).copy()
+            rec["_nn_pos"] = (ref.unsqueeze(3) == canon.unsqueeze(2)).float().argmax(3).numpy().astype(np.int64)
         return r
 
     orig_max = torch.max
@@ -426,6 +437,53 @@ def capture_indices(networks_mod, som_mod):
         torch.max = orig_max
         torch.nn.ReLU.forward = orig_relu
     return rec, restore
+
+
+def reorder_neighbour_decisions(rec, n_layers):
+    """RPN_Detector_KNN: the reference's decisions over its own (unspecified) neighbour order, re-expressed over the
+    canonical order of idx/nn_idx: the first two max-pools (over the point neighbourhoods) and the near-zero ReLU
+    lists of conv1..conv5."""
+    pos = rec.pop("_nn_pos")                                  # [B,M,K]: canonical position of the reference's k-th pick
+    B, M, K = pos.shape
+    for i in range(2):
+        arg = rec["pool_arg_%d" % i].astype(np.int64)        # [B,C,M]
+        rec["pool_arg_%d" % i] = np.take_along_axis(pos[:, None].repeat(arg.shape[1], 1), arg[..., None], 3)[..., 0] \
+            .astype(np.int8)
+    for i in range(n_layers):
+        flat = rec["relu_near_idx_%d" % i].astype(np.int64)
+        C = int(rec["relu_numel_%d" % i]) // (B * M * K)
+        b, c, m, k = np.unravel_index(flat, (B, C, M, K))
+        new = np.ravel_multi_index((b, c, m, pos[b, m, k]), (B, C, M, K))
+        order = np.argsort(new, kind="stable")
+        rec["relu_near_idx_%d" % i] = new[order].astype(np.int32)
+        rec["relu_near_on_%d" % i] = rec["relu_near_on_%d" % i][order]
+
+
+def gen_detectors_r3(networks, losses, som):
+    """Round 3: the reference's other two detector call sequences on this surface -- RPN_DetectorLite
+    (networks.py:165-307: what every indoor train_detector.py builds) and RPN_Detector_KNN (:482-608)."""
+    opt = Opt(surface_normal_len=3, node_knn_k_1=16, loss_sigma_lower_bound=1e-4)
+    batch = synth.make_pair_batch(seed=3131, pairs=2, n=1280, m=48, cs=3, kind="sphere")
+    net = networks.RPN_DetectorLite(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=1.0)
+    restore()
+    save("detector_lite_micro.npz", cfg_model="lite", cfg_knn=np.int32(16), cfg_sigma_lb=np.float32(1e-4),
+         cfg_alpha=np.float32(1.0), **{"in/" + k: v for k, v in batch.items()},
+         **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+    opt = Opt(surface_normal_len=4, node_knn_k_1=16, loss_sigma_lower_bound=1e-3)
+    batch = synth.make_pair_batch(seed=5151, pairs=2, n=2048, m=64, cs=4, kind="slab:14")
+    net = networks.RPN_Detector_KNN(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=0.01)
+    restore()
+    reorder_neighbour_decisions(rec, 5)
+    save("detector_knn_micro.npz", cfg_model="knn", cfg_knn=np.int32(16), cfg_sigma_lb=np.float32(1e-3),
+         cfg_alpha=np.float32(0.01), **{"in/" + k: v for k, v in batch.items()},
+         **{"idx/" + k: v for k, v in rec.items()}, **out)
 
 
 def gen_detectors(networks, losses, som):
@@ -490,11 +548,13 @@ def gen_descriptor(networks, losses):
     net.train()
     orig = np.random.permutation
     np.random.permutation = lambda n: perm.copy()
+    rec, restore = capture_indices(networks, None)           # round 3: the two max-pool routings + near-zero ReLUs
     try:
         desc, x_feat = net(torch.from_numpy(np.concatenate([anc, pos])), torch.from_numpy(np.concatenate([anc_sn, pos_sn])),
                            torch.from_numpy(np.concatenate([anc_kp, pos_kp])), True, None)
     finally:
         np.random.permutation = orig
+        restore()
     anc_d, pos_d = desc[:B], desc[B:]
     net.zero_grad()
     trip, active = losses.DescPairScanLoss(opt)(anc_d, pos_d, anc_d[torch.from_numpy(neg_idx), :, :],
@@ -506,6 +566,7 @@ def gen_descriptor(networks, losses):
                x_features=x_feat.detach().numpy(), triplet=trip.detach().numpy(), active=active.numpy(),
                loss=loss.detach().numpy())
     out.update(grad_digest(net))
+    out.update({"idx/" + k: v for k, v in rec.items() if k.startswith(("pool_arg_", "relu_n"))})
     for k, v in net.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             out["buf/" + k] = v.numpy().copy()
@@ -586,6 +647,9 @@ if __name__ == "__main__":
     if "--only-detectors" in sys.argv:
         gen_detectors(networks, losses, som)
         sys.exit(0)
+    if "--only-detectors-r3" in sys.argv:
+        gen_detectors_r3(networks, losses, som)
+        sys.exit(0)
     if "--only-bn-decay" in sys.argv:
         gen_bn_decay(layers)
         sys.exit(0)
@@ -596,5 +660,6 @@ if __name__ == "__main__":
     gen_bn_decay(layers)
     gen_losses(losses)
     gen_detectors(networks, losses, som)
+    gen_detectors_r3(networks, losses, som)
     gen_descriptor(networks, losses)
     gen_pre_post(networks)

@@ -397,3 +397,44 @@ def test_detector_tail_elementwise_ops_match_torch():
     for a, b, name in zip(run(True), run(False), ("kp", "sigma", "kp_t", "loss", "on_src", "on_dst", "dks", "dd")):
         scale_ = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, scale_), name
+
+
+@pytest.mark.parametrize("case", [(2, 40, 2048, 64, "slab:14"), (1, 17, 16384, 64, "slab"), (3, 9, 300, 64, "sphere"),
+                                  (2, 5, 64, 64, "sphere"), (1, 33, 5000, 16, "sphere"), (1, 8, 777, 200, "slab:10")])
+def test_knn_points_matches_stable_sort_of_the_distance_rows(case):
+    """usip_knn_points_f32 (RPN_Detector_KNN front end, models/networks.py:576-581): the K nearest cloud points of
+    every node, nearest first, ties towards the lower index == the first K columns of a stable sort of the
+    torch.norm distance row (oracle/detector.py knn_rows_canonical), bit for bit; and as a SET it is what
+    torch.topk(sorted=False) picks."""
+    from oracle import detector as od
+    from usip_amd import ops, synth
+    B, M, N, K, kind = case
+    rng = np.random.default_rng(B * 1000 + N + K)
+    x = np.stack([synth.make_cloud(rng, N, kind) for _ in range(B)])
+    node = np.ascontiguousarray(np.stack([x[b][:, rng.permutation(N)[:M]] for b in range(B)]))
+    node[0, :, 0] += 0.37                                       # a node that is not a cloud point
+    got = ops.knn_points(torch.from_numpy(node).to(DEV), torch.from_numpy(x).to(DEV), K).cpu()
+    dist = od.pairwise_norm(torch.from_numpy(node), torch.from_numpy(x))
+    want = od.knn_rows_canonical(dist, K)
+    assert torch.equal(got.long(), want)
+    ref = torch.topk(dist, k=K, dim=2, largest=False, sorted=False)[1]
+    assert torch.equal(torch.sort(ref, dim=2)[0], torch.sort(got.long(), dim=2)[0])
+
+
+def test_knn_points_degenerate_clouds_take_the_exact_path():
+    """Clouds padded by repetition (thousands of points at the same few distances) overflow the candidate list of the
+    fast path; the bisection path must return the same canonical rows: ties towards the lower index."""
+    from oracle import detector as od
+    from usip_amd import ops
+    rng = np.random.default_rng(5)
+    B, M, N, K = 2, 12, 8192, 64
+    base = rng.normal(0, 3, (B, 3, 40)).astype(np.float32)
+    x = np.ascontiguousarray(base[:, :, rng.integers(0, 40, N)])          # 40 distinct points, ~200 copies each
+    x[1, :, :3000] = rng.normal(0, 3, (3, 3000)).astype(np.float32)       # second cloud: part distinct, part repeated
+    node = np.ascontiguousarray(x[:, :, :M] + np.float32(0.01))
+    got = ops.knn_points(torch.from_numpy(node).to(DEV), torch.from_numpy(x).to(DEV), K).cpu()
+    want = od.knn_rows_canonical(od.pairwise_norm(torch.from_numpy(node), torch.from_numpy(x)), K)
+    assert torch.equal(got.long(), want)
+    allsame = np.zeros((1, 3, 4096), np.float32)                           # every distance equal: rows are 0..K-1
+    got = ops.knn_points(torch.zeros(1, 3, 4, device=DEV) + 1.0, torch.from_numpy(allsame).to(DEV), K).cpu()
+    assert torch.equal(got, torch.arange(K, dtype=torch.int32).expand(1, 4, K))

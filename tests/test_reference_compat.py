@@ -37,10 +37,13 @@ SCRIPT = textwrap.dedent("""
     opt.bn_momentum, opt.bn_momentum_decay_step, opt.bn_momentum_decay = 0.1, None, 0.6
     opt.k, opt.node_knn_k_1, opt.loss_sigma_lower_bound = 1, 16, 1e-3
     out = {}
-    for cls in ("RPN_Detector", "RPN_Detector_Ball", "RPN_Detector_KNN"):
+    for cls in ("RPN_Detector", "RPN_DetectorLite", "RPN_Detector_Ball", "RPN_Detector_KNN"):
         net = getattr(networks, cls)(opt)
         out[cls] = {k: list(v.shape) for k, v in net.state_dict().items()}
         out[cls + "/layer_module"] = type(net.mlp1).__module__
+        if mode == "ours":                                   # the fused classes of usip_amd.networks: same keys, shapes
+            from usip_amd import networks as fused
+            out[cls + "/fused"] = {k: list(v.shape) for k, v in getattr(fused, cls)(opt).state_dict().items()}
     print(json.dumps(out))
 """) % (ROOT, REF)
 
@@ -53,7 +56,8 @@ def test_reference_networks_builds_unchanged_on_our_modules():
         p = subprocess.run([sys.executable, "-c", SCRIPT, mode], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
         res[mode] = json.loads(p.stdout.strip().splitlines()[-1])
-    for cls in ("RPN_Detector", "RPN_Detector_Ball", "RPN_Detector_KNN"):
+    for cls in ("RPN_Detector", "RPN_DetectorLite", "RPN_Detector_Ball", "RPN_Detector_KNN"):
         assert res["ours"][cls] == res["theirs"][cls], cls           # same keys, same shapes
+        assert res["ours"][cls + "/fused"] == res["theirs"][cls], cls    # usip_amd.networks' own classes too
         assert res["ours"][cls + "/layer_module"] == "usip_amd.layers"
         assert res["theirs"][cls + "/layer_module"] == "models.layers"

@@ -53,6 +53,55 @@ WT_CACHE = None
 PIN_POOL_ARGS = None
 
 
+class pinned_decisions:
+    """THE one switch of the two test hooks (PIN_POOL_ARGS here, PIN_RELU_FIX below): a context manager that
+    installs the given decisions and ALWAYS removes them again, so that a failing test cannot leave them behind.
+
+        with Fh.pinned_decisions(pools=[...], relu_fix=[...]) as pins:
+            step.step(batch)            # a step object built with allow_pinned_decisions=True
+        pins.flips                      # nudged ReLU decisions per layer; pins.leftover: decisions nobody consumed
+
+    Outside this context the hooks are inert; usip_amd.step refuses to run (and bench.py asserts it never does)
+    with pins active unless the step object was created for such a test."""
+
+    def __init__(self, pools=None, relu_fix=None, record=False):
+        """record=True: take no decisions from outside; instead keep this forward's own (`.pools`: the arg-max of
+        every pool, `.relu`: (flat index, on) of every pre-activation within PIN_RECORD_NEAR of zero per BatchNorm +
+        ReLU layer), in the form another run accepts as pools= / relu_fix=."""
+        self._pools = None if pools is None else list(pools)
+        self._relu = None if relu_fix is None else list(relu_fix)
+        self._record = bool(record)
+        self.flips, self.leftover, self.pools, self.relu = [], None, [], []
+
+    def __enter__(self):
+        global PIN_POOL_ARGS, PIN_RELU_FIX, PIN_RECORD
+        if pins_active():
+            raise RuntimeError("usip_amd: pinned_decisions does not nest")
+        if self._record:
+            PIN_RECORD = self
+        else:
+            PIN_POOL_ARGS, PIN_RELU_FIX = self._pools, self._relu
+        PIN_RELU_FLIPS.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global PIN_POOL_ARGS, PIN_RELU_FIX, PIN_RECORD
+        self.leftover = (len(PIN_POOL_ARGS or []), len(PIN_RELU_FIX or []))
+        self.flips = list(PIN_RELU_FLIPS)
+        PIN_POOL_ARGS = PIN_RELU_FIX = PIN_RECORD = None
+        PIN_RELU_FLIPS.clear()
+        return False
+
+
+PIN_RECORD = None            # the pinned_decisions(record=True) context that is open, if any
+PIN_RECORD_NEAR = 1e-4       # as tests/golden/make_golden.py RELU_NEAR
+
+
+def pins_active() -> bool:
+    """True while a pinned_decisions context is open (test-only state; the product never sets it)."""
+    return PIN_POOL_ARGS is not None or PIN_RELU_FIX is not None or PIN_RECORD is not None
+
+
 def _pooled_act(y4, coef, relu, want_yarg=False):
     """(max over K of the lazily activated y4 [B,C,M,K], arg-max i32 [B,C,M][, y4 at the arg-max]); coef None: y4 is
     already activated."""
@@ -61,6 +110,8 @@ def _pooled_act(y4, coef, relu, want_yarg=False):
         pooled, arg, yarg = ops.group_max_act(y4, coef, relu, want_yarg=True)
     else:
         pooled, arg = ops.group_max_act(y4, coef, relu) if coef is not None else ops.group_max(y4)
+    if PIN_RECORD is not None:
+        PIN_RECORD.pools.append(arg.clone())
     if PIN_POOL_ARGS is not None:
         arg = PIN_POOL_ARGS.pop(0).to(device=y4.device, dtype=torch.int32).contiguous()
         if tuple(arg.shape) != tuple(y4.shape[:3]):
@@ -84,6 +135,19 @@ def _pooled_act(y4, coef, relu, want_yarg=False):
 PIN_RELU_FIX = None
 PIN_RELU_MARGIN = 5e-5
 PIN_RELU_FLIPS = []          # number of nudged elements per layer, for the test's report
+
+
+def _relu_hook(y, coef):
+    """Called by every BatchNorm + ReLU layer with its pre-BN output: the identity unless a pinned_decisions context
+    is open."""
+    if PIN_RECORD is not None:
+        z = ops.bn_apply(y, coef, False).reshape(-1)
+        idx = torch.nonzero(z.abs() < PIN_RECORD_NEAR).reshape(-1)
+        PIN_RECORD.relu.append((idx, z[idx] > 0))
+        return y
+    if PIN_RELU_FIX is not None:
+        return _align_relu_decisions(y, coef)
+    return y
 
 
 def _align_relu_decisions(y, coef):
@@ -340,10 +404,27 @@ def as_tensor(x):
 
 # BatchNorm-backward partial sums that the kernel PRODUCING a gradient tensor already took (the fused narrow backward
 # has the tile of dX in registers and the tile of the producing layer's pre-BN output in LDS):
-#   {dz.data_ptr(): (shape of dz, [partials [2, rows, C], ...])}
-# The layer that receives that tensor as its incoming gradient then skips its own pass over (dZ, Y).  Entries are
-# consumed by the receiver; the training step clears the table at the start of every step.
+#   {dz.data_ptr(): (shape of dz, [partials [2, rows, C], ...], dz._version when the sums were taken)}
+# The layer that receives that tensor as its incoming gradient then skips its own pass over (dZ, Y).
+# Entries are only registered inside the training step (GRAD_SINK: one consumer per tensor, no hooks, no retained
+# graph), are ALWAYS removed by the receiver whether it can use them or not, carry the tensor's version counter so
+# that a gradient autograd accumulated into in place (a second consumer) is recognised as changed, and the step
+# clears the table when it starts and when it ends -- a stale entry can never meet a recycled address.
 PRE_BN_SUMS = {}
+
+
+def _register_pre_bn_sums(dx, partials):
+    if GRAD_SINK:
+        PRE_BN_SUMS[dx.data_ptr()] = (tuple(dx.shape), partials, dx._version)
+
+
+def _take_pre_bn_sums(dz, shape=None):
+    """The partial sums registered for exactly this tensor (address, shape, unmodified since), else None; the entry
+    is removed either way."""
+    pre = PRE_BN_SUMS.pop(dz.data_ptr(), None)
+    if pre is None or pre[0] != tuple(dz.shape if shape is None else shape) or pre[2] != dz._version:
+        return None
+    return pre
 
 
 def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
@@ -352,8 +433,8 @@ def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
     (Folding these sums into the consuming layer's data-gradient GEMM epilogue for the MFMA-bound layers was
     implemented and measured slower -- their epilogue is not overlapped -- and removed)"""
     go, bo = (sink[2], sink[3]) if sink else (None, None)
-    pre = PRE_BN_SUMS.pop(dz.data_ptr(), None) if (group == 0 and relu) else None
-    if pre is not None and pre[0] == tuple(dz.shape):
+    pre = _take_pre_bn_sums(dz)                  # removed even when this layer cannot use them
+    if pre is not None and group == 0 and relu:
         return ops.bn_backward_from_partials(pre[1], dz.shape[0] * dz.shape[2], coef, mean, invstd, go, bo)
     dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, relu, group=group,
                                                         dgamma_out=go, dbeta_out=bo)
@@ -404,8 +485,8 @@ class _SharedMLPLayer(torch.autograd.Function):
             y, stats = ops.mlp_gemm(wt, x, bias, want_stats=True, pro=pro, coef=xcoef)
             mean, invstd, coef = ops.bn_finalize(stats, nb * P, gamma, beta, eps, momentum,
                                                  running_mean, running_var)
-            if PIN_RELU_FIX is not None and relu:
-                y = _align_relu_decisions(y, coef)
+            if relu:
+                y = _relu_hook(y, coef)
         else:
             y, _ = ops.mlp_gemm(wt, x, bias, pro=pro, coef=xcoef)
             invstd = torch.rsqrt(running_var + eps)
@@ -445,13 +526,13 @@ class _SharedMLPLayer(torch.autograd.Function):
         x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
         if (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
-                and ops.narrow_backward_supported(x.shape[1], w2.shape[0], x.shape[2])):
+                and ops.narrow_backward_supported(x.shape[1], w2.shape[0], x.shape[2], (dz, y, x))):
             red = FUSED_NARROW_RED and xcoef is not None and xcoef.shape[0] >= 4   # input = lazy activation of a train-mode BN layer
             res = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
                                           dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
             dx, dw = res[0], res[1]
             if red:
-                PRE_BN_SUMS[dx.data_ptr()] = (tuple(dx.shape), [res[2]])
+                _register_pre_bn_sums(dx, [res[2]])
             db = torch.zeros_like(gamma) if (ctx.needs_input_grad[3] and not sink) else None
             if sink:
                 dw = db = dgamma = dbeta = None
@@ -495,8 +576,7 @@ class _SharedMLPLayerMax(torch.autograd.Function):
         y, stats = ops.mlp_gemm(_kmajor(w2), x3, bias, want_stats=True,
                                 pro=0 if xcoef is None else 1, coef=xcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum, running_mean, running_var)
-        if PIN_RELU_FIX is not None:
-            y = _align_relu_decisions(y, coef)
+        y = _relu_hook(y, coef)
         pooled, arg, yarg = _pooled_act(y.view(B, Cout, M, K), coef, True, want_yarg=True)
         ctx.save_for_backward(x3, xcoef, w2, y, coef, mean, invstd, gamma, arg, yarg)
         ctx.dims, ctx.sink, ctx.x_shape = (B, Cin, Cout, M, K), sink, tuple(x.shape)
@@ -582,8 +662,8 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
                                 pro=0 if hcoef is None else 1, coef=hcoef)
         mean, invstd, coef = ops.bn_finalize(stats, B * M * K, gamma, beta, eps, momentum,
                                              running_mean, running_var)
-        if PIN_RELU_FIX is not None and relu:
-            y = _align_relu_decisions(y, coef)
+        if relu:
+            y = _relu_hook(y, coef)
         ctx.save_for_backward(h3, hcoef, pooled, w2, y, coef, mean, invstd, gamma)
         ctx.dims = (B, Ch, Cp, Cout, M, K, poff, hoff)
         ctx.h_shape = tuple(h.shape)
@@ -610,13 +690,13 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         if ctx.needs_input_grad[3]:
             dpooled = ops.mlp_gemm(w2c, sdy, tag="dgrad_pooled", M=Cp, a_offset=poff)[0]
         fused = (FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[4] and ctx.relu
-                 and ops.narrow_backward_supported(Ch, Cout, M * K))
+                 and ops.narrow_backward_supported(Ch, Cout, M * K, (dz, y, h3)))
         if fused:                                           # data and weight gradient of the feature half in one pass
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
             red = FUSED_NARROW_RED and hcoef is not None and hcoef.shape[0] >= 4
             res = ops.mlp_narrow_backward(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch, want_red=red)
             if red:
-                PRE_BN_SUMS[res[0].data_ptr()] = (tuple(res[0].shape), [res[2]])
+                _register_pre_bn_sums(res[0], [res[2]])
             dh = res[0].view(ctx.h_shape)
             ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
         if ctx.needs_input_grad[0] and not fused:
@@ -749,18 +829,19 @@ class _GroupMaxActFork(torch.autograd.Function):
             return dy, None, None
         if dy is None:
             return ops.group_max_backward(dpooled.contiguous(), arg, ctx.K), None, None
-        pre = PRE_BN_SUMS.pop(dy.data_ptr(), None)            # sums the producer of dy took for the dense part
+        B, C, M, K = y4.shape
+        pre = _take_pre_bn_sums(dy, (B, C, M * K))            # sums the producer of dy took for the dense part
         # Inside the training step (GRAD_SINK: no hooks, no retained graph, one consumer) dy is the data gradient the
         # consuming layer just produced for this node alone, so it is updated in place; anywhere else autograd may
         # share that buffer (retain_grad, hooks, a second consumer), so the sum goes into a private copy
         dy = dy.contiguous() if GRAD_SINK else dy.clone(memory_format=torch.contiguous_format)
         dpooled = dpooled.contiguous()
         out = ops.group_max_backward_add_(dy, dpooled, arg)
-        if pre is not None and coef.shape[0] >= 4 and pre[0][0] == y4.shape[0] and pre[0][1] == y4.shape[1]:
+        if pre is not None and coef.shape[0] >= 4 and GRAD_SINK:
             # the sums are linear in the gradient: add those of the sparse pooling part (B*C*M elements)
             sparse = ops.bn_pool_backward_partials(dpooled, arg, y4, coef, coef[2], coef[3], ctx.relu, yarg=yarg)
-            B, C, M, K = y4.shape
-            PRE_BN_SUMS[out.data_ptr()] = ((B, C, M * K), pre[1] + [sparse])
+            out3 = out.view(B, C, M * K)
+            PRE_BN_SUMS[out3.data_ptr()] = ((B, C, M * K), pre[1] + [sparse], out3._version)
         return out, None, None
 
 

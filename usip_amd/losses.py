@@ -64,8 +64,9 @@ class DescPairScanLoss(nn.Module):
         self.opt = opt
 
     def forward(self, anc_descriptors, pos_descriptors, neg_descriptors, anc_sigmas):
-        d_pos, _ = Fh.nearest_distance_i32(anc_descriptors, pos_descriptors)
-        d_neg, _ = Fh.nearest_distance_i32(anc_descriptors, neg_descriptors)
+        d_pos, j_pos = Fh.nearest_distance_i32(anc_descriptors, pos_descriptors)
+        d_neg, j_neg = Fh.nearest_distance_i32(anc_descriptors, neg_descriptors)
+        self.last_indices = (j_pos, j_neg)                              # int32 (torch.min gives int64)
         before_clamp = d_pos - d_neg + self.opt.triple_loss_gamma
         active_percentage = torch.mean((before_clamp > 0).float(), dim=1)
         w = torch.clamp(self.opt.sigma_max - anc_sigmas, min=0)

@@ -1,7 +1,7 @@
-"""The two detectors of the path, with the reference's class names, constructor, forward
-signature and state_dict keys (models/networks.py:20-162 RPN_Detector, :611-738
-RPN_Detector_Ball), written on the fused HIP operators: no B x N x M temporaries, no dense
-one-hot masks, distances in the kernels.
+"""The detectors of the path, with the reference's class names, constructor, forward
+signature and state_dict keys (models/networks.py:20-162 RPN_Detector, :165-307 RPN_DetectorLite,
+:482-608 RPN_Detector_KNN, :611-738 RPN_Detector_Ball), written on the fused HIP operators: no
+B x N x M temporaries, no dense one-hot masks, distances in the kernels.
 
 forward(x Bx3xN, sn BxCsxN, node Bx3xM, is_train=False, epoch=None)
     -> (nodes Bx3xM, keypoints Bx3xM, sigmas BxM, None)
@@ -23,9 +23,11 @@ def _bn_kw(opt):
 class _DetectorTail(nn.Module):
     """knnlayer_1 + mlp1..3 + softplus, shared by every detector (networks.py:41-72, :135-154)."""
 
+    C2_WIDTH = 512
+
     def _build_tail(self, opt):
         assert opt.node_knn_k_1 >= 2
-        self.C2 = 512
+        self.C2 = self.C2_WIDTH
         self.knnlayer_1 = GeneralKNNFusionModule(3 + self.C1, (self.C2 // 2, self.C2 // 2, self.C2 // 2),
                                                  (self.C2, self.C2), activation=opt.activation,
                                                  normalization=opt.normalization, **_bn_kw(opt))
@@ -52,12 +54,14 @@ class RPN_Detector(_DetectorTail):
     """SOM variant: nearest-node assignment -> PointNet -> index_max -> PointNet -> index_max
     -> node KNN fusion -> head (models/networks.py:20-162)."""
 
+    C1_WIDTH = 128
+
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
         if opt.k != 1:
-            raise NotImplementedError("usip_amd: RPN_Detector is implemented for opt.k == 1")
-        self.C1 = 128
+            raise NotImplementedError("usip_amd: %s is implemented for opt.k == 1" % type(self).__name__)
+        self.C1 = self.C1_WIDTH
         h = self.C1 // 2
         self.first_pointnet = PointNet(3 + opt.surface_normal_len, [h, h, h], activation=opt.activation,
                                        normalization=opt.normalization, **_bn_kw(opt))
@@ -99,6 +103,14 @@ class RPN_Detector(_DetectorTail):
         return cluster_mean, keypoints, sigmas, None
 
 
+class RPN_DetectorLite(RPN_Detector):
+    """RPN_Detector at half the widths (C1 = 64, C2 = 256; models/networks.py:165-307) -- what every indoor
+    train_detector.py of the reference builds (match3d, scenenn: models/keypoint_detector.py:18-19).  Same call
+    sequence, same state_dict keys; the kernels pick their own tile shapes for the narrower layers."""
+    C1_WIDTH = 64
+    C2_WIDTH = 256
+
+
 class RPN_Detector_Ball(_DetectorTail):
     """Ball-query variant (radius 2, 64 samples, both hard-coded in the reference:
     models/networks.py:691-692): ball grouping -> grouped shared MLP -> max -> concat -> MLP ->
@@ -120,12 +132,16 @@ class RPN_Detector_Ball(_DetectorTail):
         self.ball_radius = 2
         self.ball_k = 64
 
+    def _neighbourhoods(self, node, x):
+        """-> (int32 [B,M,K] point indices of every node's neighbourhood, name of the index tensor)."""
+        return ops.ball_query_coords(node, x, self.ball_radius, self.ball_k), "ball_idx"   # :694-698 fused
+
     def forward(self, x, sn, node, is_train=False, epoch=None):
-        Fh.require_device(x, "RPN_Detector_Ball")
+        Fh.require_device(x, type(self).__name__)
         x = x.contiguous()
         node = node.contiguous()
         x_aug = torch.cat((x, sn), dim=1)
-        ball_idx32 = ops.ball_query_coords(node, x, self.ball_radius, self.ball_k)        # :694-698 fused
+        ball_idx32, idx_name = self._neighbourhoods(node, x)
         g = ops.group_gather(x_aug, ball_idx32, sub=node)                 # gather + decenter :699-703
         # activations stay lazy between the layers: BN+ReLU is applied by the consumer's prologue
         h = self.conv3(self.conv2(self.conv1(g, defer=True), defer=True), defer=True)   # no epoch: networks.py:705
@@ -140,8 +156,19 @@ class RPN_Detector_Ball(_DetectorTail):
             second_max = Fh.group_max(self.conv5(h, defer=True))
         ball_idx = ball_idx32.long()
         keypoints, sigmas = self._tail(node, second_max, epoch)
-        self.last_indices = dict(ball_idx=ball_idx, knn_I=self.knnlayer_1.last_knn_I)
+        self.last_indices = {idx_name: ball_idx, "knn_I": self.knnlayer_1.last_knn_I}
         return node, keypoints, sigmas, None
+
+
+class RPN_Detector_KNN(RPN_Detector_Ball):
+    """RPN_Detector_Ball with the ball query replaced by the k = 64 nearest points of every node
+    (models/networks.py:482-608; k hard-coded at :574, torch.topk(sorted=False) at :581).  Same layers, same
+    state_dict keys.  topk(sorted=False) leaves the order of the k picks unspecified and nothing downstream
+    depends on it (max over the neighbours, BatchNorm sums), so the neighbourhoods come out nearest first, ties
+    towards the lower index -- `last_indices["nn_idx"]`."""
+
+    def _neighbourhoods(self, node, x):
+        return ops.knn_points(node, x, self.ball_k), "nn_idx"                              # :576-581 fused
 
 
 class DescriptorLiteOld(nn.Module):
@@ -221,8 +248,11 @@ class DetectorOptions:
             setattr(self, k, v)
 
 
+DETECTORS = {"som": RPN_Detector, "ball": RPN_Detector_Ball, "lite": RPN_DetectorLite, "knn": RPN_Detector_KNN}
+
+
 def build_detector(model: str, opt) -> nn.Module:
-    return {"som": RPN_Detector, "ball": RPN_Detector_Ball}[model](opt)
+    return DETECTORS[model](opt)
 
 
 def detector_param_shapes(model: str, surface_normal_len: int):

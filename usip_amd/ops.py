@@ -659,8 +659,19 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     return dW
 
 
-def narrow_backward_supported(Cin: int, Cout: int, P: int) -> bool:
-    return _matmul_mode != "bf16" and bool(_lib.lib().usip_mlp_narrow_backward_supported(int(Cin), int(Cout), int(P)))
+def narrow_backward_supported(Cin: int, Cout: int, P: int, tensors=()) -> bool:
+    """True when usip_mlp_narrow_backward_f32 takes this layer.  `tensors`: the (dZ, Y, X) the call would pass --
+    the kernel needs them 16-byte aligned (an offset view handed over by autograd is not) and addresses elements
+    with 32-bit offsets; anything else goes through the generic data- and weight-gradient kernels instead of
+    raising in the middle of a backward."""
+    if _matmul_mode == "bf16" or not _lib.lib().usip_mlp_narrow_backward_supported(int(Cin), int(Cout), int(P)):
+        return False
+    for t in tensors:
+        if t is None:
+            continue
+        if t.data_ptr() % 16 != 0 or t.numel() >= 2 ** 32 or not t.is_contiguous():
+            return False
+    return True
 
 
 def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64, want_red: bool = False):
@@ -853,6 +864,20 @@ def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
     with torch.cuda.device(query.device), prof.kernel("knn", 4.0 * B * (3 * (M + N) + M * K), 8.0 * B * M * N):
         _lib.check(_lib.lib().usip_knn_f32(_ptr(query), _ptr(database), _ptr(out), B, M, N, int(K), _stream(query)),
                    "usip_knn_f32")
+    return out
+
+
+def knn_points(node: torch.Tensor, x: torch.Tensor, K: int) -> torch.Tensor:
+    """RPN_Detector_KNN's neighbourhoods (models/networks.py:576-581): i32 [B,M,K], the K cloud points nearest to every
+    node, nearest first, ties towards the lower index.  node [B,3,M], x [B,3,N], N <= 16384, K <= min(N, 256)."""
+    _need_pts(node, "node")
+    _need_pts(x, "x")
+    B, _, M = node.shape
+    N = x.shape[2]
+    out = torch.empty((B, M, K), dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device), prof.kernel("knn_points", 4.0 * B * (3 * N + 3 * M + M * K)):
+        _lib.check(_lib.lib().usip_knn_points_f32(_ptr(node), _ptr(x), _ptr(out), B, M, N, int(K), _stream(x)),
+                   "usip_knn_points_f32")
     return out
 
 

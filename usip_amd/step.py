@@ -113,6 +113,9 @@ class _GraphedStep:
         # training run with epoch-decayed BatchNorm momentum or varying cloud sizes evicts instead of growing.
         self._graphs: "OrderedDict" = OrderedDict()
         self.max_graphs = 3
+        # bench.py: set to a list to have every gradient all-reduce bracketed by two HIP events on the launch stream
+        # (the collective itself runs on RCCL's stream; the launch stream waits for it, so the pair spans it)
+        self.allreduce_events = None
         self._eager_calls = 0
         self._bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
         self._bn_counters = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
@@ -137,6 +140,12 @@ class _GraphedStep:
     def _forward_backward(self, batch, epoch):
         from . import functional as Fh
         from . import ops
+        if Fh.pins_active() and not getattr(self, "allow_pinned_decisions", False):
+            # the decision-pinning hooks are test instruments (tests/test_modules_gpu.py): a training step never runs
+            # with them unless the step object was built for such a test, and never inside a captured graph
+            raise RuntimeError("usip_amd: functional.pinned_decisions is active during a training step")
+        if Fh.pins_active() and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("usip_amd: pinned decisions cannot be captured into a HIP graph")
         self.bucket.zero()                                    # zero_grad()
         Fh.GRAD_SINK = True       # every parameter is used once per step and the bucket was just zeroed:
         Fh.DEFER_BN_COUNTERS = True   # the backward kernels write dW/dgamma/dbeta straight into the bucket
@@ -160,6 +169,7 @@ class _GraphedStep:
             Fh.DEFER_BN_COUNTERS = False
             Fh.WT_CACHE = None
             ops.PLANES_CACHE = None
+            Fh.PRE_BN_SUMS.clear()
         if self._bn_counters:
             torch._foreach_add_(self._bn_counters, 1)         # every BatchNorm ran exactly once
         return loss
@@ -173,9 +183,19 @@ class _GraphedStep:
             return self._step_graph(batch, epoch, group)
         return self._step_eager(batch, epoch, group)
 
+    def _all_reduce(self, group):
+        if self.allreduce_events is not None and self.device.type == "cuda":
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.bucket.all_reduce_mean(group)
+            e.record()
+            self.allreduce_events.append((s, e))
+        else:
+            self.bucket.all_reduce_mean(group)
+
     def _step_eager(self, batch, epoch, group):
         loss = self._forward_backward(batch, epoch)
-        self.bucket.all_reduce_mean(group)
+        self._all_reduce(group)
         if self.optimizer is not None:
             self.optimizer.step()
         return loss
@@ -239,7 +259,7 @@ class _GraphedStep:
             for bn, m in zip(self._bns, key[1]):
                 bn.momentum = m
         ga.replay()
-        self.bucket.all_reduce_mean(group)
+        self._all_reduce(group)
         if gb is not None:
             gb.replay()
         self.last = last
