@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--n", "--points", dest="n", type=int, default=16384)
     ap.add_argument("--m", "--nodes", dest="m", type=int, default=512)
     ap.add_argument("--cloud", default="slab")
-    ap.add_argument("--precision", default="f32x3", choices=["f32", "f32x3", "bf16"],
+    ap.add_argument("--precision", default="f32x3", choices=["f32", "f32x3", "f32x2", "bf16"],
                     help="f32x3 (default) = fp32-ACCURATE products on the bf16 matrix cores for the "
                          "matrix-bound layers (three bf16 planes per operand, six plane products, fp32 accumulation; "
                          "error at the fp32 kernels' level, every parity test passes in this mode: "
@@ -375,7 +375,12 @@ def main():
                     pci_bus_id=int(getattr(props, "pci_bus_id", -1)), step_ms_wall=elapsed / args.steps * 1e3,
                     allreduce_us_p50=ar[len(ar) // 2] if ar else None,
                     allreduce_us_p90=ar[min(len(ar) - 1, int(0.9 * len(ar)))] if ar else None,
-                    allreduce_calls=len(ar), loss=loss_val)
+                    allreduce_calls=len(ar), loss=loss_val,
+                    # replicas start identical and receive identical reduced gradients: the parameters must agree bit
+                    # for bit on every rank after the run (fp64 sum of the flat parameter buffer, and its first words)
+                    param_checksum=[float(st.bucket.flat_param.detach().double().sum().item()),
+                                    float(st.bucket.flat_param.detach()[:8].double().abs().sum().item())]
+                    if st.bucket.flat_param is not None else None)
         census = [None] * world
         dist.all_gather_object(census, mine)
     summ = None
@@ -409,6 +414,9 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f32x3": "f32 (matrix-bound products as six bf16-plane MFMAs of an exact three-way "
                                              "split, fp32 accumulate: fp32-accurate)",
+                      "f32x2": "f32 (matrix-bound products as three fp16-plane MFMAs of a two-way split with exact "
+                               "power-of-two operand scaling, fp32 accumulate: fp32-accurate; launches without an operand "
+                               "bound as six bf16-plane MFMAs)",
                       "bf16": "bf16 multiply, f32 accumulate and storage (perf mode)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("KITTI descriptor head N=%d, 256 keypoints, K=64, batch=%d pairs/GPU (BASELINE "
@@ -446,6 +454,8 @@ def main():
                                         "step of the timed region, max over ranks of each rank's percentile"},
                 "step_ms_per_rank": [round(c["step_ms_wall"], 4) for c in census],
                 "loss_per_rank": [c["loss"] for c in census],
+                "param_checksum_per_rank": [c["param_checksum"] for c in census],
+                "replicas_identical": len({str(c["param_checksum"]) for c in census}) == 1,
                 "launcher": "self-spawned torch.distributed.run" if os.environ.get("USIP_BENCH_SPAWNED") else
                             "external launcher"}
         raw_steps = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -456,16 +466,25 @@ def main():
                                     "max": round(per_step[-1], 4), "first": round(raw_steps[0], 4)}
         if not args.no_kernel_timing:
             traffic_db, traffic_src = load_traffic_db(args.precision)
-            def is_x3(r):
+            def products(r):
+                """Matrix products per fp32 product of a split-product launch: 6 (three bf16 planes), 3 (two fp16
+                planes, template argument NPL = 2 / kernel name x2h), 0 for every other kernel."""
                 key = (r.get("rocprof_key") or "").split(" |wg=")[0]
-                return "x3" in key or ("bf16_kernel" in key and key.rstrip(">").endswith(", 3"))
+                if "x2h" in key or (("x3p_kernel" in key or "wgrad_x3_kernel" in key) and key.rstrip(">").endswith(", 2")):
+                    return 3
+                if "x3" in key or ("bf16_kernel" in key and key.rstrip(">").endswith(", 3")):
+                    return 6
+                return 0
+
+            def is_x3(r):
+                return products(r) > 0
 
             kernels = []
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
                 mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
                 # a split-product launch does six bf16 matrix products per fp32 product: its ceiling in fp32-equivalent
                 # flops is the dense bf16 peak / 6
-                mm_peak = PEAK_BF16_TFLOPS / 6.0 if is_x3(r) else mfma_peak
+                mm_peak = PEAK_BF16_TFLOPS / products(r) if is_x3(r) else mfma_peak
                 # the roofline that binds a shared-MLP launch is the one whose floor is higher: the narrow layers
                 # (64 inputs, 16 flop/B) are HBM-bound, the wide ones matrix-bound
                 if mfma and r["bytes_per_call"] / (PEAK_HBM_GBPS * 1e9) > r["flops_per_call"] / (mm_peak * 1e12):
@@ -503,7 +522,8 @@ def main():
                 top_name, top = max(fam.items(), key=lambda kv: kv[1]["ms"])
                 avg_s = top["ms"] * 1e-3 / top["calls"]
                 if top["mfma"]:
-                    top_peak = PEAK_BF16_TFLOPS / 6.0 if is_x3({"rocprof_key": top_name}) else mfma_peak
+                    top_peak = (PEAK_BF16_TFLOPS / products({"rocprof_key": top_name})
+                                if is_x3({"rocprof_key": top_name}) else mfma_peak)
                     ach, peak, unit, bound = top["flops"] / top["calls"] / avg_s / 1e12, top_peak, "TFLOP/s", "mfma"
                 else:
                     ach, peak, unit, bound = top["nbytes"] / top["calls"] / avg_s / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
@@ -520,9 +540,11 @@ def main():
                                "(%d steps)" % (sample_every, timed_steps_sampled)),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
                     "traffic_source": traffic_src,
-                    "peak_note": ("fp32-equivalent: a split-product launch issues six bf16 matrix products per fp32 "
-                                  "product, so its ceiling is the dense bf16 peak (2500 TFLOP/s) / 6; the same launch "
-                                  "priced in bf16 flops actually issued: %.0f of 2500 TFLOP/s" % (6.0 * ach))
+                    "peak_note": ("fp32-equivalent: a split-product launch issues %d 16-bit matrix products per fp32 "
+                                  "product, so its ceiling is the dense bf16/fp16 peak (2500 TFLOP/s) / %d; the same "
+                                  "launch priced in 16-bit flops actually issued: %.0f of 2500 TFLOP/s"
+                                  % (products({"rocprof_key": top_name}), products({"rocprof_key": top_name}),
+                                     products({"rocprof_key": top_name}) * ach))
                     if (top["mfma"] and peak != mfma_peak) else None,
                     "attainable_peak_note": "a pure fp32-MFMA loop (tools/mfma_peak.hip) sustains 121-141 TFLOP/s with "
                                             "random operands on this chip (clock 1.85-2.15 GHz under load), see "

@@ -255,7 +255,7 @@ int usip_mlp_x3p_tile_rows(int M);                 /* rows per tile (128 or 256)
  * usip_mlp_split3_f32) with first_block = running sum of usip_mlp_split3_blocks(M, K) over the entries before. */
 typedef struct usip_split3_desc {
     const float* At; void* planes; int32_t lda, M, K, first_block;
-    int32_t tile_rows, reserved;                      /* usip_mlp_x3p_tile_rows(M) */
+    int32_t tile_rows, reserved;                      /* usip_mlp_x3p_tile_rows(M); reserved: 2 = two fp16 planes (below) */
 } usip_split3_desc;
 int usip_mlp_split3_blocks(int M, int K);
 int usip_mlp_split3_multi_f32(const usip_split3_desc* descs_device, int n, int total_blocks, void* stream);
@@ -264,6 +264,22 @@ int usip_mlp_x3p_tile_cols(int M, int P, int nb, int pro, int with_stats);
 long long usip_mlp_split3_bytes(int M, int K);
 int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream);
 int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                          const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
+                          const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
+                          int M, int K, int P, int nb, void* stream);
+/* "f32x2": the same fp32-accurate product from TWO fp16 planes per operand (11 + 11 significant bits) and THREE plane
+ * products -- half the matrix work of f32x3 at the same error level.  fp16 has 5 exponent bits, so both operands are
+ * multiplied by powers of two (exact): the weights by 2^e with max|A| 2^e in [2^13, 2^14) (usip_mlp_split2h_f32 stores
+ * 2^e behind the image; buffer size usip_mlp_split3_bytes), the streamed operand by 2^e derived in the kernel from a
+ * RIGOROUS upper bound of what its prologue can produce:
+ *   pro 1: coef = [4][K] (scale, shift, mean, invstd) of a training-mode BatchNorm over exactly the nb * P samples of
+ *          this launch: |relu(bn(y))| <= |gamma| sqrt(n) + |beta|;
+ *   pro 2 / 3: coef = the [5][K] array usip_bn_backward_reduce_f32 / usip_bn_pool_backward_reduce_f32 write with
+ *          want_bound (row 4: bounds of |dY| per 64 channels).
+ * pro 0 (no bound available) is not offered: callers use usip_mlp_gemm_x3p_f32.  Otherwise the contract of
+ * usip_mlp_gemm_x3p_f32. */
+int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, void* planes, void* stream);
+int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
                           const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
                           const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
                           int M, int K, int P, int nb, void* stream);
@@ -299,7 +315,11 @@ int usip_bn_apply_f32(const float* Y, const float* coef, float* Z, int relu,
 int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* coef_fwd,
                                 const float* mean, const float* invstd, const float* gamma, int relu,
                                 float* partial, float* dgamma, float* dbeta, float* coef4,
-                                float* gsum, int group, int nb, int C, int P, void* stream);
+                                float* gsum, int group, int nb, int C, int P, int want_bound, void* stream);
+/* want_bound != 0: `partial` holds [3][nb*C] floats (third plane: max |dYhat| per row) and coef4 is [5][C]: entry i of
+ * row 4 (i < ceil(C/64)) is an upper bound of |dY| over channels [64 i, 64 i + 64) -- |a1| (max|dYhat| + |mean dYhat| +
+ * |mean dYhat yhat| sqrt(n)), rigorous for batch statistics -- which the split-fp16 kernels (usip_mlp_gemm_x2h_f32,
+ * usip_mlp_wgrad_x2h_f32) use to scale the operand into the fp16 range.  want_bound == 0: [2][nb*C] and [4][C]. */
 
 
 /* usip_bn_backward_reduce_f32 for a layer whose output fed ONLY a max over K neighbours: the incoming
@@ -310,7 +330,7 @@ int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, const float* co
 int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int32_t* arg, const float* Y, const float* yarg,
                                      const float* coef_fwd, const float* mean, const float* invstd,
                                      const float* gamma, int relu, float* partial, float* dgamma, float* dbeta,
-                                     float* coef4, int nb, int C, int M, int K, void* stream);
+                                     float* coef4, int nb, int C, int M, int K, int want_bound, void* stream);
 
 /* dW[m][n] = sum_{b,p} pro(G)[b][m][p] * X[b][n][p]   (pro 0: G = dY given; pro 2: G = dZ, G2 = Y,
  * coef = coef4 as above; pro 3: dZ synthesised from pool_dp / pool_arg as in usip_mlp_gemm_f32).  workspace: usip_mlp_wgrad_workspace(M, N, P, nb) floats of partial tiles,
@@ -355,6 +375,14 @@ int usip_mlp_wgrad_bf16(const float* G, const float* G2, const float* coef, int 
                         int M, int N, int P, int nb, void* stream);
 /* f32x3 variant (see usip_mlp_gemm_f32x3); same workspace, same deterministic fp32 reduction. */
 int usip_mlp_wgrad_f32x3(const float* G, const float* G2, const float* coef, int pro, const float* X,
+                        const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                        float* workspace, float* dW, int ldw, int coloff,
+                        int M, int N, int P, int nb, void* stream);
+/* f32x2 form of the weight gradient: as usip_mlp_wgrad_f32x3, and launches with pro 2 / 3, M, N > 128, coef = the [5][M]
+ * array usip_bn_backward_reduce_f32 writes with want_bound and xcoef = the [4][N] (scale, shift, mean, invstd) of a
+ * training-mode BatchNorm over exactly the nb * P samples of this launch run on two fp16 planes per operand and three
+ * plane products (see usip_mlp_gemm_x2h_f32); every other launch exactly as usip_mlp_wgrad_f32x3. */
+int usip_mlp_wgrad_x2h_f32(const float* G, const float* G2, const float* coef, int pro, const float* X,
                         const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                         float* workspace, float* dW, int ldw, int coloff,
                         int M, int N, int P, int nb, void* stream);

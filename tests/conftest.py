@@ -51,7 +51,7 @@ def assert_close(actual, expected, rel=1e-5, name=""):
     return err
 
 
-@pytest.fixture(params=["f32", "f32x3"])
+@pytest.fixture(params=["f32", "f32x3", "f32x2"])
 def matmul_mode(request):
     """The two fp32-accurate arithmetic modes of the shared-MLP kernels: "f32" = fp32 MFMA everywhere, "f32x3" = the
     mode bench.py times by default (six bf16-plane products per fp32 product).  The fixtures are small, and at small
@@ -60,14 +60,14 @@ def matmul_mode(request):
     the arithmetic the full-size step runs, not a mode switch that changes nothing."""
     from usip_amd import _lib, ops
     prev = ops.set_matmul_mode(request.param)
-    if request.param == "f32x3":
+    if request.param in ("f32x3", "f32x2"):
         _lib.lib().usip_set_tuning(b"gemm_split3", 2)
     yield request.param
     _lib.lib().usip_set_tuning(b"gemm_split3", 0)
     ops.set_matmul_mode(prev)
 
 
-@pytest.fixture(params=["f32", "f32x3"])
+@pytest.fixture(params=["f32", "f32x3", "f32x2"])
 def matmul_mode_natural(request):
     """The same two modes with the dispatcher's own choice of kernel per launch: for tests at bench.py's full size."""
     from usip_amd import ops

@@ -18,6 +18,8 @@ for STEP in "$@"; do
     bench)     timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ;;
     benchq)    timeout 900 python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err ;;
     bench_x3)  timeout 900 python bench.py --precision f32x3 --no-cpu-baseline > gpurun_out/${TAG}_bench_x3.json 2> gpurun_out/${TAG}_bench_x3.err ;;
+    bench_x2)  timeout 900 python bench.py --precision f32x2 --no-cpu-baseline > gpurun_out/${TAG}_bench_x2.json 2> gpurun_out/${TAG}_bench_x2.err ;;
+    modes)     timeout 1200 python -m pytest tests/test_modules_gpu.py -m gpu -q -k "pinned or full_size or graph_replay_equals or reproducible or descriptor_step" > gpurun_out/${TAG}_modes.log 2>&1; echo "rc=$?" >> gpurun_out/${TAG}_modes.log ;;
     bench_f32) timeout 900 python bench.py --precision f32 --no-cpu-baseline > gpurun_out/${TAG}_bench_f32.json 2> gpurun_out/${TAG}_bench_f32.err ;;
     profile_f32) timeout 1200 bash tools/profile_roofline.sh ${TAG}_f32 --precision f32 > gpurun_out/${TAG}_profile_f32.log 2>&1 ;;
     bench_som) timeout 900 python bench.py --model som --no-cpu-baseline > gpurun_out/${TAG}_bench_som.json 2> gpurun_out/${TAG}_bench_som.err ;;
@@ -32,7 +34,7 @@ for STEP in "$@"; do
   esac
   echo "== $STEP done ($(date +%T))"
 done
-for f in gpurun_out/${TAG}_pytest.log gpurun_out/${TAG}_pytest_x3.log gpurun_out/${TAG}_pinned.log gpurun_out/${TAG}_x3test.log; do [ -f $f ] && { echo "--- $f"; tail -n 15 $f; }; done
+for f in gpurun_out/${TAG}_pytest.log gpurun_out/${TAG}_pytest_x3.log gpurun_out/${TAG}_pinned.log gpurun_out/${TAG}_x3test.log gpurun_out/${TAG}_modes.log; do [ -f $f ] && { echo "--- $f"; tail -n 15 $f; }; done
 for f in gpurun_out/${TAG}_x3bench.txt gpurun_out/${TAG}_index_max_sweep.txt gpurun_out/${TAG}_host_overhead.txt; do [ -f $f ] && { echo "--- $f"; cat $f; }; done
 for f in gpurun_out/${TAG}_bench*.json; do [ -f $f ] && { echo "--- $f"; head -c 700 $f; echo; }; done
 exit 0

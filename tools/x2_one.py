@@ -1,0 +1,23 @@
+"""A few launches of the f32x2 forward GEMM (512 x 512, BN+ReLU prologue, statistics) for counter passes."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from usip_amd import _lib, ops  # noqa: E402
+
+dev = "cuda:0"
+mode = sys.argv[1] if len(sys.argv) > 1 else "f32x2"
+ops.set_matmul_mode(mode)
+M, K, P, nb = 512, 512, 8192, 16
+At = (torch.randn(K, M, device=dev) * (2.0 / K) ** 0.5)
+X = torch.randn(nb, K, P, device=dev)
+b = torch.randn(M, device=dev)
+mu, var = X.mean(dim=(0, 2)), X.var(dim=(0, 2), unbiased=False)
+istd = torch.rsqrt(var + 1e-5)
+coef = torch.stack([istd, -mu * istd, mu, istd]).contiguous()
+ops.PLANES_CACHE = {}
+for _ in range(6):
+    ops.mlp_gemm(At, X, b, want_stats=True, pro=1, coef=coef)
+torch.cuda.synchronize()

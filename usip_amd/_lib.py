@@ -68,15 +68,18 @@ SIGNATURES = {
     "usip_mlp_split3_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
     "usip_mlp_gemm_x3p_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_split2h_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
+    "usip_mlp_gemm_x2h_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
+                               _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3_used": ([_int, _int, _int, _int], _int),
     "usip_mlp_wgrad_f32x3_blocks": ([_int, _int, _int, _int], _int),
     "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p,
-                                          _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
+                                          _f32p, _f32p, _int, _int, _int, _int, _int, _stream], _int),
     "usip_bn_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _flt, _flt, _f32p, _f32p, _f32p,
                               _f32p, _f32p, _stream], _int),
     "usip_bn_apply_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_backward_reduce_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _f32p,
-                                     _f32p, _int, _int, _int, _int, _stream], _int),
+                                     _f32p, _int, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_workspace": ([_int, _int, _int, _int], ctypes.c_longlong),
     "usip_mlp_wgrad_blocks": ([_int, _int, _int, _int], _int),
     "usip_mlp_wgrad_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int,
@@ -85,6 +88,8 @@ SIGNATURES = {
                              _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int,
                               _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_wgrad_x2h_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _f32p, _int, _int,
+                                _int, _int, _int, _int, _stream], _int),
     "usip_mlp_narrow_backward_supported": ([_int, _int, _int], _int),
     "usip_mlp_narrow_backward_workspace": ([_int, _int, _int], ctypes.c_longlong),
     "usip_mlp_narrow_backward_blocks": ([_int, _int, _int], _int),

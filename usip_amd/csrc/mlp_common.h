@@ -224,5 +224,7 @@ int launch_wgrad_x3(const WgradArgs& a, int pro, bool xpro, bool vec, unsigned b
 // 256 x 256 tiles, own slicing (shared_mlp_x3.hip); needs the vector path (P % 4 == 0, 16-B aligned operands)
 void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* tiles);
 int launch_wgrad_x3_256(const WgradArgs& a, int pro, bool xpro, unsigned blocks, hipStream_t st);
+// the same from two fp16 planes per operand (pro 2 / 3 with the [5][M] coef4, xcoef = [4][N] batch statistics)
+int launch_wgrad_x2h_256(const WgradArgs& a, int pro, unsigned blocks, hipStream_t st);
 
 }  // namespace usip_mlp

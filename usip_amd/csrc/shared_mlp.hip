@@ -558,13 +558,13 @@ template <bool GROUP>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dZ, const float* __restrict__ Y, const float* __restrict__ coef,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
-    float* __restrict__ gsum, int relu, int plain, int C, int P, int nrows, int K)
+    float* __restrict__ gsum, int relu, int plain, int C, int P, int nrows, int K, int want_max)
 {
-    __shared__ float red[2][4];
+    __shared__ float red[3][4];
     const long long rowid = blockIdx.x;
     const int ch = (int)(rowid % C);
     const float* dz = dZ + rowid * P;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;                      // mx: max |dYhat| of the row (want_max: partial[2][row])
     if (plain) {
         for (int p = threadIdx.x; p < P; p += 256) s1 += dz[p];
     } else if (GROUP) {
@@ -585,6 +585,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
                 gd = (d0 + d1) + (d2 + d3);
                 gy = (yv.x + yv.y) + (yv.z + yv.w);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
                 s1 += gd;
                 s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
                 s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 const float d1 = (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
                 const float d2 = (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f;
                 const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
                 s1 += (d0 + d1) + (d2 + d3);
                 s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
                 s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
@@ -619,18 +621,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             for (int p = threadIdx.x; p < P; p += 256) {
                 const float yv = y[p];
                 const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dz[p] : 0.f;
+                mx = fmaxf(mx, fabsf(d));
                 s1 += d;
                 s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
             }
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); mx = fmaxf(mx, __shfl_down(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         partial[rowid] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         partial[nrows + rowid] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        if (want_max) partial[2LL * nrows + rowid] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
     }
 }
 
@@ -639,28 +645,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(
     const float* __restrict__ dpooled, const int* __restrict__ arg, const float* __restrict__ Y,
     const float* __restrict__ coef, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ partial, int relu, int C, int M, int K, int nrows, const float* __restrict__ yarg)
+    float* __restrict__ partial, int relu, int C, int M, int K, int nrows, const float* __restrict__ yarg, int want_max)
 {
-    __shared__ float red[2][4];
+    __shared__ float red[3][4];
     const long long rowid = blockIdx.x;
     const int ch = (int)(rowid % C);
     const float sc = coef[ch], sh = coef[C + ch], mu = mean[ch], is = invstd[ch];
     const float* y = Y + rowid * M * K;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;
     for (int m = threadIdx.x; m < M; m += 256) {
         // yarg: y at the arg-max, kept by the forward pooling pass (otherwise one 128-B line fetched per 4-B value)
         const float yv = yarg ? yarg[rowid * M + m] : y[(long long)m * K + arg[rowid * M + m]];
         const float d = (!relu || __builtin_fmaf(yv, sc, sh) > 0.f) ? dpooled[rowid * M + m] : 0.f;
+        mx = fmaxf(mx, fabsf(d));
         s1 += d;
         s2 = __builtin_fmaf(d, (yv - mu) * is, s2);
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    for (int off = 32; off > 0; off >>= 1) {
+        s1 += __shfl_down(s1, off); s2 += __shfl_down(s2, off); mx = fmaxf(mx, __shfl_down(mx, off));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; red[2][threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         partial[rowid] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         partial[nrows + rowid] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        if (want_max) partial[2LL * nrows + rowid] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
     }
 }
 
@@ -669,26 +679,40 @@ __global__ __launch_bounds__(256) void bn_bwd_pool_reduce_kernel(
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, int nb, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ coef_fwd, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef4)
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef4, int want_bound)
 {
     const int ch = blockIdx.x * 64 + threadIdx.x;
-    if (ch >= C) return;
     const long long nrows = (long long)nb * C;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nb; ++b) {
-        s1 += (double)partial[(long long)b * C + ch];
-        s2 += (double)partial[nrows + (long long)b * C + ch];
+    float bound = 0.f;
+    if (ch < C) {
+        double s1 = 0.0, s2 = 0.0;
+        float mx = 0.f;
+        for (int b = 0; b < nb; ++b) {
+            s1 += (double)partial[(long long)b * C + ch];
+            s2 += (double)partial[nrows + (long long)b * C + ch];
+            if (want_bound) mx = fmaxf(mx, partial[2 * nrows + (long long)b * C + ch]);
+        }
+        if (dbeta) dbeta[ch] = (float)s1;
+        if (dgamma) dgamma[ch] = (float)s2;
+        if (coef4) {
+            const float a1 = coef_fwd[ch], a0 = coef_fwd[C + ch];
+            const float is = invstd[ch], mu = mean[ch];
+            const float c1m = (float)(s1 / count), c2m = (float)(s2 / count);
+            coef4[ch] = a1;
+            coef4[C + ch] = a0;
+            coef4[2 * C + ch] = -a1 * c2m * is;
+            coef4[3 * C + ch] = a1 * (c2m * is * mu - c1m);
+            // |dY| = |a1| |dYhat - c1m - yhat c2m| <= |a1| (max|dYhat| + |c1m| + |c2m| sqrt(n)):  |yhat| <= sqrt(n) for
+            // batch statistics over n samples (n (y - mean)^2 <= n sum (y - mean)^2 = n^2 var)
+            bound = fabsf(a1) * (mx + fabsf(c1m) + fabsf(c2m) * (float)sqrt(count));
+        }
     }
-    if (dbeta) dbeta[ch] = (float)s1;
-    if (dgamma) dgamma[ch] = (float)s2;
-    if (coef4) {
-        const float a1 = coef_fwd[ch], a0 = coef_fwd[C + ch];
-        const float is = invstd[ch], mu = mean[ch];
-        const float c1m = (float)(s1 / count), c2m = (float)(s2 / count);
-        coef4[ch] = a1;
-        coef4[C + ch] = a0;
-        coef4[2 * C + ch] = -a1 * c2m * is;
-        coef4[3 * C + ch] = a1 * (c2m * is * mu - c1m);
+    if (want_bound && coef4) {
+        // row 4 of coef4 ([5][C]): entry i = bound of |dY| over the channels [64 i, 64 i + 64) -- what the split-fp16
+        // kernels scale their streamed operand by (they take the max over the ceil(C/64) entries)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bound = fmaxf(bound, __shfl_down(bound, off));
+        if (threadIdx.x == 0) coef4[4 * C + blockIdx.x] = bound;
     }
     (void)gamma;
 }
@@ -768,6 +792,7 @@ static bool x3_gemm_pays(int M, int K, int P, int nb)
     const int t = usip_tuning_value(USIP_TUNE_GEMM_SPLIT3);          // 1: never, 2: whenever the shape allows
     if (t == 1) return false;
     const long long tiles = (long long)nb * ((P + 127) / 128) * ((M + 127) / 128);
+    if ((long long)K * P >= (1LL << 30)) return false;        // the split kernels address a cloud with 32-bit byte offsets
     if (t == 2) return M > 64 && K >= 16;
     return M >= 128 && K >= 128 && tiles >= 512;
 }
@@ -903,12 +928,14 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
         return USIP_EINVAL;
     int seglen, segs, small, tiles;
     wgrad_plan(M, N, P, nb, &seglen, &segs, &small, &tiles);
-    const bool bf16 = (mode == 1), x3 = (mode == 2) && !small && x3_wgrad_pays(M, N, P, nb);
+    const bool bf16 = (mode == 1), x3 = (mode == 2 || mode == 3) && !small && x3_wgrad_pays(M, N, P, nb);
     // 256 x 256 tiles for the wide layers (every streamed element is prepared for twice as many partners)
     const bool vec0 = (P % 4 == 0) && (pro == PRO_BN_BWD_POOL || (reinterpret_cast<uintptr_t>(G) & 15u) == 0) &&
                       ((reinterpret_cast<uintptr_t>(X) & 15u) == 0) &&
                       (pro == PRO_NONE || (reinterpret_cast<uintptr_t>(G2) & 15u) == 0);
     const bool x3big = x3 && vec0 && M > 128 && N > 128 && usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 1;
+    // mode 3: two fp16 planes per operand where both operands have a bound (see usip_mlp_wgrad_x2h_f32); f32x3 otherwise
+    const bool x2h = (mode == 3) && x3big && (pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && xcoef != nullptr;
     if (x3big) wgrad_x3_plan(M, N, P, nb, &seglen, &segs, &tiles);
     WgradArgs a{G, G2, coef, X, xcoef, pool_dp, pool_arg, pool_group, workspace, M, N, P, nb, seglen, segs};
     const bool xpro = xcoef != nullptr;
@@ -924,7 +951,8 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
         if (rc != USIP_OK) return rc;
     }
     if (x3) {
-        const int rc = x3big ? launch_wgrad_x3_256(a, pro, xpro, (unsigned)blocks, st)
+        const int rc = x2h ? launch_wgrad_x2h_256(a, pro, (unsigned)blocks, st)
+                     : x3big ? launch_wgrad_x3_256(a, pro, xpro, (unsigned)blocks, st)
                              : launch_wgrad_x3(a, pro, xpro, vec, (unsigned)blocks, st);
         if (rc != USIP_OK) return rc;
     }
@@ -957,6 +985,10 @@ static int mlp_wgrad_impl(int mode, const float* G, const float* G2, const float
 extern "C" int usip_mlp_wgrad_f32(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(0, USIP_WGRAD_ARGS); }
 extern "C" int usip_mlp_wgrad_bf16(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(1, USIP_WGRAD_ARGS); }
 extern "C" int usip_mlp_wgrad_f32x3(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(2, USIP_WGRAD_ARGS); }
+// f32x2: as usip_mlp_wgrad_f32x3, and launches with pro 2 / 3, M, N > 128, coef = the [5][M] array of
+// usip_bn_backward_reduce_f32(want_bound) and xcoef = the [4][N] (scale, shift, mean, invstd) of a training-mode BatchNorm
+// over the nb * P samples of this launch use two fp16 planes and three plane products (usip_mlp_gemm_x2h_f32's scheme).
+extern "C" int usip_mlp_wgrad_x2h_f32(USIP_WGRAD_PARAMS) { return mlp_wgrad_impl(3, USIP_WGRAD_ARGS); }
 #undef USIP_WGRAD_PARAMS
 #undef USIP_WGRAD_ARGS
 
@@ -1010,7 +1042,7 @@ extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, cons
                                            const float* mean, const float* invstd, const float* gamma,
                                            int relu, float* partial, float* dgamma, float* dbeta,
                                            float* coef4, float* gsum, int group,
-                                           int nb, int C, int P, void* stream)
+                                           int nb, int C, int P, int want_bound, void* stream)
 {
     if (nb < 1 || C < 1 || P < 1 || !dZ || !partial) return USIP_EINVAL;
     const int plain = (Y == nullptr);
@@ -1027,13 +1059,14 @@ extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, cons
     if (rows > 0x7fffffffLL) return USIP_EINVAL;
     if (gsum)
         USIP_LAUNCH((bn_bwd_reduce_kernel<true>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean,
-                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group);
+                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group, want_bound);
     else
         USIP_LAUNCH((bn_bwd_reduce_kernel<false>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean,
-                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group);
+                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group, want_bound);
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
-                (double)nb * (double)P, gamma, coef_fwd, mean, invstd, dgamma, dbeta, plain ? nullptr : coef4);
+                (double)nb * (double)P, gamma, coef_fwd, mean, invstd, dgamma, dbeta, plain ? nullptr : coef4,
+                want_bound);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
@@ -1042,7 +1075,7 @@ extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int3
                                                 const float* yarg, const float* coef_fwd, const float* mean,
                                                 const float* invstd, const float* gamma, int relu, float* partial,
                                                 float* dgamma, float* dbeta, float* coef4, int nb, int C, int M,
-                                                int K, void* stream)
+                                                int K, int want_bound, void* stream)
 {
     if (nb < 1 || C < 1 || M < 1 || K < 1 || !dpooled || !arg || !Y || !coef_fwd || !mean || !invstd || !partial)
         return USIP_EINVAL;
@@ -1050,11 +1083,11 @@ extern "C" int usip_bn_pool_backward_reduce_f32(const float* dpooled, const int3
     const long long rows = (long long)nb * C;
     if (rows > 0x7fffffffLL) return USIP_EINVAL;
     USIP_LAUNCH(bn_bwd_pool_reduce_kernel, dim3((unsigned)rows), dim3(256), 0, st, dpooled, arg, Y, coef_fwd, mean,
-                invstd, partial, relu, C, M, K, (int)rows, yarg);
+                invstd, partial, relu, C, M, K, (int)rows, yarg, want_bound);
     USIP_LAUNCH_CHECK();
     if (!dgamma && !dbeta && !coef4) return USIP_OK;          // partial sums only (combined by usip_bn_backward_finalize_f32)
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
-                (double)nb * (double)M * (double)K, gamma, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
+                (double)nb * (double)M * (double)K, gamma, coef_fwd, mean, invstd, dgamma, dbeta, coef4, want_bound);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -23,11 +23,27 @@ using namespace usip_mlp;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 constexpr int XBK = 16;                                        // k per stage: one MFMA step
+
+// 2^e with bound * 2^e in [2^(top-1), 2^top) for a positive normal bound; e clamped to [-60, 60] (an all-zero operand
+// gets 2^60, which still maps it to zero); inf / NaN bounds leave the operand unscaled (the result is inf / NaN then,
+// as it is in fp32).
+__device__ __forceinline__ float pow2_scale(float bound, int top)
+{
+    const int eb = (int)((__float_as_uint(bound) >> 23) & 0xffu);          // bound = m 2^(eb - 127), m in [1, 2)
+    int e = top - (eb - 126);
+    e = e < -60 ? -60 : (e > 60 ? 60 : e);
+    if (eb == 255) e = 0;
+    return __uint_as_float((unsigned)(127 + e) << 23);
+}
+constexpr int X2H_TOP = 15;
+                                    // scaled operands stay below 2^15 (fp16 max: 65504)
 
 // Two fp32 -> three packed bf16 pairs (low half = first element), x = h + m + l exactly up to 2^-26 |x|.
 __device__ __forceinline__ void split_pair(float x, float y, unsigned& p0, unsigned& p1, unsigned& p2)
@@ -45,8 +61,72 @@ __device__ __forceinline__ void split_pair(float x, float y, unsigned& p0, unsig
     p2 = __builtin_bit_cast(unsigned, l);
 }
 
+// "f32x2h": the same idea with TWO fp16 planes (11 + 11 significant bits) and the THREE plane pairs of weight >= 2^-11:
+// half the matrix products of f32x3.  fp16 has 5 exponent bits, so the caller scales both operands by powers of two
+// (exact) such that the largest element sits near the top of the fp16 range; the low plane of an element x is then a
+// normal fp16 number unless |x| < 2^-3 in scaled units, where what is lost is below 2^-26 of the operand's scale.
+// Two fp32 -> two packed fp16 pairs, x = h + l up to 2^-22 |x|.
+__device__ __forceinline__ void split_pair_h(float x, float y, unsigned& p0, unsigned& p1)
+{
+    f32x2 v = {x, y};
+    f16x2 h = __builtin_convertvector(v, f16x2);               // RNE
+    p0 = __builtin_bit_cast(unsigned, h);
+    f32x2 hf = __builtin_convertvector(h, f32x2);
+    v = v - hf;                                                // exact
+    f16x2 l = __builtin_convertvector(v, f16x2);
+    p1 = __builtin_bit_cast(unsigned, l);
+}
+
 // byte offset of (row, 16-B half) inside a [rows][16 bf16] plane: halves swapped in every other block of 8 rows
 __device__ __forceinline__ int lds_off(int row, int half) { return row * 32 + ((half ^ (row >> 3)) & 1) * 16; }
+
+// Scale of a weight operand for the two-plane fp16 image: 2^e with max|A| 2^e in [2^13, 2^14).  Two levels without
+// atomics: X2H_PARTS workgroups per operand each leave the maximum of their share behind the image (floats
+// [4, 4 + X2H_PARTS) of the trailer); the split kernel combines them (every workgroup the same way) and the operand's
+// first workgroup writes the scale into trailer float 0 for the GEMM.
+constexpr int X2H_PARTS = 32;
+
+__device__ __forceinline__ float* x2h_trailer(const usip_split3_desc& d)
+{
+    const int bm = d.tile_rows, ksteps = (d.K + XBK - 1) / XBK;
+    return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d.planes) +
+                                    (long long)((d.M + bm - 1) / bm) * ksteps * 2 * bm * 32);
+}
+
+__device__ __forceinline__ void absmax_part(const usip_split3_desc& d, int part)
+{
+    __shared__ float red[4];
+    const long long total = (long long)d.M * d.K, per = (total + X2H_PARTS - 1) / X2H_PARTS;
+    const long long i0 = part * per, i1 = i0 + per < total ? i0 + per : total;
+    float mx = 0.f;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int k = (int)(i / d.M), m = (int)(i % d.M);
+        mx = fmaxf(mx, fabsf(d.At[(long long)k * d.lda + m]));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) x2h_trailer(d)[4 + part] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__device__ __forceinline__ float x2h_weight_scale(const usip_split3_desc& d)
+{
+    const float* t = x2h_trailer(d);
+    float mx = 0.f;
+    for (int i = 0; i < X2H_PARTS; ++i) mx = fmaxf(mx, t[4 + i]);
+    return pow2_scale(mx, X2H_TOP - 1);
+}
+
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const usip_split3_desc* __restrict__ descs, int n)
+{
+    const usip_split3_desc d = descs[blockIdx.x / X2H_PARTS];
+    if (d.reserved != 2) return;
+    absmax_part(d, blockIdx.x % X2H_PARTS);
+    (void)n;
+}
+
+__global__ __launch_bounds__(256) void absmax_one_kernel(usip_split3_desc d) { absmax_part(d, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // Weight operand -> per-stage LDS images.  At is the K-major operand of usip_mlp_gemm_f32 (A[m][k] = At[k*lda + m]);
@@ -54,8 +134,14 @@ __device__ __forceinline__ int lds_off(int row, int half) { return row * 32 + ((
 // k = ks*16 + half*8 .. +7 of row mt*bm + row, zero outside M x K.  bm (128 or 256) = rows of the GEMM's tile.
 // One workgroup of 2*bm threads per (mt, ks) stage.
 __global__ __launch_bounds__(512) void split3_tiles_kernel(const float* __restrict__ At, int lda, int M, int K,
-                                                           uint4* __restrict__ out, int ksteps, int bm)
+                                                           uint4* __restrict__ out, int ksteps, int bm, int npl)
 {
+    float wscale = 1.0f;
+    if (npl == 2) {
+        const usip_split3_desc d{At, out, lda, M, K, 0, bm, 2};
+        wscale = x2h_weight_scale(d);
+        if (blockIdx.x == 0 && threadIdx.x == 0) x2h_trailer(d)[0] = wscale;
+    }
     const int ks = blockIdx.x % ksteps, mt = blockIdx.x / ksteps;
     const int row = threadIdx.x % bm, half = threadIdx.x / bm;
     const int m = mt * bm + row;
@@ -66,11 +152,15 @@ __global__ __launch_bounds__(512) void split3_tiles_kernel(const float* __restri
         v[i] = (m < M && k < K) ? At[(long long)k * lda + m] : 0.0f;
     }
     unsigned p[3][4];
+    if (npl == 2) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
-    uint4* stage = out + (long long)blockIdx.x * (3 * bm * 2);
+        for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j] * wscale, v[2 * j + 1] * wscale, p[0][j], p[1][j]);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 3; ++s)          // chunk position = its LDS position (lds_off / 16): the GEMM copies linearly
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    }
+    uint4* stage = out + (long long)blockIdx.x * (npl * bm * 2);
+    for (int s = 0; s < npl; ++s)        // chunk position = its LDS position (lds_off / 16): the GEMM copies linearly
         stage[s * (bm * 2) + row * 2 + ((half ^ (row >> 3)) & 1)] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
 }
 
@@ -94,11 +184,19 @@ __global__ __launch_bounds__(512) void split3_multi_kernel(const usip_split3_des
         v[j] = (m < d.M && k < d.K) ? d.At[(long long)k * d.lda + m] : 0.0f;
     }
     unsigned p[3][4];
+    const int npl = d.reserved == 2 ? 2 : 3;
+    if (npl == 2) {
+        // the operand's scale, from the partial maxima absmax_multi_kernel left behind the two-plane image
+        const float ws = x2h_weight_scale(d);
+        if (blk == 0 && threadIdx.x == 0) x2h_trailer(d)[0] = ws;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
-    uint4* stage = reinterpret_cast<uint4*>(d.planes) + (long long)blk * (3 * bm * 2);
+        for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j] * ws, v[2 * j + 1] * ws, p[0][j], p[1][j]);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+    }
+    uint4* stage = reinterpret_cast<uint4*>(d.planes) + (long long)blk * (npl * bm * 2);
+    for (int s = 0; s < npl; ++s)
         stage[s * (bm * 2) + row * 2 + ((half ^ (row >> 3)) & 1)] = make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
 }
 
@@ -110,12 +208,12 @@ __global__ __launch_bounds__(512) void split3_multi_kernel(const usip_split3_des
 //              (4, 2): 256 x 128, 256 threads, two workgroups per CU   (the wide layers: every streamed element is
 //                      prepared for 256 channels instead of 128 -- half the preparation per MFMA, half the L2 reads)
 //              (4, 4): 256 x 256, 512 threads, one workgroup per CU
-template <int PRO, int EPI, int TM, int WN>
+template <int PRO, int EPI, int TM, int WN, int NPL = 3>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x3p_kernel(const GemmArgs a, const uint4* __restrict__ planes)
 {
     constexpr int XBM = 64 * TM, XBN = 64 * WN, NT = 128 * WN;
     constexpr int APL = XBM * 32, BPL = XBN * 32;              // bytes of one plane of one stage
-    constexpr int ASTAGE = 3 * APL, BSTAGE = 3 * BPL;
+    constexpr int ASTAGE = NPL * APL, BSTAGE = NPL * BPL;
     constexpr int NA = XBM * 2 / NT;                           // 16-B chunks of an A plane per thread: 1 or 2
     constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
     constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
@@ -143,8 +241,37 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int m0 = mt * XBM, p0 = pt * XBN;
     const int nk = (a.K + XBK - 1) / XBK;
 
+    // Two fp16 planes: both operands are scaled by powers of two (exact) so that neither leaves the fp16 range.  The
+    // weights carry their scale behind their image (absmax_multi_kernel); the streamed operand's comes from a rigorous
+    // bound of what the prologue can produce -- forward: |gamma| sqrt(n) + |beta| for a BatchNorm output over the n
+    // samples of THIS launch; backward: the bound usip_bn_backward_reduce_f32 left in row 4 of coef4 -- and is folded
+    // into the prologue coefficients (relu(fma(x, s c0, s c1)) = s relu(fma(x, c0, c1)) exactly for s = 2^e > 0).
+    float xs = 1.0f, out_scale = 1.0f;
+    if (NPL == 2) {
+        float* redm = reinterpret_cast<float*>(Bs);            // free until the first stage is written (a barrier later)
+        float bnd = 0.f;
+        if (PRO == PRO_AFFINE_RELU) {
+            const float rn = sqrtf((float)a.nb * (float)a.P);
+            for (int k = tid; k < a.K; k += NT) {
+                const float c0 = a.coef[k], c1 = a.coef[a.K + k], mu = a.coef[2 * a.K + k], is = a.coef[3 * a.K + k];
+                bnd = fmaxf(bnd, fabsf(c0) / is * rn + fabsf(__builtin_fmaf(mu, c0, c1)));
+            }
+        } else {
+            for (int i = tid; i < (a.K + 63) / 64; i += NT) bnd = fmaxf(bnd, a.coef[4 * a.K + i]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, off));
+        if (lane == 0) redm[wave] = bnd;
+        __syncthreads();
+        bnd = redm[0];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) bnd = fmaxf(bnd, redm[w]);
+        xs = pow2_scale(bnd, X2H_TOP);
+        const float ws = __uint_as_float(planes[(long long)nmt * nk * (ASTAGE / 16)].x);
+        out_scale = 1.0f / (xs * ws);
+    }
     if (NCOEF) {
-        for (int i = tid; i < NCOEF * a.K; i += NT) cf[(i / a.K) * KMAX + i % a.K] = a.coef[i];
+        for (int i = tid; i < NCOEF * a.K; i += NT) cf[(i / a.K) * KMAX + i % a.K] = a.coef[i] * xs;
     }
 
     // A: the global image IS the LDS image, so a stage of A is copied by LDS-DMA (global_load_lds_dwordx4: every lane
@@ -154,14 +281,25 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     // X: thread -> position p = tid % XBN, k-group = tid / XBN (wave-uniform): 8 consecutive k of one position
     const int xp = tid & (XBN - 1);
     const int xkg = __builtin_amdgcn_readfirstlane(tid / XBN);
-    const int xpc = min(p0 + xp, a.P - 1);
+    const unsigned xpc = (unsigned)min(p0 + xp, a.P - 1);
     const int x_lds = lds_off(xp, xkg);
-    const float* Xp = (POOL ? a.X2 : a.X) + (long long)b * a.K * a.P + xpc;       // + k * P
-    const float* X2p = TWO ? a.X2 + (long long)b * a.K * a.P + xpc : nullptr;
+    // The streamed operand is read through buffer descriptors built from wave-uniform values (the cloud's base, its
+    // size): a load is `buffer_load_dword v, v_off, s[rsrc], s_row offen` -- one constant VGPR offset per lane, the row
+    // as a scalar byte offset -- instead of a 64-bit vector add per load (12-20 v_lshl_add_u64 per stage in the r02
+    // loop, which after halving the matrix work was a third of the loop's vector instructions).
     const int pgrp = POOL ? a.P / a.pool_group : 0;
-    const float* pdp = POOL ? a.pool_dp + (long long)b * a.K * pgrp + xpc / a.pool_group : nullptr;
-    const int* parg = POOL ? a.pool_arg + (long long)b * a.K * pgrp + xpc / a.pool_group : nullptr;
-    const int xkin = POOL ? xpc % a.pool_group : 0;
+    const unsigned cloud_bytes = (unsigned)a.K * (unsigned)a.P * 4u, pool_bytes = (unsigned)a.K * (unsigned)pgrp * 4u;
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((POOL ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((TWO ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? a.pool_dp + (long long)b * a.K * pgrp : a.X), 0, POOL ? pool_bytes : 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPa = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? (const float*)(a.pool_arg + (long long)b * a.K * pgrp) : a.X), 0, POOL ? pool_bytes : 4u, 0x00020000);
+    const int xoff = (int)(xpc * 4u);
+    const int goff = POOL ? (int)((xpc / (unsigned)a.pool_group) * 4u) : 0;
+    const int xkin = POOL ? (int)(xpc % (unsigned)a.pool_group) : 0;
 
     f32x16 acc[TM][2];
 #pragma unroll
@@ -176,7 +314,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     auto dma_stage = [&](int buf, int kt) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < NPL; ++s)
 #pragma unroll
             for (int j = 0; j < NA; ++j)
                 __builtin_amdgcn_global_load_lds(
@@ -189,12 +327,12 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int i = 0; i < 8; ++i) {
             const int kc = min(kb + i, a.K - 1);               // scalar: the k-group is wave-uniform
             if (POOL) {
-                rx[i] = pdp[(long long)kc * pgrp];
-                rarg[i] = parg[(long long)kc * pgrp];
+                rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, goff, kc * pgrp * 4, 0));
+                rarg[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, goff, kc * pgrp * 4, 0);
             } else {
-                rx[i] = Xp[(long long)kc * a.P];
+                rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, kc * a.P * 4, 0));
             }
-            if (TWO) ry[i] = X2p[(long long)kc * a.P];
+            if (TWO) ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX2, xoff, kc * a.P * 4, 0));
         }
     };
     auto store_stage = [&](int buf, int kt) {
@@ -218,10 +356,15 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
         // zero padding of the weight planes, so no masking is needed (a branch here would also split the loop body
         // and with it the MFMA / preparation interleave)
         unsigned p[3][4];
+        if (NPL == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+            for (int j = 0; j < 4; ++j) split_pair_h(v[2 * j], v[2 * j + 1], p[0][j], p[1][j]);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+            for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+        }
+#pragma unroll
+        for (int s = 0; s < NPL; ++s)
             *reinterpret_cast<uint4*>(Bs + buf * BSTAGE + s * BPL + x_lds) =
                 make_uint4(p[s][0], p[s][1], p[s][2], p[s][3]);
     };
@@ -252,24 +395,42 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     // the six plane pairs, smallest terms first; operands swapped: D'[position][channel], see gemm_epilogue
 #define USIP_X3_PRODUCT(PA_, PB_)                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_][0], fa[PA_][i], acc[i][0], 0, 0, 0);        \
-            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_][1], fa[PA_][i], acc[i][1], 0, 0, 0);        \
+            if constexpr (NPL == 2) {                                                                              \
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[PB_][0]), __builtin_bit_cast(f16x8, fa[PA_][i]), acc[i][0], 0, 0, 0); \
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fb[PB_][1]), __builtin_bit_cast(f16x8, fa[PA_][i]), acc[i][1], 0, 0, 0); \
+            } else {                                                                                               \
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_][0], fa[PA_][i], acc[i][0], 0, 0, 0);    \
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB_][1], fa[PA_][i], acc[i][1], 0, 0, 0);    \
+            }                                                                                                      \
         }
 #define USIP_X3_READ_FRAGS()                                                                                       \
-        bf16x8 fa[3][TM], fb[3][2];                                                                                \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                            \
+        bf16x8 fa[NPL][TM], fb[NPL][2];                                                                            \
+        _Pragma("unroll") for (int s = 0; s < NPL; ++s) {                                                          \
             _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
                 fa[s][t] = *reinterpret_cast<const bf16x8*>(As + cur * ASTAGE + s * APL + fa_off[t]);              \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
                 fb[s][t] = *reinterpret_cast<const bf16x8*>(Bs + cur * BSTAGE + s * BPL + fb_off[t]);              \
         }
+#define USIP_X3_FIRST_HALF()                                                                                       \
+        if constexpr (NPL == 2) { USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) }                                    \
+        else { USIP_X3_PRODUCT(2, 0) USIP_X3_PRODUCT(0, 2) USIP_X3_PRODUCT(1, 1) }
+#define USIP_X3_SECOND_HALF()                                                                                      \
+        if constexpr (NPL == 2) { USIP_X3_PRODUCT(0, 0) }                                                          \
+        else { USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) USIP_X3_PRODUCT(0, 0) }
     for (int kt = 0; kt + 1 < nk; ++kt) {
         dma_stage(cur ^ 1, kt + 1);                            // A of stage kt+1: memory -> LDS (the other buffer is free)
+        // no memory instruction may cross: the counted wait below relies on "DMA first, then the NXL register loads"
+        // (ALU, MFMA and LDS instructions may still be scheduled across).  Measured and not kept (r03, f32x2 512 x 512
+        // forward, same box): the DMA issued after store_stage, so that hipcc's vmcnt(0) at the first use of the
+        // register loads does not also wait for it (284 vs 258 us: the compiler sinks it to the end of the stage);
+        // three scheduling regions pinned with sched_barrier(0), 16 + 8 or 8 + 16 MFMAs around the memory
+        // instructions (265 / 263 vs 254 us).
+        __builtin_amdgcn_sched_barrier(0x38F);
         USIP_X3_READ_FRAGS()
-        USIP_X3_PRODUCT(2, 0) USIP_X3_PRODUCT(0, 2) USIP_X3_PRODUCT(1, 1)
+        USIP_X3_FIRST_HALF()
         store_stage(cur ^ 1, kt + 1);                          // X of stage kt+1: registers -> LDS
         load_stage(min(kt + 2, nk - 1));                       // X of stage kt+2: memory -> registers (last: a harmless repeat)
-        USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) USIP_X3_PRODUCT(0, 0)
+        USIP_X3_SECOND_HALF()
         // The DMA (issued before the register loads of stage kt+2, loads retire in order) must have landed and this
         // wave's LDS writes must be done before anyone reads the other buffer; the register loads stay in flight
         // across the barrier -- __syncthreads() would drain them (it waits vmcnt(0) while an LDS-DMA is pending).
@@ -279,12 +440,22 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     {
         USIP_X3_READ_FRAGS()
-        USIP_X3_PRODUCT(2, 0) USIP_X3_PRODUCT(0, 2) USIP_X3_PRODUCT(1, 1)
-        USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) USIP_X3_PRODUCT(0, 0)
+        USIP_X3_FIRST_HALF()
+        USIP_X3_SECOND_HALF()
         __syncthreads();
     }
 #undef USIP_X3_PRODUCT
 #undef USIP_X3_READ_FRAGS
+#undef USIP_X3_FIRST_HALF
+#undef USIP_X3_SECOND_HALF
+    if (NPL == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= out_scale;
+    }
     gemm_epilogue<2, WN, EPI, TM>(a, acc, reinterpret_cast<float*>(smem), OPER_BYTES / 4, b, m0, p0, tn, tpc);
 }
 
@@ -295,11 +466,11 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
 // instead of 128 -- 16 elements per thread per 48 MFMAs (the 128 x 128 kernel: 16 per 24).  Same two-stage
 // software pipeline as the GEMM; positions are the contraction index, 16 per stage, contiguous in memory, so a
 // thread's float4 becomes 8 B of its LDS row directly.
-template <int PRO, bool XPRO>
+template <int PRO, bool XPRO, int NPL = 3>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_x3_kernel(const WgradArgs a)
 {
     constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256, NT = 512;
-    constexpr int PL = BM * 32, STAGE = 3 * PL;                // bytes: one plane, one operand stage (BM == BN)
+    constexpr int PL = BM * 32, STAGE = NPL * PL;              // bytes: one plane, one operand stage (BM == BN)
     constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
     constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * STAGE];       // [stage][G | X][plane][row][16 p]
@@ -342,16 +513,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         pdp[i] = POOL ? a.pool_dp + ((long long)b * a.M + grow[i]) * pgrp : nullptr;
         pap[i] = POOL ? a.pool_arg + ((long long)b * a.M + grow[i]) * pgrp : nullptr;
     }
+    // Two fp16 planes (NPL == 2, see gemm_x3p_kernel): G is scaled by 2^e from the bound in row 4 of coef4, X by 2^e
+    // from |gamma| sqrt(n) + |beta| of its BatchNorm (xcoef = [4][N] batch statistics over the nb * P samples); both
+    // folded into the per-row prologue coefficients, the partial tile is multiplied by 2^-(e_g + e_x) on the way out.
+    float gscale = 1.0f, xscale = 1.0f;
+    if (NPL == 2) {
+        float* redm = reinterpret_cast<float*>(smem);          // free until the first stage is written (barrier below)
+        float gb = 0.f, xb = 0.f;
+        for (int i = tid; i < (a.M + 63) / 64; i += NT) gb = fmaxf(gb, a.coef[4 * a.M + i]);
+        const float rn = sqrtf((float)a.nb * (float)a.P);
+        for (int k = tid; k < a.N; k += NT) {
+            const float c0 = a.xcoef[k], c1 = a.xcoef[a.N + k], mu = a.xcoef[2 * a.N + k], is = a.xcoef[3 * a.N + k];
+            xb = fmaxf(xb, fabsf(c0) / is * rn + fabsf(__builtin_fmaf(mu, c0, c1)));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { gb = fmaxf(gb, __shfl_xor(gb, off)); xb = fmaxf(xb, __shfl_xor(xb, off)); }
+        if (lane == 0) { redm[wave] = gb; redm[8 + wave] = xb; }
+        __syncthreads();
+        gb = redm[0]; xb = redm[8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { gb = fmaxf(gb, redm[w]); xb = fmaxf(xb, redm[8 + w]); }
+        gscale = pow2_scale(gb, X2H_TOP);
+        xscale = pow2_scale(xb, X2H_TOP);
+        __syncthreads();                                       // everyone has read redm before the stages overwrite it
+    }
     float gc[TWO ? 2 : 1][4], xc[XPRO ? 2 : 1][2];
     if (TWO) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gc[i][j] = a.coef[j * a.M + grow[i]];
+            for (int j = 0; j < 4; ++j) gc[i][j] = a.coef[j * a.M + grow[i]] * gscale;
     }
     if (XPRO) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { xc[i][0] = a.xcoef[xrow[i]]; xc[i][1] = a.xcoef[a.N + xrow[i]]; }
+        for (int i = 0; i < 2; ++i) { xc[i][0] = a.xcoef[xrow[i]] * xscale; xc[i][1] = a.xcoef[a.N + xrow[i]] * xscale; }
     }
 
     f32x16 acc[TM][TN];
@@ -399,22 +594,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // load returned there meets a zero
             if (!(gok[i] && pok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
             unsigned p0[2], p1[2], p2[2];
-            split_pair(v.x, v.y, p0[0], p1[0], p2[0]);
-            split_pair(v.z, v.w, p0[1], p1[1], p2[1]);
+            if (NPL == 2) {
+                split_pair_h(v.x, v.y, p0[0], p1[0]);
+                split_pair_h(v.z, v.w, p0[1], p1[1]);
+            } else {
+                split_pair(v.x, v.y, p0[0], p1[0], p2[0]);
+                split_pair(v.z, v.w, p0[1], p1[1], p2[1]);
+            }
             *reinterpret_cast<uint2*>(Gs + buf * STAGE + 0 * PL + lds[i]) = make_uint2(p0[0], p0[1]);
             *reinterpret_cast<uint2*>(Gs + buf * STAGE + 1 * PL + lds[i]) = make_uint2(p1[0], p1[1]);
-            *reinterpret_cast<uint2*>(Gs + buf * STAGE + 2 * PL + lds[i]) = make_uint2(p2[0], p2[1]);
+            if (NPL == 3) *reinterpret_cast<uint2*>(Gs + buf * STAGE + 2 * PL + lds[i]) = make_uint2(p2[0], p2[1]);
             float4 x = rx[i];
             if (XPRO) {
                 const float s0 = xc[XPRO ? i : 0][0], s1 = xc[XPRO ? i : 0][1];
                 x.x = fmaxf(__builtin_fmaf(x.x, s0, s1), 0.f); x.y = fmaxf(__builtin_fmaf(x.y, s0, s1), 0.f);
                 x.z = fmaxf(__builtin_fmaf(x.z, s0, s1), 0.f); x.w = fmaxf(__builtin_fmaf(x.w, s0, s1), 0.f);
             }
-            split_pair(x.x, x.y, p0[0], p1[0], p2[0]);
-            split_pair(x.z, x.w, p0[1], p1[1], p2[1]);
+            if (NPL == 2) {
+                split_pair_h(x.x, x.y, p0[0], p1[0]);
+                split_pair_h(x.z, x.w, p0[1], p1[1]);
+            } else {
+                split_pair(x.x, x.y, p0[0], p1[0], p2[0]);
+                split_pair(x.z, x.w, p0[1], p1[1], p2[1]);
+            }
             *reinterpret_cast<uint2*>(Xs + buf * STAGE + 0 * PL + lds[i]) = make_uint2(p0[0], p0[1]);
             *reinterpret_cast<uint2*>(Xs + buf * STAGE + 1 * PL + lds[i]) = make_uint2(p1[0], p1[1]);
-            *reinterpret_cast<uint2*>(Xs + buf * STAGE + 2 * PL + lds[i]) = make_uint2(p2[0], p2[1]);
+            if (NPL == 3) *reinterpret_cast<uint2*>(Xs + buf * STAGE + 2 * PL + lds[i]) = make_uint2(p2[0], p2[1]);
         }
     };
 
@@ -426,11 +631,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int t = 0; t < TN; ++t) fb_off[t] = lds_off((wn * TN + t) * 32 + c, kh);
 #define USIP_X3W_PRODUCT(PA_, PB_)                                                                                 \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA_][i], fb[PB_][j], acc[i][j], 0, 0, 0);
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                       \
+                if constexpr (NPL == 2)                                                                            \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[PA_][i]), __builtin_bit_cast(f16x8, fb[PB_][j]), acc[i][j], 0, 0, 0); \
+                else                                                                                               \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA_][i], fb[PB_][j], acc[i][j], 0, 0, 0); \
+            }
+#define USIP_X3W_FIRST_HALF()                                                                                      \
+        if constexpr (NPL == 2) { USIP_X3W_PRODUCT(1, 0) USIP_X3W_PRODUCT(0, 1) }                                  \
+        else { USIP_X3W_PRODUCT(2, 0) USIP_X3W_PRODUCT(0, 2) USIP_X3W_PRODUCT(1, 1) }
+#define USIP_X3W_SECOND_HALF()                                                                                     \
+        if constexpr (NPL == 2) { USIP_X3W_PRODUCT(0, 0) }                                                         \
+        else { USIP_X3W_PRODUCT(1, 0) USIP_X3W_PRODUCT(0, 1) USIP_X3W_PRODUCT(0, 0) }
 #define USIP_X3W_READ_FRAGS()                                                                                      \
-        bf16x8 fa[3][TM], fb[3][TN];                                                                               \
-        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                            \
+        bf16x8 fa[NPL][TM], fb[NPL][TN];                                                                           \
+        _Pragma("unroll") for (int s = 0; s < NPL; ++s) {                                                          \
             _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
                 fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + cur * STAGE + s * PL + fa_off[t]);                \
             _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                         \
@@ -444,19 +659,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();
         for (int st = 0; st + 1 < nst; ++st) {
             USIP_X3W_READ_FRAGS()
-            USIP_X3W_PRODUCT(2, 0) USIP_X3W_PRODUCT(0, 2) USIP_X3W_PRODUCT(1, 1)
+            USIP_X3W_FIRST_HALF()
             store_stage(cur ^ 1, st + 1);                      // stage st+1: registers -> LDS
             load_stage(min(st + 2, nst - 1));                  // stage st+2: memory -> registers
-            USIP_X3W_PRODUCT(1, 0) USIP_X3W_PRODUCT(0, 1) USIP_X3W_PRODUCT(0, 0)
+            USIP_X3W_SECOND_HALF()
             __syncthreads();
             cur ^= 1;
         }
         USIP_X3W_READ_FRAGS()
-        USIP_X3W_PRODUCT(2, 0) USIP_X3W_PRODUCT(0, 2) USIP_X3W_PRODUCT(1, 1)
-        USIP_X3W_PRODUCT(1, 0) USIP_X3W_PRODUCT(0, 1) USIP_X3W_PRODUCT(0, 0)
+        USIP_X3W_FIRST_HALF()
+        USIP_X3W_SECOND_HALF()
     }
 #undef USIP_X3W_PRODUCT
 #undef USIP_X3W_READ_FRAGS
+#undef USIP_X3W_FIRST_HALF
+#undef USIP_X3W_SECOND_HALF
+    if (NPL == 2) {
+        const float out_scale = 1.0f / (gscale * xscale);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= out_scale;
+    }
     wgrad_store_partial<TM, TN>(a, acc, slice, m0, n0, wm, wn, lane);
 }
 
@@ -469,12 +695,13 @@ extern "C" int usip_mlp_x3p_tile_rows(int M)
     return (M > 128 && t != 1) ? 256 : 128;
 }
 
+
 // Bytes of the split weight image usip_mlp_split3_f32 writes for an M x K operand.
 extern "C" long long usip_mlp_split3_bytes(int M, int K)
 {
     if (M < 1 || K < 1) return 0;
     const int bm = usip_mlp_x3p_tile_rows(M);
-    return (long long)((M + bm - 1) / bm) * ((K + XBK - 1) / XBK) * 3 * bm * 32;
+    return (long long)((M + bm - 1) / bm) * ((K + XBK - 1) / XBK) * 3 * bm * 32;      // sized for three planes
 }
 
 extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream)
@@ -483,7 +710,23 @@ extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void*
     const int bm = usip_mlp_x3p_tile_rows(M);
     const int ksteps = (K + XBK - 1) / XBK, mts = (M + bm - 1) / bm;
     USIP_LAUNCH(split3_tiles_kernel, dim3((unsigned)(mts * ksteps)), dim3(2 * bm), 0, (hipStream_t)stream, At, lda, M, K,
-                reinterpret_cast<uint4*>(planes), ksteps, bm);
+                reinterpret_cast<uint4*>(planes), ksteps, bm, 3);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+// The two-plane fp16 image of the same operand for usip_mlp_gemm_x2h_f32 (same buffer size: usip_mlp_split3_bytes):
+// per stage two planes, and behind the image one float = the power of two the operand was multiplied by.
+extern "C" int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, void* planes, void* stream)
+{
+    if (!At || !planes || M < 1 || K < 1 || lda < M || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
+    const int bm = usip_mlp_x3p_tile_rows(M);
+    const int ksteps = (K + XBK - 1) / XBK, mts = (M + bm - 1) / bm;
+    usip_split3_desc d{At, planes, lda, M, K, 0, bm, 2};
+    USIP_LAUNCH(absmax_one_kernel, dim3(X2H_PARTS), dim3(256), 0, (hipStream_t)stream, d);
+    USIP_LAUNCH_CHECK();
+    USIP_LAUNCH(split3_tiles_kernel, dim3((unsigned)(mts * ksteps)), dim3(2 * bm), 0, (hipStream_t)stream, At, lda, M, K,
+                reinterpret_cast<uint4*>(planes), ksteps, bm, 2);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
@@ -500,12 +743,15 @@ extern "C" int usip_mlp_split3_multi_f32(const usip_split3_desc* descs_device, i
     if (n < 0 || total_blocks < 0) return USIP_EINVAL;
     if (n == 0 || total_blocks == 0) return USIP_OK;
     if (!descs_device) return USIP_EINVAL;
+    // operands asked for as two fp16 planes (reserved == 2) get their scale first; the others return at once
+    USIP_LAUNCH(absmax_multi_kernel, dim3((unsigned)(n * X2H_PARTS)), dim3(256), 0, (hipStream_t)stream, descs_device, n);
+    USIP_LAUNCH_CHECK();
     USIP_LAUNCH(split3_multi_kernel, dim3((unsigned)total_blocks), dim3(512), 0, (hipStream_t)stream, descs_device, n);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
 
-template <int TM, int WN>
+template <int TM, int WN, int NPL = 3>
 static int launch_x3p(const GemmArgs& a, const uint4* pl, int pro, hipStream_t st)
 {
     constexpr int BM = 64 * TM, BN = 64 * WN;
@@ -516,12 +762,14 @@ static int launch_x3p(const GemmArgs& a, const uint4* pl, int pro, hipStream_t s
     dim3 grid((unsigned)total), block(128 * WN);
 #define USIP_X3P_CASE(P_, E_)                                                                 \
     if (pro == P_ && epi == E_) {                                                             \
-        USIP_LAUNCH((gemm_x3p_kernel<P_, E_, TM, WN>), grid, block, 0, st, a, pl);            \
+        USIP_LAUNCH((gemm_x3p_kernel<P_, E_, TM, WN, NPL>), grid, block, 0, st, a, pl);       \
         USIP_LAUNCH_CHECK();                                                                  \
         return USIP_OK;                                                                       \
     }
-    USIP_X3P_CASE(PRO_NONE, EPI_STATS)
-    USIP_X3P_CASE(PRO_NONE, EPI_NONE)
+    if constexpr (NPL == 3) {
+        USIP_X3P_CASE(PRO_NONE, EPI_STATS)
+        USIP_X3P_CASE(PRO_NONE, EPI_NONE)
+    }
     USIP_X3P_CASE(PRO_AFFINE_RELU, EPI_STATS)
     USIP_X3P_CASE(PRO_AFFINE_RELU, EPI_NONE)
     USIP_X3P_CASE(PRO_BN_BWD, EPI_NONE)
@@ -570,6 +818,36 @@ extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const f
     return launch_x3p<4, 2>(a, pl, pro, st);
 }
 
+// The same product from TWO fp16 planes per operand and THREE plane products (half the matrix work of f32x3, error at
+// the same level): `planes` from usip_mlp_split2h_f32 (or a usip_split3_desc with reserved = 2).  Only for launches
+// whose streamed operand has a known bound: pro 1 with coef = the [4][K] (scale, shift, mean, invstd) of a BatchNorm
+// over exactly the nb * P samples of this launch (training mode), pro 2 / 3 with coef = the [5][K] array
+// usip_bn_backward_reduce_f32 / usip_bn_pool_backward_reduce_f32 write with want_bound.  Everything else as
+// usip_mlp_gemm_x3p_f32.
+extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                                     const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
+                                     const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
+                                     int M, int K, int P, int nb, void* stream)
+{
+    if (M < 1 || K < 1 || K > 640 || P < 0 || nb < 0) return USIP_EINVAL;
+    if (pro != PRO_AFFINE_RELU && pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && K > 512) return USIP_EINVAL;
+    if ((long long)P * nb == 0) return USIP_OK;
+    if (!planes || !Y || !coef || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
+    if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || stats)) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 1 || P % pool_group != 0)) return USIP_EINVAL;
+    if (rowbias && (rb_group < 1 || P % rb_group != 0)) return USIP_EINVAL;
+    if (y_rows == 0) y_rows = M;
+    if (y_rows < M) return USIP_EINVAL;
+    GemmArgs a{nullptr, 0, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rb_group, pool_dp, pool_arg, pool_group,
+               0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
+    hipStream_t st = (hipStream_t)stream;
+    const uint4* pl = reinterpret_cast<const uint4*>(planes);
+    if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2, 2>(a, pl, pro, st);
+    return launch_x3p<4, 2, 2>(a, pl, pro, st);
+}
+
 // ---- weight gradient, 256 x 256 tiles -------------------------------------------------------------------------
 namespace usip_mlp {
 
@@ -588,6 +866,16 @@ void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* til
     if (sl < 512) sl = 512;
     *seglen = (int)sl;
     *segs = (int)((P + sl - 1) / sl);
+}
+
+int launch_wgrad_x2h_256(const WgradArgs& a, int pro, unsigned blocks, hipStream_t st)
+{
+    dim3 grid(blocks), block(512);
+    if (pro == PRO_BN_BWD) USIP_LAUNCH((wgrad_x3_kernel<PRO_BN_BWD, true, 2>), grid, block, 0, st, a);
+    else if (pro == PRO_BN_BWD_POOL) USIP_LAUNCH((wgrad_x3_kernel<PRO_BN_BWD_POOL, true, 2>), grid, block, 0, st, a);
+    else return USIP_EINVAL;
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
 }
 
 int launch_wgrad_x3_256(const WgradArgs& a, int pro, bool xpro, unsigned blocks, hipStream_t st)

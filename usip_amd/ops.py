@@ -365,7 +365,14 @@ def _opt(t):
 # weight-gradient kernels, fp32 accumulate, everything else fp32 (BASELINE.json configs[1] perf mode).
 #   "f32x3": fp32-accurate products on the bf16 matrix cores (three bf16 planes per operand, six plane products) for
 #   the matrix-bound launches, the fp32 kernel for the rest; results equal "f32" to fp32 rounding.
-MATMUL_MODES = ("f32", "bf16", "f32x3")
+#   "f32x2": as f32x3, and the launches whose streamed operand has a rigorous bound (BatchNorm outputs forward, the
+#   BatchNorm-backward operand with the bound usip_bn_backward_reduce_f32 computes) use TWO fp16 planes and THREE plane
+#   products instead (half the matrix work, error at the same level); the others run the f32x3 kernel.
+MATMUL_MODES = ("f32", "bf16", "f32x3", "f32x2")
+
+
+def _x3_family() -> bool:
+    return _matmul_mode in ("f32x3", "f32x2")
 _matmul_mode = "f32"
 import os as _os                                             # noqa: E402
 if _os.environ.get("USIP_MATMUL_MODE"):                      # lets the whole GPU test suite run under another mode
@@ -393,17 +400,19 @@ def matmul_mode() -> str:
 PLANES_CACHE = None
 
 
-def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int) -> torch.Tensor:
-    """Split image (uint8 tensor) of the M x K operand A[m][k] = At[k, a_offset + m] for usip_mlp_gemm_x3p_f32."""
+def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int, npl: int = 3) -> torch.Tensor:
+    """Split image (uint8 tensor) of the M x K operand A[m][k] = At[k, a_offset + m]: three bf16 planes for
+    usip_mlp_gemm_x3p_f32 (npl 3) or two fp16 planes + scale for usip_mlp_gemm_x2h_f32 (npl 2)."""
     lda = At.shape[1]
-    key = (At.data_ptr(), lda, int(a_offset), int(M), int(K))
+    key = (At.data_ptr(), lda, int(a_offset), int(M), int(K), int(npl))
     if PLANES_CACHE is not None and key in PLANES_CACHE:
         return PLANES_CACHE[key][1]
     nbytes = int(_lib.lib().usip_mlp_split3_bytes(M, K))
     planes = torch.empty(nbytes, dtype=torch.uint8, device=At.device)
+    fn = "usip_mlp_split2h_f32" if npl == 2 else "usip_mlp_split3_f32"
     with torch.cuda.device(At.device), prof.kernel("weight_split3", 4.0 * M * K + nbytes):
-        _lib.check(_lib.lib().usip_mlp_split3_f32(ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset)), lda, M, K,
-                                                  _ptr(planes), _stream(At)), "usip_mlp_split3_f32")
+        _lib.check(getattr(_lib.lib(), fn)(ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset)), lda, M, K,
+                                           _ptr(planes), _stream(At)), fn)
     if PLANES_CACHE is not None:
         PLANES_CACHE[key] = (At, planes)      # holding At keeps its storage (the key) from being reused meanwhile
     return planes
@@ -420,11 +429,12 @@ class PlanesPlan:
         spans = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in storages if t is not None]
         self.entries, rows, blocks = {}, [], 0
         for key, (At, planes) in cache.items():
-            ptr, lda, off, M, K = key
+            ptr, lda, off, M, K, npl = key
             if not any(lo <= ptr < hi for lo, hi in spans):
                 continue
             self.entries[key] = (At, planes)
-            rows.append((ptr + 4 * off, planes.data_ptr(), lda, M, K, blocks, int(_lib.lib().usip_mlp_x3p_tile_rows(M)), 0))
+            rows.append((ptr + 4 * off, planes.data_ptr(), lda, M, K, blocks, int(_lib.lib().usip_mlp_x3p_tile_rows(M)),
+                         2 if npl == 2 else 0))
             blocks += int(_lib.lib().usip_mlp_split3_blocks(M, K))
         self.blocks = blocks
         dt = np.dtype([("At", "<u8"), ("planes", "<u8"), ("lda", "<i4"), ("M", "<i4"), ("K", "<i4"), ("first", "<i4"),
@@ -508,9 +518,13 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
         stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
     bf16 = _matmul_mode == "bf16"
-    fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
-    x3 = _matmul_mode == "f32x3" and bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb))
+    fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3",
+               "f32x2": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
+    x3 = _x3_family() and bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb))
     x3p = x3 and not a_trans and K <= (512 if pro >= 2 else 640)       # weight operand split ahead of time
+    # two fp16 planes: only where the streamed operand's bound is known (see usip_mlp_gemm_x2h_f32)
+    x2h = (x3p and _matmul_mode == "f32x2" and coef is not None and
+           ((pro == 1 and coef.shape[0] >= 4) or (pro >= 2 and coef.shape[0] >= 5)))
 
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
@@ -521,8 +535,10 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         if x3p:
             bm = _lib.lib().usip_mlp_x3p_tile_rows(M)
             bn = _lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), e)
-            return "gemm_x3p_kernel<%d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64,
-                                                               nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
+            if x2h:
+                bn = 128
+            return "gemm_x3p_kernel<%d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3,
+                                                                   nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
         if x3:
             return "gemm_bf16_kernel<2, 2, 16, %d, %d, 3> |wg=%d" % (pro, e, nb * ((P + 127) // 128) * ((M + 127) // 128))
         # csrc/shared_mlp.hip mlp_gemm_impl: 32 rows per wave when 128-row tiles would not fill the chip
@@ -532,16 +548,16 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         return "gemm_kernel<%d, %d, 16, %d, %d, %s, %d> |wg=%d" % (wm, wn, pro, e, "true" if P % 4 == 0 else "false", tm,
                                                                    tiles * ((M + bm - 1) // bm))
 
-    planes = weight_planes(At, a_offset, M, K) if x3p else None
+    planes = weight_planes(At, a_offset, M, K, 2 if x2h else 3) if x3p else None
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P, rocprof_key=_key):
         if x3p:
-            _lib.check(_lib.lib().usip_mlp_gemm_x3p_f32(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
-                                                        _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
-                                                        _opt(pool_dp), _opt(pool_arg), int(pool_group), y_ptr,
-                                                        int(y_rows), _opt(stats), M, K, P, nb, _stream(X)),
-                       "usip_mlp_gemm_x3p_f32")
+            fn = "usip_mlp_gemm_x2h_f32" if x2h else "usip_mlp_gemm_x3p_f32"
+            _lib.check(getattr(_lib.lib(), fn)(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
+                                               _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
+                                               _opt(pool_dp), _opt(pool_arg), int(pool_group), y_ptr,
+                                               int(y_rows), _opt(stats), M, K, P, nb, _stream(X)), fn)
             return Y, stats
         _lib.check(getattr(_lib.lib(), fn_name)(a_ptr, -lda if a_trans else lda,
                                                 None if pool is not None else _ptr(X), _opt(X2),
@@ -582,19 +598,21 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
     group > 0 additionally returns gsum [2,nb,C,P/group] (per-neighbourhood sums of dYhat and y)."""
     nb, C, P = dZ.shape
     dev = dZ.device
-    partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
+    # f32x2 mode: the pass also takes max |dYhat| per row and leaves a bound of |dY| in row 4 of coef4 ([5][C])
+    want_bound = 1 if (_matmul_mode == "f32x2" and Y is not None) else 0
+    partial = torch.empty((3 if want_bound else 2) * nb * C, dtype=torch.float32, device=dev)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
     dgamma = coef4 = gsum = None
     if Y is not None:
         dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
-        coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+        coef4 = torch.empty((5 if want_bound else 4, C), dtype=torch.float32, device=dev)
         if group:
             gsum = torch.empty((2, nb, C, P // group), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("bn_backward_reduce", 4.0 * nb * C * P * (1 if Y is None else 2)):
         _lib.check(_lib.lib().usip_bn_backward_reduce_f32(_ptr(dZ), _opt(Y), _opt(coef_fwd), _opt(mean), _opt(invstd),
                                                           _opt(gamma), int(bool(relu)), _ptr(partial), _opt(dgamma),
                                                           _ptr(dbeta), _opt(coef4), _opt(gsum), int(group),
-                                                          nb, C, P, _stream(dZ)),
+                                                          nb, C, P, want_bound, _stream(dZ)),
                    "usip_bn_backward_reduce_f32")
     return dgamma, dbeta, coef4, gsum
 
@@ -605,15 +623,16 @@ def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, rel
     yarg: Y4 at the arg-max as group_max_act(..., want_yarg=True) returned it (saves the gathers)."""
     nb, C, M, K = Y4.shape
     dev = Y4.device
-    partial = torch.empty(2 * nb * C, dtype=torch.float32, device=dev)
+    want_bound = 1 if _matmul_mode == "f32x2" else 0
+    partial = torch.empty((3 if want_bound else 2) * nb * C, dtype=torch.float32, device=dev)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
-    coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+    coef4 = torch.empty((5 if want_bound else 4, C), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("bn_backward_reduce_pooled", 4.0 * nb * C * M * 3):
         _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _opt(yarg),
                                                                _ptr(coef_fwd), _ptr(mean), _ptr(invstd), _opt(gamma),
                                                                int(bool(relu)), _ptr(partial), _ptr(dgamma), _ptr(dbeta),
-                                                               _ptr(coef4), nb, C, M, K, _stream(Y4)),
+                                                               _ptr(coef4), nb, C, M, K, want_bound, _stream(Y4)),
                    "usip_bn_pool_backward_reduce_f32")
     return dgamma, dbeta, coef4
 
@@ -635,15 +654,22 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     ldw = dW.shape[1]
     bf16 = _matmul_mode == "bf16"
-    fn_name = {"bf16": "usip_mlp_wgrad_bf16", "f32x3": "usip_mlp_wgrad_f32x3"}.get(_matmul_mode, "usip_mlp_wgrad_f32")
-    x3 = _matmul_mode == "f32x3" and not (M <= 64 and N <= 64) and bool(_lib.lib().usip_mlp_wgrad_f32x3_used(M, N, P, nb))
+    fn_name = {"bf16": "usip_mlp_wgrad_bf16", "f32x3": "usip_mlp_wgrad_f32x3",
+               "f32x2": "usip_mlp_wgrad_f32x3"}.get(_matmul_mode, "usip_mlp_wgrad_f32")
+    x3 = _x3_family() and not (M <= 64 and N <= 64) and bool(_lib.lib().usip_mlp_wgrad_f32x3_used(M, N, P, nb))
+    # two fp16 planes: both operands need a bound (coef4 with its fifth row, xcoef = batch statistics)
+    x2h = (x3 and _matmul_mode == "f32x2" and pro >= 2 and coef4 is not None and coef4.shape[0] >= 5 and M > 128 and N > 128
+           and xcoef is not None and xcoef.shape[0] >= 4 and P % 4 == 0)
+    if x2h:
+        fn_name = "usip_mlp_wgrad_x2h_f32"
 
     def _key():
         t = 1 if (M <= 64 and N <= 64) else 2
         if x3:
             blocks = _lib.lib().usip_mlp_wgrad_f32x3_blocks(M, N, P, nb)
             if blocks < 0:
-                return "wgrad_x3_kernel<%d, %s> |wg=%d" % (pro, "true" if xcoef is not None else "false", -blocks)
+                return "wgrad_x3_kernel<%d, %s, %d> |wg=%d" % (pro, "true" if xcoef is not None else "false",
+                                                               2 if x2h else 3, -blocks)
         planes = ", 1" if bf16 else (", 3" if x3 else "")
         return "%s<%d, %d, %d, %s, %s%s> |wg=%d" % ("wgrad_bf16_kernel" if (bf16 or x3) else "wgrad_kernel", t, t, pro,
                                                     "true" if xcoef is not None else "false",
@@ -715,7 +741,7 @@ def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bo
         _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _opt(yarg),
                                                                _ptr(coef_fwd), _ptr(mean), _ptr(invstd), None,
                                                                int(bool(relu)), _ptr(partial), None, None, None, nb, C,
-                                                               M, K, _stream(Y4)), "usip_bn_pool_backward_reduce_f32")
+                                                               M, K, 0, _stream(Y4)), "usip_bn_pool_backward_reduce_f32")
     return partial
 
 
