@@ -53,11 +53,14 @@ def parse():
     ap.add_argument("--n", "--points", dest="n", type=int, default=16384)
     ap.add_argument("--m", "--nodes", dest="m", type=int, default=512)
     ap.add_argument("--cloud", default="slab")
-    ap.add_argument("--precision", default="f32x3", choices=["f32", "f32x3", "f32x2", "bf16"],
-                    help="f32x3 (default) = fp32-ACCURATE products on the bf16 matrix cores for the "
-                         "matrix-bound layers (three bf16 planes per operand, six plane products, fp32 accumulation; "
-                         "error at the fp32 kernels' level, every parity test passes in this mode: "
-                         "tests/test_f32x3_mode_gpu.py, USIP_MATMUL_MODE=f32x3 pytest -m gpu), fp32 MFMA for the rest; "
+    ap.add_argument("--precision", default="f32x2", choices=["f32", "f32x3", "f32x2", "bf16"],
+                    help="f32x2 (default since round 3) = fp32-ACCURATE products on the 16-bit matrix cores for the "
+                         "matrix-bound layers: two fp16 planes per operand, three plane products, operands scaled by "
+                         "exact powers of two from rigorous bounds (tests/test_f32x2_mode_gpu.py; the whole-step parity "
+                         "tests of tests/test_modules_gpu.py run in this mode), launches without an operand bound as "
+                         "f32x3, fp32 MFMA for the HBM-bound layers; "
+                         "f32x3 = three bf16 planes per operand, six plane products (round 2's default; "
+                         "tests/test_f32x3_mode_gpu.py); "
                          "f32 = fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere; "
                          "bf16 = bf16 multiply / fp32 accumulate, tensors stay fp32 (perf mode of BASELINE configs[1]; "
                          "NOT a parity mode)")
@@ -67,6 +70,9 @@ def parse():
                     help="(default since round 2, kept for old command lines) replay from HIP graphs at every N: graph A "
                          "(forward+backward) / eager RCCL all-reduce / graph B (Adam); a refused capture falls back "
                          "to eager launches with a warning")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                    help="measurement aid: set a launch-geometry knob of the library (usip_set_tuning; speed only, never "
+                         "results), e.g. --tune x3_gemm_tile=5; recorded in config.tuning")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -275,6 +281,10 @@ def main():
     from usip_amd import ops, prof, synth
     from usip_amd.networks import DetectorOptions
     assert not Fh.pins_active(), "bench.py never runs with the decision-pinning test hooks"
+    from usip_amd import _lib
+    for kv in args.tune:
+        name, val = kv.split("=")
+        _lib.check(_lib.lib().usip_set_tuning(name.encode(), int(val)), "usip_set_tuning(%s)" % kv)
     if args.only_kernels:
         print(json.dumps({"kernels": kernel_leg(dev, load_traffic_db(args.precision)[0])}), flush=True)
         return
@@ -433,7 +443,7 @@ def main():
                                ("" if args.no_optimizer else "+adam"),
                        "launch": "HIP graph replay (2 graphs per step, all-reduce between them)" if graphed
                                  else "eager",
-                       "parallelism": "dp%d" % world},
+                       "parallelism": "dp%d" % world, "tuning": args.tune or None},
             "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,
         }
         if census is not None:

@@ -1,0 +1,229 @@
+"""The f32x2 mode of the shared-MLP kernels (csrc/shared_mlp_x3.hip, NPL = 2): fp32-accurate products from TWO fp16
+planes per operand and THREE plane products, both operands scaled by exact powers of two derived from rigorous bounds.
+
+Held to the same bar as f32x3 (tests/test_f32x3_mode_gpu.py): against an fp64 product of the SAME fp32 operands
+(prologue evaluated in fp32 first) the error must be at the fp32-MFMA kernel's own level -- here additionally over
+operand magnitudes from 1e-12 to 1e4 (gradient-like scales), with heavy-tailed operands (the scale comes from a
+BOUND, so typical elements sit far below the top of the fp16 range), and for hard values of the split.
+
+The kernels take their operand scale from BatchNorm statistics, so the tests build operands the way a training step
+has them: X is a layer's pre-BN output with its true batch statistics, dZ / Y go through usip_bn_backward_reduce_f32."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _fma(a, b, c):
+    return (a.double() * b.double() + c.double()).float()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-300))
+
+
+@pytest.fixture
+def x2_forced():
+    from usip_amd import _lib, ops
+    prev = ops.set_matmul_mode("f32x2")
+    _lib.lib().usip_set_tuning(b"gemm_split3", 2)
+    yield
+    _lib.lib().usip_set_tuning(b"gemm_split3", 0)
+    ops.set_matmul_mode(prev)
+
+
+def _bn_coef(y, gamma, beta, eps=1e-5):
+    """(scale, shift, mean, invstd) of training-mode BatchNorm over y [nb,C,P], as usip_bn_finalize_f32 leaves them."""
+    mu = y.double().mean(dim=(0, 2))
+    var = y.double().var(dim=(0, 2), unbiased=False)
+    istd = (1.0 / torch.sqrt(var + eps)).float()
+    sc = gamma * istd
+    return torch.stack([sc, beta - mu.float() * sc, mu.float(), istd]).contiguous()
+
+
+SHAPES = [(2, 128, 128, 1024), (1, 131, 256, 512), (1, 512, 512, 1024), (2, 256, 256, 2048), (2, 40, 130, 333),
+          (1, 640, 512, 512), (2, 512, 256, 640)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("scale", [1.0, 1e-6, 3e3])
+@pytest.mark.parametrize("heavy", [False, True])
+def test_gemm_forward_f32x2_is_fp32_accurate(shape, scale, heavy, x2_forced):
+    """pro = 1: Y = W . relu(bn(X)) + bias with statistics epilogue.  `scale`: magnitude of the pre-BN tensor (the
+    BatchNorm brings it back to O(gamma), the weights carry `scale` instead so the PRODUCT spans the range)."""
+    from usip_amd import ops
+    nb, K, M, P = shape
+    g = torch.Generator().manual_seed(K * 7 + M + P)
+    At = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5 * scale).to(DEV)
+    X = torch.randn(nb, K, P, generator=g)
+    if heavy:
+        X = X * torch.exp(1.5 * torch.randn(nb, K, P, generator=g))
+    X = (X * 7.0 + 3.0).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    bias = (0.1 * scale * torch.randn(M, generator=g)).to(DEV)
+    coef = _bn_coef(X, gamma, beta)
+    xin = torch.relu(_fma(X, coef[0].view(1, K, 1), coef[1].view(1, K, 1)))
+    Y, stats = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)
+    want = torch.matmul(At.double().t().unsqueeze(0), xin.double()) + bias.double().view(1, M, 1)
+    prev = ops.set_matmul_mode("f32")
+    Y32, _ = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)
+    ops.set_matmul_mode(prev)
+    e2, e32 = _rel(Y, want), _rel(Y32, want)
+    assert torch.isfinite(Y).all()
+    assert e2 <= max(5e-7, 2 * e32), (e2, e32)
+    assert e2 < 2e-6
+    assert not torch.equal(Y, Y32)                         # it really is the other kernel
+    s = stats.double().sum(-1)
+    assert _rel(s[1], (Y.double() ** 2).sum((0, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[1] <= 512])
+@pytest.mark.parametrize("gscale", [1.0, 1e-12, 1e-6, 1e4])
+def test_gemm_backward_f32x2_is_fp32_accurate(shape, gscale, x2_forced):
+    """pro = 2: dX = W^T . dY with dY = BatchNorm'(ReLU'(dZ)) rebuilt from (dZ, Y, coef4); the incoming gradient at
+    magnitudes from 1e-12 to 1e4, heavy-tailed (a few entries 1e3 x the typical one)."""
+    from usip_amd import ops
+    nb, K, M, P = shape
+    g = torch.Generator().manual_seed(K * 11 + M + P)
+    W = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)          # [Cout = K][Cin = M], the dgrad's K-major operand
+    Yp = (torch.randn(nb, K, P, generator=g) * 2.0 + 0.5).to(DEV)            # the layer's pre-BN output
+    dZ = torch.randn(nb, K, P, generator=g)
+    dZ[torch.rand(nb, K, P, generator=g) < 1e-4] *= 1e3
+    dZ = (dZ * gscale).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    cf = _bn_coef(Yp, gamma, beta)
+    dgamma, dbeta, coef4, _ = ops.bn_backward_reduce(dZ, Yp, cf, cf[2].contiguous(), cf[3].contiguous(), gamma, True)
+    assert coef4.shape[0] == 5
+    c = [coef4[i].view(1, K, 1) for i in range(4)]
+    dyh = torch.where(_fma(Yp, c[0], c[1]) > 0, dZ, torch.zeros_like(dZ))
+    dy = _fma(c[0], dyh, _fma(c[2], Yp, c[3]))
+    assert float(coef4[4, :(K + 63) // 64].max()) >= float(dy.abs().max())    # the bound is a bound
+    dX, _ = ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4, tag="dgrad")
+    want = torch.matmul(W.double().t().unsqueeze(0), dy.double())
+    prev = ops.set_matmul_mode("f32")
+    dX32, _ = ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4[:4].contiguous(), tag="dgrad")
+    ops.set_matmul_mode(prev)
+    e2, e32 = _rel(dX, want), _rel(dX32, want)
+    assert torch.isfinite(dX).all()
+    assert e2 <= max(5e-7, 2 * e32), (e2, e32)
+    assert e2 < 2e-6
+    assert not torch.equal(dX, dX32)
+
+
+@pytest.mark.parametrize("shape", [(1, 512, 512, 4096), (2, 256, 512, 2048), (1, 256, 256, 8192), (2, 384, 200, 1024)])
+@pytest.mark.parametrize("gscale", [1.0, 1e-12, 1e4])
+def test_wgrad_f32x2_is_fp32_accurate(shape, gscale, x2_forced):
+    """dW = sum_p dY[m][p] act(X)[n][p] with both operands on two fp16 planes (256 x 256 tiles: M, N > 128)."""
+    from usip_amd import ops
+    nb, M, N, P = shape
+    g = torch.Generator().manual_seed(M * 5 + N + P)
+    Yp = (torch.randn(nb, M, P, generator=g) * 2.0 + 0.5).to(DEV)
+    dZ = (torch.randn(nb, M, P, generator=g) * gscale).to(DEV)
+    X = (torch.randn(nb, N, P, generator=g) * 3.0 - 1.0).to(DEV)
+    gm, bm = (1 + 0.3 * torch.randn(M, generator=g)).to(DEV), (0.3 * torch.randn(M, generator=g)).to(DEV)
+    gn, bn = (1 + 0.3 * torch.randn(N, generator=g)).to(DEV), (0.3 * torch.randn(N, generator=g)).to(DEV)
+    cf, xcoef = _bn_coef(Yp, gm, bm), _bn_coef(X, gn, bn)
+    _, _, coef4, _ = ops.bn_backward_reduce(dZ, Yp, cf, cf[2].contiguous(), cf[3].contiguous(), gm, True)
+    c = [coef4[i].view(1, M, 1) for i in range(4)]
+    dyh = torch.where(_fma(Yp, c[0], c[1]) > 0, dZ, torch.zeros_like(dZ))
+    gin = _fma(c[0], dyh, _fma(c[2], Yp, c[3]))
+    xin = torch.relu(_fma(X, xcoef[0].view(1, N, 1), xcoef[1].view(1, N, 1)))
+    dW = ops.mlp_wgrad(dZ, X, pro=2, G2=Yp, coef4=coef4, xcoef=xcoef)
+    want = torch.einsum("bmp,bnp->mn", gin.double(), xin.double())
+    prev = ops.set_matmul_mode("f32x3")
+    dW3 = ops.mlp_wgrad(dZ, X, pro=2, G2=Yp, coef4=coef4, xcoef=xcoef)
+    ops.set_matmul_mode("f32")
+    dW32 = ops.mlp_wgrad(dZ, X, pro=2, G2=Yp, coef4=coef4[:4].contiguous(), xcoef=xcoef)
+    ops.set_matmul_mode(prev)
+    e2, e3, e32 = _rel(dW, want), _rel(dW3, want), _rel(dW32, want)
+    assert torch.isfinite(dW).all()
+    assert e2 <= max(1e-6, 4 * e32, 1.5 * e3), (e2, e3, e32)
+    assert e2 < 2e-6
+    if M > 128 and N > 128:
+        assert not torch.equal(dW, dW3)                    # the two-plane kernel ran
+    assert torch.equal(ops.mlp_wgrad(dZ, X, pro=2, G2=Yp, coef4=coef4, xcoef=xcoef), dW)      # deterministic
+
+
+def test_two_plane_split_is_exact_for_hard_values(x2_forced):
+    """Single products isolated by a diagonal weight matrix: values with all 24 mantissa bits set, powers of two,
+    exact zeros, elements 2^-20 below the tensor's largest.  With both operands scaled towards the top of the fp16
+    range, an element x within 2^-13 of its tensor's bound keeps 22 bits; what the third plane of f32x3 would add
+    is below 2^-22 relative."""
+    from usip_amd import ops
+    K = M = 128
+    P = 256
+    vals = torch.tensor([1.0, -1.0, 3.0, 1.0 + 2.0 ** -23, 2.0 - 2.0 ** -23, 0.333333343, 0.0, -0.0, 7.0e-3, 123.456789,
+                         -9.87654321e-2, 1.9999, 0.5000001, 2.0 ** -6, -2.0 ** -9, 5.0], dtype=torch.float32)
+    At = torch.zeros(K, M)
+    for i in range(K):
+        At[i, i] = vals[i % len(vals)]
+    g = torch.Generator().manual_seed(3)
+    X = (torch.randn(1, K, P, generator=g) * 4.0).to(DEV)
+    ones, zeros = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+    coef = _bn_coef(X, ones, zeros)
+    xin = torch.relu(_fma(X, coef[0].view(1, K, 1), coef[1].view(1, K, 1)))
+    Y, _ = ops.mlp_gemm(At.to(DEV), X, pro=1, coef=coef)
+    want = (At.double().t().to(DEV) @ xin[0].double()).unsqueeze(0)
+    err = (Y.double() - want).abs()
+    big = xin.abs().max().double() * At.abs().max().double()
+    # relative to the element itself for elements within 2^-10 of the operand maxima, relative to the scale otherwise
+    ok = (err <= want.abs() * 2.0 ** -21 + big * 2.0 ** -34)
+    assert bool(ok.all()), float((err / (want.abs() + big * 2.0 ** -13)).max())
+
+
+def test_layer_forward_backward_in_f32x2_mode(x2_forced):
+    """Two stacked shared-MLP layers (conv1x1 + BatchNorm + ReLU, the second consuming the first's lazy activation:
+    that is where the two-plane kernels get their operand bounds) forward and backward against fp64 truth, with the
+    fp32 mode's own bar: <= 1e-5, or no worse than 4x ATen."""
+    import torch.nn.functional as F
+    from usip_amd import functional as Fh
+    for (nb, C0, C1, C2, P) in [(2, 128, 256, 256, 1024), (1, 512, 512, 512, 1024), (2, 131, 256, 512, 512)]:
+        g = torch.Generator().manual_seed(C0 + C1 + C2)
+        x = torch.randn(nb, C0, P, generator=g).to(DEV)
+        w1 = (torch.randn(C1, C0, generator=g) * (2.0 / C0) ** 0.5).to(DEV)
+        w2 = (torch.randn(C2, C1, generator=g) * (2.0 / C1) ** 0.5).to(DEV)
+        b1, b2 = (0.1 * torch.randn(C1, generator=g)).to(DEV), (0.1 * torch.randn(C2, generator=g)).to(DEV)
+        gy = (torch.randn(nb, C2, P, generator=g) * 1e-5).to(DEV)
+        g1, be1 = (1 + 0.1 * torch.randn(C1, generator=g)).to(DEV), (0.1 * torch.randn(C1, generator=g)).to(DEV)
+        g2, be2 = (1 + 0.1 * torch.randn(C2, generator=g)).to(DEV), (0.1 * torch.randn(C2, generator=g)).to(DEV)
+
+        def ref(dtype):
+            t = [v.detach().to(dtype).requires_grad_(True) for v in (x, w1, b1, g1, be1, w2, b2, g2, be2)]
+            h = torch.relu(F.batch_norm(torch.matmul(t[1], t[0]) + t[2].view(1, -1, 1), None, None, t[3], t[4], True, 0.1, 1e-5))
+            y = torch.relu(F.batch_norm(torch.matmul(t[5], h) + t[6].view(1, -1, 1), None, None, t[7], t[8], True, 0.1, 1e-5))
+            y.backward(gy.to(dtype))
+            return [y.detach(), t[0].grad, t[1].grad, t[5].grad, t[3].grad, t[7].grad]
+        truth, aten = ref(torch.float64), ref(torch.float32)
+        xs = x.clone().requires_grad_(True)
+        w1s, w2s = w1.clone().view(C1, C0, 1).requires_grad_(True), w2.clone().view(C2, C1, 1).requires_grad_(True)
+        b1s, b2s = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+        bn1, bn2 = torch.nn.BatchNorm1d(C1).to(DEV).train(), torch.nn.BatchNorm1d(C2).to(DEV).train()
+        bn1.weight.data.copy_(g1); bn1.bias.data.copy_(be1); bn2.weight.data.copy_(g2); bn2.bias.data.copy_(be2)
+        h = Fh.conv1x1_bn_act(xs, w1s, b1s, bn1, True, defer=True)
+        y = Fh.conv1x1_bn_act(h, w2s, b2s, bn2, True)
+        y.backward(gy)
+        got = [y.detach(), xs.grad, w1s.grad.view(C1, C0), w2s.grad.view(C2, C1), bn1.weight.grad, bn2.weight.grad]
+        for name, a, t, f32 in zip(["y", "dx", "dw1", "dw2", "dgamma1", "dgamma2"], got, truth, aten):
+            err, aten_err = _rel(a, t), _rel(f32, t)
+            assert err <= max(1e-5, 4 * aten_err), (name, (nb, C0, C1, C2, P), err, aten_err)
+
+
+def test_f32x2_falls_back_where_no_bound_exists(x2_forced):
+    """Launches whose streamed operand has no bound (raw inputs, eval-mode BatchNorm: coef with two rows) run the
+    f32x3 kernel in f32x2 mode -- same bits as f32x3 mode."""
+    from usip_amd import ops
+    K, M, P = 256, 256, 1024
+    g = torch.Generator().manual_seed(1)
+    At = torch.randn(K, M, generator=g).to(DEV)
+    X = torch.randn(2, K, P, generator=g).to(DEV)
+    coef2 = torch.stack([1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)]).to(DEV)
+    y_raw, _ = ops.mlp_gemm(At, X)
+    y_eval, _ = ops.mlp_gemm(At, X, pro=1, coef=coef2)
+    prev = ops.set_matmul_mode("f32x3")
+    assert torch.equal(ops.mlp_gemm(At, X)[0], y_raw)
+    assert torch.equal(ops.mlp_gemm(At, X, pro=1, coef=coef2)[0], y_eval)
+    ops.set_matmul_mode(prev)

@@ -845,6 +845,7 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
     hipStream_t st = (hipStream_t)stream;
     const uint4* pl = reinterpret_cast<const uint4*>(planes);
     if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2, 2>(a, pl, pro, st);
+    if (usip_mlp_x3p_tile_cols(M, P, nb, pro, stats != nullptr) == 256) return launch_x3p<4, 4, 2>(a, pl, pro, st);
     return launch_x3p<4, 2, 2>(a, pl, pro, st);
 }
 
