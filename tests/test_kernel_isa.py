@@ -1,0 +1,95 @@
+"""Build-time guard for the kernels that synchronise LDS-DMA with hand-counted `s_waitcnt vmcnt(N)` across a raw
+`s_barrier` (csrc/narrow_fwd.hip, csrc/shared_mlp_x3.hip).  Their waits assume an exact number and ORDER of vector
+memory instructions per loop body; if the compiler emitted others (a spill, a hoisted load, a re-ordered DMA) the wait
+would be too short and a tile would be read before its DMA landed -- silently.  hipcc cross-compiles gfx950 without a
+GPU, so the ISA is checked here, on CPU, every time the suite runs:
+
+  narrow_fwd_kernel<OTW, ...>   no scratch; LDS-DMA instructions come in groups of NDMA = 4 per basic block; the only
+                                vmcnt constants are {0, NDMA, NST, NDMA + NST} with NST = 16 * OTW stores per tile
+  gemm_x3p_kernel<..., NPL>     no scratch; in the main loop every LDS-DMA precedes every register load of the streamed
+                                operand, there are NPL * NA DMAs and NXL loads, and the wait in front of the barrier is
+                                vmcnt(NXL) -- "all but the register loads", i.e. the DMA has landed
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S", "--cuda-device-only"]
+
+pytestmark = pytest.mark.skipif(shutil.which(HIPCC) is None and not os.path.exists(HIPCC), reason="hipcc not present")
+
+
+def _asm(src, tmp_path):
+    out = str(tmp_path / (os.path.basename(src) + ".s"))
+    subprocess.run([HIPCC] + FLAGS + ["-x", "hip", os.path.join(ROOT, "usip_amd", "csrc", src), "-o", out],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    return open(out).read()
+
+
+def _functions(asm, prefix):
+    for m in re.finditer(r"^(%s\w+):" % prefix, asm, re.M):
+        body = asm[m.start():asm.index(".Lfunc_end", m.start())]
+        ins = [ln.split(";")[0].strip() for ln in body.split("\n")]
+        yield m.group(1), [i for i in ins if i and (not i.startswith(".") or i.endswith(":"))]
+
+
+def _blocks(ins):
+    cur = []
+    for i in ins:
+        if re.match(r"^\.LBB\d+_\d+:$", i) or i.endswith(":"):
+            if cur:
+                yield cur
+            cur = []
+        else:
+            cur.append(i)
+    if cur:
+        yield cur
+
+
+def test_narrow_forward_kernel_vmcnt_assumptions(tmp_path):
+    asm = _asm("narrow_fwd.hip", tmp_path)
+    seen = 0
+    for name, ins in _functions(asm, "_ZN12_GLOBAL__N_117narrow_fwd_kernel"):
+        seen += 1
+        otw = int(re.search(r"narrow_fwd_kernelILi(\d)E", name).group(1))
+        ndma, nst = 4, 16 * otw
+        assert not any("scratch_" in i for i in ins), name
+        for blk in _blocks(ins):
+            d = sum("global_load_lds_dwordx4" in i for i in blk)
+            assert d in (0, ndma), (name, d)
+        consts = {int(c) for i in ins if i.startswith("s_waitcnt") for c in re.findall(r"vmcnt\((\d+)\)", i)}
+        assert consts <= {0, ndma, nst, ndma + nst}, (name, consts)
+        assert {ndma, nst, ndma + nst} <= consts, (name, consts)          # the counted waits are really there
+    assert seen == 16                                                       # OTW x PRO x STATS x RB
+
+
+def test_split_gemm_main_loop_order_and_counts(tmp_path):
+    asm = _asm("shared_mlp_x3.hip", tmp_path)
+    seen = 0
+    for name, ins in _functions(asm, "_ZN12_GLOBAL__N_115gemm_x3p_kernel"):
+        pro, epi, tm, wn, npl = (int(v) for v in re.search(r"kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELi(\d)E", name).groups())
+        assert not any("scratch_" in i for i in ins), name
+        # the main loop: the block with the most MFMAs that ends in a backward branch
+        per_stage = tm * 2 * (6 if npl == 3 else 3)                         # MFMAs of one stage of one wave
+        loops = [b for b in _blocks(ins) if sum("v_mfma" in i for i in b) >= per_stage and any(i.startswith("s_cbranch") for i in b)]
+        assert loops, name
+        body = max(loops, key=len)
+        dma = [n for n, i in enumerate(body) if "global_load_lds_dwordx4" in i]
+        loads = [n for n, i in enumerate(body) if i.startswith("buffer_load_dword")]
+        na = (64 * tm * 2) // (128 * wn)
+        nxl = {0: 8, 1: 8, 2: 16, 3: 24}[pro]
+        assert len(dma) == npl * na, (name, len(dma))
+        assert len(loads) == nxl, (name, len(loads))
+        assert max(dma) < min(loads), name                                  # "DMA first, then the register loads"
+        bar = max(n for n, i in enumerate(body) if i.startswith("s_barrier"))
+        waits = [i for i in body[:bar] if i.startswith("s_waitcnt") and "vmcnt" in i]
+        assert waits and re.search(r"vmcnt\((\d+)\)", waits[-1]).group(1) == str(nxl), (name, waits[-3:])
+        assert max(loads) < body.index(waits[-1]), name                     # ... and the wait comes after all of them
+        seen += 1
+    assert seen >= 20

@@ -424,7 +424,13 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
         // forward, same box): the DMA issued after store_stage, so that hipcc's vmcnt(0) at the first use of the
         // register loads does not also wait for it (284 vs 258 us: the compiler sinks it to the end of the stage);
         // three scheduling regions pinned with sched_barrier(0), 16 + 8 or 8 + 16 MFMAs around the memory
-        // instructions (265 / 263 vs 254 us).
+        // instructions (265 / 263 vs 254 us); the register loads as inline-asm buffer loads with a hand-counted
+        // vmcnt(DMA count) in front of their first use instead of hipcc's vmcnt(0) (252 vs 260 us, inside the noise).
+        // What the counters say instead (profiles/r03_pmc_x2_gemm.txt): the loop moves 48 KB per stage pair into the
+        // CU -- A planes from L2, the streamed operand from HBM -- at ~25 GB/s per CU, the rate every streaming kernel
+        // of this library tops out at; the matrix pipe is 38 % busy, the vector L1 has requests pending 60 % of the
+        // time.  Larger tiles move fewer bytes per flop: 256 x 256 (one 8-wave workgroup per CU) is 8-14 % faster
+        // stand-alone and 0.5 % SLOWER inside the step (operands then partly sit in the Infinity Cache).
         __builtin_amdgcn_sched_barrier(0x38F);
         USIP_X3_READ_FRAGS()
         USIP_X3_FIRST_HALF()
