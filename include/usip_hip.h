@@ -162,6 +162,14 @@ int usip_detector_loss_combine_f32(const float* d, const float* chamfer, float a
 /* out[0:n] = g[0] * factor (the gradient of a mean). */
 int usip_fill_scaled_f32(const float* g, float factor, float* out, long long n, void* stream);
 
+/* ------------------------------------------------------------------ a-11  optimizer.step()
+ * One Adam step (models/keypoint_detector.py:42-45, :207: torch.optim.Adam(lr, betas = (0.9, 0.999)), eps 1e-8, no
+ * weight decay) on flat fp32 buffers of n elements, 16-B aligned: step_count[0] += 1 (device float, so the update can
+ * live in a captured HIP graph), then m = lerp(m, g, 1 - b1), v = b2 v + (1 - b2) g^2,
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) -- the arithmetic of torch's single-tensor update. */
+int usip_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step_count,
+                       float lr, float beta1, float beta2, float eps, long long n, void* stream);
+
 /* Pooled-concat layers (a-6 / a-7 row-bias rewrite): the sum over each neighbourhood's K positions of the layer's
  * dY, from the per-neighbourhood sums of the BatchNorm-backward reduction: out[b][c][g] = K * coef4[3][c]
  * + coef4[0][c] * gsum0[b][c][g] + coef4[2][c] * gsum1[b][c][g].  gsum0/1, out [nb][C][G], coef4 [4][C]. */

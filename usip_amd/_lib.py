@@ -105,6 +105,7 @@ SIGNATURES = {
     "usip_group_max_backward_f32": ([_f32p, _i32p, _f32p, ctypes.c_longlong, _int, _stream], _int),
     "usip_group_max_backward_add_f32": ([_f32p, _i32p, _f32p, ctypes.c_longlong, _int, _stream], _int),
     "usip_multi_transpose_f32": ([_f32p, _f32p, _i32p, _int, _int, _stream], _int),
+    "usip_adam_step_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _flt, ctypes.c_longlong, _stream], _int),
     "usip_knn_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_knn_points_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_fps_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _stream], _int),

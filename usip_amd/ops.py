@@ -893,6 +893,17 @@ def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr: float, beta1: float, beta2: float, eps: float):
+    """One Adam step on flat fp32 buffers, in place (usip_adam_step_f32); `step` is a device float[1], incremented."""
+    for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (step, "step")):
+        _need(t, n, torch.float32)
+    n = param.numel()
+    with torch.cuda.device(param.device), prof.kernel("adam", 4.0 * 7 * n):
+        _lib.check(_lib.lib().usip_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(step),
+                                                 float(lr), float(beta1), float(beta2), float(eps), n, _stream(param)),
+                   "usip_adam_step_f32")
+
+
 def knn_points(node: torch.Tensor, x: torch.Tensor, K: int) -> torch.Tensor:
     """RPN_Detector_KNN's neighbourhoods (models/networks.py:576-581): i32 [B,M,K], the K cloud points nearest to every
     node, nearest first, ties towards the lower index.  node [B,3,M], x [B,3,N], N <= 16384, K <= min(N, 256)."""
