@@ -79,12 +79,32 @@ __global__ __launch_bounds__(256) void group_max_kernel(
 // is applied on the fly (the activated tensor is never written): rows are (b, c, m), c = (row / M) % C.
 // Every thread group handles RPT rows whose 16-B loads are issued together (non-temporal: the tensor is next read
 // in backward): 4 KiB in flight per wave is what moved ball_query from ~5 to 6.5 TB/s.
+// (r03: rows handled in 32-bit arithmetic -- the channel of a row was a 64-bit division per row --, eight rows per
+// thread group instead of four, and the reduction over the L lanes of a row through DPP lane permutations (quad_perm /
+// row_half_mirror / row_mirror: pure VALU) instead of three ds_bpermute per step: 70 -> 5x us for the K = 64 pools.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+
+template <int L, int CTRL>
+__device__ __forceinline__ void argmax_step(float& best, int& bk, float& braw)
+{
+    const float ov = dpp_f<CTRL>(best);
+    const int ok = dpp_i<CTRL>(bk);
+    const float orw = dpp_f<CTRL>(braw);
+    if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
+}
+
 template <int L>
 __global__ __launch_bounds__(256) void group_max4_kernel(
     const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows,
     const float* __restrict__ coef, int relu, int C, int M, float* __restrict__ zarg)
 {
-    constexpr int RPB = 256 / L, RPT = 4;
+    constexpr int RPB = 256 / L, RPT = 8;
     const int sub = threadIdx.x % L;
     const long long row0 = (long long)blockIdx.x * RPB * RPT + threadIdx.x / L;
     float4 v[RPT];
@@ -93,12 +113,14 @@ __global__ __launch_bounds__(256) void group_max4_kernel(
         const long long row = min(row0 + (long long)j * RPB, rows - 1);          // clamped: branch-free loads
         v[j] = usip_load_stream4(z + (row * L + sub) * 4);
     }
+    const bool small = rows < (1LL << 31);
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
         const long long row = row0 + (long long)j * RPB;
         float4 w = v[j];
         if (coef) {
-            const int ch = (int)((min(row, rows - 1) / M) % C);
+            const int ch = small ? (int)(((unsigned)min(row, rows - 1) / (unsigned)M) % (unsigned)C)
+                                 : (int)((min(row, rows - 1) / M) % C);
             const float s0 = coef[ch], s1 = coef[C + ch];
             w.x = __builtin_fmaf(w.x, s0, s1); w.y = __builtin_fmaf(w.y, s0, s1);
             w.z = __builtin_fmaf(w.z, s0, s1); w.w = __builtin_fmaf(w.w, s0, s1);
@@ -109,12 +131,23 @@ __global__ __launch_bounds__(256) void group_max4_kernel(
         if (w.y > best) { best = w.y; bk = sub * 4 + 1; braw = v[j].y; }
         if (w.z > best) { best = w.z; bk = sub * 4 + 2; braw = v[j].z; }
         if (w.w > best) { best = w.w; bk = sub * 4 + 3; braw = v[j].w; }
+        if constexpr (L == 4 || L == 16) {
+            // every lane of the row ends up with the row's (max, first arg-max): the comparison is symmetric, so any
+            // pairing of lanes that covers the row works -- xor 1, xor 2 inside a quad, then the two mirror steps
+            argmax_step<L, 0xB1>(best, bk, braw);          // quad_perm [1,0,3,2]
+            argmax_step<L, 0x4E>(best, bk, braw);          // quad_perm [2,3,0,1]
+            if constexpr (L == 16) {
+                argmax_step<L, 0x141>(best, bk, braw);     // row_half_mirror
+                argmax_step<L, 0x140>(best, bk, braw);     // row_mirror
+            }
+        } else {
 #pragma unroll
-        for (int off = L / 2; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off);
-            const int ok = __shfl_xor(bk, off);
-            const float orw = __shfl_xor(braw, off);
-            if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
+            for (int off = L / 2; off > 0; off >>= 1) {
+                const float ov = __shfl_xor(best, off);
+                const int ok = __shfl_xor(bk, off);
+                const float orw = __shfl_xor(braw, off);
+                if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
+            }
         }
         if (sub == 0 && row < rows) {
             pooled[row] = best;
@@ -284,7 +317,7 @@ extern "C" int usip_group_max_act_f32(const float* y, const float* coef, int rel
     hipStream_t st = (hipStream_t)stream;
 #define USIP_GM4(L_)                                                                             \
     if (L4 == L_) {                                                                              \
-        const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));                 \
+        const long long blocks = (rows + 8 * (256 / L_) - 1) / (8 * (256 / L_));                 \
         if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                           \
         USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, y, pooled, arg, rows, \
                     coef, relu, C, M, yarg);                                                     \
@@ -306,7 +339,7 @@ extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, l
     if (K % 4 == 0 && (L4 & (L4 - 1)) == 0 && L4 <= 64 && (reinterpret_cast<uintptr_t>(z) & 15u) == 0) {
 #define USIP_GM4(L_)                                                                             \
         if (L4 == L_) {                                                                          \
-            const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));             \
+            const long long blocks = (rows + 8 * (256 / L_) - 1) / (8 * (256 / L_));             \
             if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                       \
             USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows, \
                         (const float*)nullptr, 0, 1, 1, (float*)nullptr);                        \

@@ -858,13 +858,16 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
 // ---- weight gradient, 256 x 256 tiles -------------------------------------------------------------------------
 namespace usip_mlp {
 
-// Slicing of the 256 x 256-tile weight gradient: ~512 workgroups (one per CU at a time, two rounds), position
+// Slicing of the 256 x 256-tile weight gradient: ~256 workgroups (one per CU, one round), position
 // segments that are multiples of 32 and at least 512 long (a workgroup writes a 256 KiB partial tile; shorter
 // segments would make that the dominant traffic).
 void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* tiles)
 {
     *tiles = ((M + 255) / 256) * ((N + 255) / 256);
-    long long want = 512 / (*tiles);
+    // ONE round of workgroups (256, one per CU) since r03: two rounds (512) wrote and re-read twice the partial tiles
+    // (134 MB for the 512 x 512 gradient) for no better balance -- 5.64 -> 5.60 ms per step, same box, three runs each
+    // (measurement knob x3_wgrad_tile = 2 restores the two rounds)
+    long long want = (usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) == 2 ? 512 : 256) / (*tiles);
     if (want < 1) want = 1;
     long long per_cloud = (want + nb - 1) / nb;
     if (per_cloud < 1) per_cloud = 1;
