@@ -100,6 +100,8 @@ def load_traffic_db(precision):
             return "f32"
         if "som" in name or "desc" in name:
             return None
+        if "x2" in name:
+            return "f32x2"
         return "f32x3"
     cands = []
     for f in glob.glob(os.path.join(ROOT, "profiles", "r*traffic*.json")):

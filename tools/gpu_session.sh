@@ -27,7 +27,7 @@ for STEP in "$@"; do
     bench_som_x3) timeout 900 python bench.py --model som --precision f32x3 --no-cpu-baseline > gpurun_out/${TAG}_bench_som_x3.json 2> gpurun_out/${TAG}_bench_som_x3.err ;;
     bench_desc) timeout 900 python bench.py --model descriptor > gpurun_out/${TAG}_bench_desc.json 2> gpurun_out/${TAG}_bench_desc.err ;;
     bench_bf16) timeout 900 python bench.py --precision bf16 --no-cpu-baseline > gpurun_out/${TAG}_bench_bf16.json 2> gpurun_out/${TAG}_bench_bf16.err ;;
-    bench_cfg1) for pr in f32x3 f32 bf16; do timeout 600 python bench.py --model som --points 5000 --nodes 64 --pairs 24 --precision $pr --no-cpu-baseline --no-kernel-leg > gpurun_out/${TAG}_bench_cfg1_${pr}.json 2> gpurun_out/${TAG}_bench_cfg1_${pr}.err; done ;;
+    bench_cfg1) for pr in f32x2 f32x3 f32 bf16; do timeout 600 python bench.py --model som --points 5000 --nodes 64 --pairs 24 --precision $pr --no-cpu-baseline --no-kernel-leg > gpurun_out/${TAG}_bench_cfg1_${pr}.json 2> gpurun_out/${TAG}_bench_cfg1_${pr}.err; done ;;
     profile_som) timeout 1200 bash tools/profile_roofline.sh ${TAG}_som --model som > gpurun_out/${TAG}_profile_som.log 2>&1 ;;
     profile)   timeout 1200 bash tools/profile_roofline.sh ${TAG} > gpurun_out/${TAG}_profile.log 2>&1 ;;
     profile_x2) timeout 1200 bash tools/profile_roofline.sh ${TAG}_x2 --precision f32x2 > gpurun_out/${TAG}_profile_x2.log 2>&1 ;;

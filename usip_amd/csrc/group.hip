@@ -79,9 +79,11 @@ __global__ __launch_bounds__(256) void group_max_kernel(
 // is applied on the fly (the activated tensor is never written): rows are (b, c, m), c = (row / M) % C.
 // Every thread group handles RPT rows whose 16-B loads are issued together (non-temporal: the tensor is next read
 // in backward): 4 KiB in flight per wave is what moved ball_query from ~5 to 6.5 TB/s.
-// (r03: rows handled in 32-bit arithmetic -- the channel of a row was a 64-bit division per row --, eight rows per
-// thread group instead of four, and the reduction over the L lanes of a row through DPP lane permutations (quad_perm /
-// row_half_mirror / row_mirror: pure VALU) instead of three ds_bpermute per step: 70 -> 5x us for the K = 64 pools.)
+// (r03: rows handled in 32-bit arithmetic -- the channel of a row was a 64-bit division per row -- and the reduction over
+// the L lanes of a row through DPP lane permutations (quad_perm / row_half_mirror / row_mirror: pure VALU) instead of
+// three ds_bpermute per step.  Neither changed the time (70 us for 268 MB at K = 64, tools/group_max_bench.py): the pass
+// is bound by its read rate, not by instructions; eight rows per thread group instead of four halved the workgroups
+// and made the smaller pools slower (36 -> 50 us), so four it stays.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void group_max4_kernel(
     const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows,
     const float* __restrict__ coef, int relu, int C, int M, float* __restrict__ zarg)
 {
-    constexpr int RPB = 256 / L, RPT = 8;
+    constexpr int RPB = 256 / L, RPT = 4;
     const int sub = threadIdx.x % L;
     const long long row0 = (long long)blockIdx.x * RPB * RPT + threadIdx.x / L;
     float4 v[RPT];
@@ -317,7 +319,7 @@ extern "C" int usip_group_max_act_f32(const float* y, const float* coef, int rel
     hipStream_t st = (hipStream_t)stream;
 #define USIP_GM4(L_)                                                                             \
     if (L4 == L_) {                                                                              \
-        const long long blocks = (rows + 8 * (256 / L_) - 1) / (8 * (256 / L_));                 \
+        const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));                 \
         if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                           \
         USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, y, pooled, arg, rows, \
                     coef, relu, C, M, yarg);                                                     \
@@ -339,7 +341,7 @@ extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, l
     if (K % 4 == 0 && (L4 & (L4 - 1)) == 0 && L4 <= 64 && (reinterpret_cast<uintptr_t>(z) & 15u) == 0) {
 #define USIP_GM4(L_)                                                                             \
         if (L4 == L_) {                                                                          \
-            const long long blocks = (rows + 8 * (256 / L_) - 1) / (8 * (256 / L_));             \
+            const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));             \
             if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                       \
             USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows, \
                         (const float*)nullptr, 0, 1, 1, (float*)nullptr);                        \
