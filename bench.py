@@ -37,6 +37,8 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3         # f32-in MFMA / f32 vector peak
 PEAK_BF16_TFLOPS = 2500.0
+CU_PATH_GBPS = 6400.0           # what 256 CUs' vector memory paths carry together (~25 GB/s each, L2 hits included):
+#                                 the rate every streaming kernel of this library tops out at
 
 
 def parse():
@@ -521,7 +523,8 @@ def main():
                 fam = {}
                 for name, r in summ.items():
                     f = fam.setdefault(family(name, r), dict(ms=0.0, calls=0, flops=0.0, nbytes=0.0, traffic=0.0,
-                                                          traffic_calls=0, mfma=False))
+                                                          traffic_calls=0, mfma=False, moved=0.0))
+                    f["moved"] += r.get("moved_per_call", 0.0) * r["calls"]
                     f["ms"] += r["total_ms"]
                     f["calls"] += r["calls"]
                     f["flops"] += r["flops_per_call"] * r["calls"]
@@ -551,6 +554,17 @@ def main():
                                if light else "HIP events on the launch stream, every %d-th step of the timed region "
                                "(%d steps)" % (sample_every, timed_steps_sampled)),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
+                    # the second roofline of a split GEMM: bytes it moves into its CUs by construction (weight planes
+                    # re-read from L2 per position tile + streamed operand + output) against the CUs' memory paths
+                    "cu_memory_path": ({"moved_bytes_per_launch": top["moved"] / top["calls"],
+                                        "achieved_GBps": round(top["moved"] / top["calls"] / avg_s / 1e9, 1),
+                                        "ceiling_GBps": CU_PATH_GBPS,
+                                        "frac": round(top["moved"] / top["calls"] / avg_s / 1e9 / CU_PATH_GBPS, 4),
+                                        "note": "~25 GB/s per CU x 256, L2-served bytes included (measured: every "
+                                                "streaming kernel here tops out at it; DESIGN.md 5): this, not the "
+                                                "matrix pipe (38 % busy), bounds the kernel"}
+                                       if top["moved"] > 0 else None),
+                    "fp32_mfma_peak_ratio": (round(ach / PEAK_F32_TFLOPS, 3) if (top["mfma"] and peak != mfma_peak) else None),
                     "traffic_source": traffic_src,
                     "peak_note": ("fp32-equivalent: a split-product launch issues %d 16-bit matrix products per fp32 "
                                   "product, so its ceiling is the dense bf16/fp16 peak (2500 TFLOP/s) / %d; the same "

@@ -549,9 +549,16 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                                    tiles * ((M + bm - 1) // bm))
 
     planes = weight_planes(At, a_offset, M, K, 2 if x2h else 3) if x3p else None
+    moved = 0.0
+    if x3p:      # bytes into the CUs: per (tile, 16-k stage) the weight planes (L2) + the streamed operand, + the output
+        bm_ = int(_lib.lib().usip_mlp_x3p_tile_rows(M))
+        bn_ = 128 if x2h else int(_lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), 1 if want_stats else 0))
+        ntiles = nb * ((P + bn_ - 1) // bn_) * ((M + bm_ - 1) // bm_)
+        moved = ntiles * ((K + 15) // 16) * ((2 if x2h else 3) * bm_ * 32 + 16 * bn_ * 4 * (2 if pro == 2 else 1)) \
+            + 4.0 * nb * M * P
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
-                                                  2.0 * M * K * nb * P, rocprof_key=_key):
+                                                  2.0 * M * K * nb * P, rocprof_key=_key, moved=moved):
         if x3p:
             fn = "usip_mlp_gemm_x2h_f32" if x2h else "usip_mlp_gemm_x3p_f32"
             _lib.check(getattr(_lib.lib(), fn)(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),

@@ -29,9 +29,11 @@ def reset():
 
 
 @contextmanager
-def kernel(name: str, nbytes: float = 0.0, flops: float = 0.0, rocprof_key=None):
+def kernel(name: str, nbytes: float = 0.0, flops: float = 0.0, rocprof_key=None, moved: float = 0.0):
     """rocprof_key: "<kernel template> |wg=<workgroups>" as tools/pmc_summary.py names launches, so that
-    PMC traffic collected in a separate rocprofv3 pass can be attached to this operator."""
+    PMC traffic collected in a separate rocprofv3 pass can be attached to this operator.
+    moved: bytes the launch moves INTO its CUs by construction, L2-served re-reads included (the split GEMMs re-read
+    their weight planes for every position tile) -- what the per-CU memory path (~25 GB/s) has to carry."""
     if not enabled or (_only is not None and not name.startswith(_only)):
         yield
         return
@@ -42,7 +44,7 @@ def kernel(name: str, nbytes: float = 0.0, flops: float = 0.0, rocprof_key=None)
     s.record()                      # current stream == launch stream of the wrapped kernel
     yield
     e.record()
-    _records[name].append((s, e, nbytes, flops))
+    _records[name].append((s, e, nbytes, flops, moved))
 
 
 def summary():
@@ -50,12 +52,13 @@ def summary():
     torch.cuda.synchronize()
     out = {}
     for name, recs in _records.items():
-        ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+        ms = [r[0].elapsed_time(r[1]) for r in recs]
         tot = sum(ms)
         nb = sum(r[2] for r in recs) / len(recs)
         fl = sum(r[3] for r in recs) / len(recs)
         avg_s = tot / len(recs) * 1e-3
         out[name] = dict(rocprof_key=_keys.get(name), calls=len(recs), total_ms=tot, avg_us=avg_s * 1e6, bytes_per_call=nb,
+                         moved_per_call=sum(r[4] for r in recs) / len(recs),
                          flops_per_call=fl, GBps=(nb / avg_s / 1e9) if avg_s > 0 else 0.0,
                          TFLOPs=(fl / avg_s / 1e12) if avg_s > 0 else 0.0)
     return out
