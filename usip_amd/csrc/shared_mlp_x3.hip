@@ -692,6 +692,256 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     wgrad_store_partial<TM, TN>(a, acc, slice, m0, n0, wm, wn, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// f32x2 GEMM for the 128-wide layers (M <= 128 outputs, K <= 128 inputs: conv5 of RPN_Detector_Ball, the second
+// PointNet of RPN_Detector, the descriptor's layers) with the WEIGHT FRAGMENTS RESIDENT IN REGISTERS.
+// The tile kernel above re-reads the layer's 64 KB of weight planes from L2 for every 128-position tile: at K = 128
+// that is as many bytes as the streamed operand itself, and these layers are bound by what a CU's memory path carries
+// (~25 GB/s, L2 hits included).  Here a wave owns 32 output channels for the kernel's lifetime and keeps
+// their fragments of both planes for all K in 64 VGPRs; persistent workgroups (two per CU) walk 64-position tiles,
+// so a CU moves the streamed operand in and the output out -- 2/3 of the bytes.
+//   workgroup = 4 waves = 128 channels x 64 positions; a tile is processed in slabs of 64 k (one barrier per slab, 24
+//   MFMAs per wave between barriers); thread -> (position tid % 64, 16 consecutive k of the slab): loads 16 (32, 48)
+//   values with buffer loads, applies the prologue, splits, writes two 16-B chunks per plane into the slab's LDS image
+//   ([plane][position][64 k], 128-B rows, 16-B chunks XOR-swizzled by the position: conflict-free ds_read_b128);
+//   the slab of step q+1 is prepared and the loads of step q+2 are in flight while step q is multiplied.
+//   The accumulator is D[channel][position] (weights as the MFMA A operand, as in narrow_fwd.hip): a lane holds ONE
+//   position and 16 channels per 32 x 32 tile, so every store instruction writes two full 128-B lines (the first
+//   version used the tile kernel's D'[position][channel] epilogue -- 16-B pieces of 32 different rows per store
+//   instruction -- and ran no faster than the tile kernel, 144 vs 160 us for conv5's forward: the store path, not
+//   the loads, was what the CU was short of).  BatchNorm statistics are per-lane running sums over all the
+//   workgroup's tiles, reduced over the 32 positions of a half-wave once at the end: one partial per channel and
+//   WORKGROUP, no LDS, no barrier in the epilogue.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x2r_kernel(const GemmArgs a, const uint4* __restrict__ planes)
+{
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
+    constexpr int NCOEF = TWO ? 4 : 2;
+    constexpr int BN = 64, SLAB = 64, PLB = BN * SLAB * 2;     // bytes of one plane of one slab: 8 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][2][PLB];   // [buffer][plane]
+    __shared__ float cf[NCOEF][128];
+    __shared__ float redm[4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, kh = lane >> 5;
+    const int nk = (a.K + XBK - 1) / XBK;                      // 16-k steps (<= 8)
+    const int nslab = (a.K + SLAB - 1) / SLAB;                 // 1 or 2
+    const int tpc = (a.P + BN - 1) / BN, total = a.nb * tpc;
+
+    // operand scales (see gemm_x3p_kernel)
+    float bnd = 0.f;
+    if (PRO == PRO_AFFINE_RELU) {
+        const float rn = sqrtf((float)a.nb * (float)a.P);
+        for (int k = tid; k < a.K; k += 256) {
+            const float c0 = a.coef[k], c1 = a.coef[a.K + k], mu = a.coef[2 * a.K + k], is = a.coef[3 * a.K + k];
+            bnd = fmaxf(bnd, fabsf(c0) / is * rn + fabsf(__builtin_fmaf(mu, c0, c1)));
+        }
+    } else {
+        for (int i = tid; i < (a.K + 63) / 64; i += 256) bnd = fmaxf(bnd, a.coef[4 * a.K + i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, off));
+    if (lane == 0) redm[wave] = bnd;
+    __syncthreads();
+    const float xs = pow2_scale(fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3])), X2H_TOP);
+    const float ws = __uint_as_float(planes[(long long)nk * (2 * 128 * 32 / 16)].x);      // behind the image (one M tile)
+    const float out_scale = 1.0f / (xs * ws);
+    for (int i = tid; i < NCOEF * 128; i += 256) {
+        const int r = i / 128, k = i % 128;
+        cf[r][k] = (k < a.K) ? a.coef[r * a.K + k] * xs : 0.f;
+    }
+
+    // resident weight fragments: step s, plane pl -> 8 consecutive k (half kh of the step) of channel 32 wave + c
+    bf16x8 fa[8][2];
+    {
+        const int row = wave * 32 + c;
+        const int chunk = row * 2 + ((kh ^ (row >> 3)) & 1);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (s8 < nk) v = planes[(long long)(s8 * 2 + pl) * 256 + chunk];
+                fa[s8][pl] = __builtin_bit_cast(bf16x8, v);
+            }
+    }
+    __shared__ float bsh[128];
+    if (tid < 128) bsh[tid] = (a.bias && tid < a.M) ? a.bias[tid] : 0.f;     // visible after the barriers below
+    float s1[EPI == EPI_STATS ? 16 : 1], s2[EPI == EPI_STATS ? 16 : 1];
+    if (EPI == EPI_STATS) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+    }
+
+    // streamed operand: thread -> position xp of the tile, 16 consecutive k (k-group xkg, wave-uniform) of a slab
+    const int xp = tid & 63;
+    const int xkg = wave;
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const unsigned cloud_bytes = (unsigned)a.K * (unsigned)a.P * 4u, pool_bytes = (unsigned)a.K * (unsigned)pgrp * 4u;
+
+    // raw operands of one slab step: TWO register sets, so that the loads of step q+3 are issued while step q is
+    // multiplied (with one set -- 4 KiB in flight per wave, 32 KiB per CU at two 4-wave workgroups -- the kernel ran at
+    // the 8 B/clk per CU that 32 KiB cover at ~2 us of loaded latency: 144 us for conv5's forward)
+    struct Raw { float x[16]; float y[TWO ? 16 : 1]; int arg[POOL ? 16 : 1]; int xkin; };
+    auto load_slab = [&](int tile, int sl, Raw& r) {
+        const int b = tile / tpc, p0 = (tile - b * tpc) * BN;
+        const unsigned xpc = (unsigned)min(p0 + xp, a.P - 1);
+        const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((POOL ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)((TWO ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rPd = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(POOL ? a.pool_dp + (long long)b * a.K * pgrp : a.X), 0, POOL ? pool_bytes : 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rPa = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(POOL ? (const float*)(a.pool_arg + (long long)b * a.K * pgrp) : a.X), 0, POOL ? pool_bytes : 4u, 0x00020000);
+        const int xoff = (int)(xpc * 4u);
+        const int goff = POOL ? (int)((xpc / (unsigned)a.pool_group) * 4u) : 0;
+        r.xkin = POOL ? (int)(xpc % (unsigned)a.pool_group) : 0;
+        const int kb = sl * SLAB + xkg * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kc = min(kb + i, a.K - 1);               // rows beyond K meet zero weight planes
+            if (POOL) {
+                r.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, goff, kc * pgrp * 4, 0));
+                r.arg[POOL ? i : 0] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, goff, kc * pgrp * 4, 0);
+            } else {
+                r.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, kc * a.P * 4, 0));
+            }
+            if (TWO) r.y[TWO ? i : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX2, xoff, kc * a.P * 4, 0));
+        }
+    };
+    auto store_slab = [&](int buf, int sl, const Raw& r) {
+        const int kb = sl * SLAB + xkg * 16;
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kc = min(kb + i, 127);
+            const float c0 = cf[0][kc], c1 = cf[1][kc];
+            float c2 = 0.f, c3 = 0.f, w = r.x[i], x = r.x[i];
+            if (TWO) { c2 = cf[TWO ? 2 : 0][kc]; c3 = cf[TWO ? 3 : 0][kc]; w = r.y[TWO ? i : 0]; }
+            if (POOL) x = (r.arg[POOL ? i : 0] == r.xkin) ? x : 0.f;
+            constexpr int PA = POOL ? PRO_BN_BWD : PRO;
+            v[i] = pro_apply<PA>(x, w, c0, c1, c2, c3);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                          // the thread's two 8-k chunks of the slab
+            unsigned p0[4], p1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair_h(v[h * 8 + 2 * j], v[h * 8 + 2 * j + 1], p0[j], p1[j]);
+            const int chunk = (xkg * 2 + h) ^ (xp & 7);
+            *reinterpret_cast<uint4*>(&Bs[buf][0][xp * 128 + chunk * 16]) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+            *reinterpret_cast<uint4*>(&Bs[buf][1][xp * 128 + chunk * 16]) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        }
+    };
+
+    // linear sequence of steps q = (tile iteration, slab); persistent over tiles blockIdx.x, + gridDim.x, ...
+    const int G = gridDim.x;
+    const int first = blockIdx.x;
+    if (first >= total) return;
+    const int my_tiles = (total - first + G - 1) / G;
+    const int nsteps = my_tiles * nslab;
+    auto tile_of = [&](int q) { return first + (q / nslab) * G; };
+    auto slab_of = [&](int q) { return q % nslab; };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    constexpr int DIST = POOL ? 1 : 2;                         // (the pooled form has three arrays per set: one set)
+    Raw rA, rB;
+    load_slab(tile_of(0), slab_of(0), rA);
+    if (DIST == 2 && nsteps > 1) load_slab(tile_of(1), slab_of(1), rB);
+    __syncthreads();                                           // cf visible
+    store_slab(0, slab_of(0), rA);
+    if (nsteps > DIST) load_slab(tile_of(DIST), slab_of(DIST), rA);
+    __syncthreads();
+    int cur = 0;
+    // one step: multiply slab q (LDS buffer cur), turn the registers of step q+1 (`nxt`) into the other buffer, refill
+    // them with step q+3
+    auto step = [&](int q, Raw& nxt) {
+        const int sl = slab_of(q);
+        // fragments of the slab's four 16-k steps: position tile j, step s, plane pl
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            bf16x8 fb[2][2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int pos = j * 32 + c;
+                    fb[pl][j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][pl][pos * 128 + (((s4 * 2 + kh) ^ (pos & 7)) * 16)]);
+                }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {             // slab 0 -> steps 0..3, slab 1 -> steps 4..7 (static indices)
+                if (half == sl) {
+                    const bf16x8 w0 = fa[half * 4 + s4][0], w1 = fa[half * 4 + s4][1];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, fb[1][j]), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w1), __builtin_bit_cast(f16x8, fb[0][j]), acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w0), __builtin_bit_cast(f16x8, fb[0][j]), acc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (q + 1 < nsteps) {
+            store_slab(cur ^ 1, slab_of(q + 1), nxt);
+            if (q + 1 + DIST < nsteps) load_slab(tile_of(q + 1 + DIST), slab_of(q + 1 + DIST), nxt);
+        }
+        if (sl == nslab - 1) {
+            // tile finished: + bias, store, statistics.  lane = position j*32 + c of the tile; register r of position tile j
+            // is channel 32 wave + 8 (r >> 2) + 4 kh + (r & 3): one store instruction = 32 consecutive positions of two rows
+            const int tile = tile_of(q);
+            const int b = tile / tpc, pt = tile - b * tpc, p0 = pt * BN;
+            float* yb = a.Y + (long long)b * a.y_rows * a.P;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pp = p0 + j * 32 + c;
+                const bool pok = pp < a.P;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = wave * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    const float v = __builtin_fmaf(acc[j][r], out_scale, bsh[ch]);
+                    if (pok && ch < a.M) {
+                        yb[(long long)ch * a.P + pp] = v;
+                        if (EPI == EPI_STATS) { s1[EPI == EPI_STATS ? r : 0] += v; s2[EPI == EPI_STATS ? r : 0] = __builtin_fmaf(v, v, s2[EPI == EPI_STATS ? r : 0]); }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // register loads stay in flight across it
+        cur ^= 1;
+    };
+    for (int q = 0; q < nsteps; q += 2) {
+        step(q, DIST == 2 ? rB : rA);                          // step q+1's registers are set B, q+2's set A, ...
+        if (q + 1 < nsteps) step(q + 1, rA);
+    }
+    if (EPI == EPI_STATS) {
+        // per channel: the 32 positions of a half-wave (two 16-lane DPP row sums and one exchange) -> lane c == 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float u = usip_row16_sum(s1[EPI == EPI_STATS ? r : 0]), v = usip_row16_sum(s2[EPI == EPI_STATS ? r : 0]);
+            u += __shfl_xor(u, 16);
+            v += __shfl_xor(v, 16);
+            const int ch = wave * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            if (c == 0 && ch < a.M) {
+                a.stats[(long long)ch * G + blockIdx.x] = u;
+                a.stats[(long long)G * a.M + (long long)ch * G + blockIdx.x] = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // Rows of the tile usip_mlp_gemm_x3p_f32 uses for an M-row operand (= rows per block of the split image).
@@ -853,6 +1103,47 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
     if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2, 2>(a, pl, pro, st);
     if (usip_mlp_x3p_tile_cols(M, P, nb, pro, stats != nullptr) == 256) return launch_x3p<4, 4, 2>(a, pl, pro, st);
     return launch_x3p<4, 2, 2>(a, pl, pro, st);
+}
+
+// f32x2 for the 128-wide layers with register-resident weight fragments (gemm_x2r_kernel): M <= 128, K <= 128, no row
+// bias; `planes` = the usip_mlp_split2h_f32 image; stats: [2][M][usip_mlp_gemm_x2r_tiles(P, nb)] (one partial per workgroup).
+// Otherwise the contract of usip_mlp_gemm_x2h_f32.
+extern "C" int usip_mlp_gemm_x2r_tiles(int P, int nb)
+{
+    const long long total = (long long)nb * ((P + 63) / 64);
+    return (int)(total < 512 ? total : 512);                   // = workgroups: one statistics partial per channel and workgroup
+}
+
+extern "C" int usip_mlp_gemm_x2r_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                                     const float* bias, const float* pool_dp, const int32_t* pool_arg, int pool_group,
+                                     float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream)
+{
+    if (M < 1 || M > 128 || K < 1 || K > 128 || P < 0 || nb < 0) return USIP_EINVAL;
+    if (pro != PRO_AFFINE_RELU && pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) return USIP_EINVAL;
+    if ((long long)P * nb == 0) return USIP_OK;
+    if (!planes || !Y || !coef || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
+    if (pro != PRO_BN_BWD_POOL && !X) return USIP_EINVAL;
+    if ((pro == PRO_BN_BWD || pro == PRO_BN_BWD_POOL) && (!X2 || stats)) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 1 || P % pool_group != 0)) return USIP_EINVAL;
+    if ((long long)K * P >= (1LL << 30)) return USIP_EINVAL;
+    if (y_rows == 0) y_rows = M;
+    if (y_rows < M) return USIP_EINVAL;
+    GemmArgs a{nullptr, 0, X, X2, coef, bias, Y, stats, M, K, P, nb, nullptr, 1, pool_dp, pool_arg, pool_group,
+               0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
+    const long long total = (long long)nb * ((P + 63) / 64);
+    const unsigned grid = (unsigned)(total < 512 ? total : 512);             // two workgroups per CU, persistent
+    hipStream_t st = (hipStream_t)stream;
+    const uint4* pl = reinterpret_cast<const uint4*>(planes);
+    if (pro == PRO_AFFINE_RELU) {
+        if (stats) USIP_LAUNCH((gemm_x2r_kernel<PRO_AFFINE_RELU, EPI_STATS>), dim3(grid), dim3(256), 0, st, a, pl);
+        else USIP_LAUNCH((gemm_x2r_kernel<PRO_AFFINE_RELU, EPI_NONE>), dim3(grid), dim3(256), 0, st, a, pl);
+    } else if (pro == PRO_BN_BWD) {
+        USIP_LAUNCH((gemm_x2r_kernel<PRO_BN_BWD, EPI_NONE>), dim3(grid), dim3(256), 0, st, a, pl);
+    } else {
+        USIP_LAUNCH((gemm_x2r_kernel<PRO_BN_BWD_POOL, EPI_NONE>), dim3(grid), dim3(256), 0, st, a, pl);
+    }
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
 }
 
 // ---- weight gradient, 256 x 256 tiles -------------------------------------------------------------------------

@@ -455,6 +455,8 @@ class PlanesPlan:
 # The narrow forward layers run the streaming kernel; USIP_NARROW_FWD=0 sends them through the generic tile kernel
 # again (A/B measurement, tools/ab_env.sh).
 NARROW_FWD = _os.environ.get("USIP_NARROW_FWD", "1") not in ("0", "off")
+# f32x2 mode: the 128-wide layers on the register-resident-weights kernel; USIP_X2R=0 for A/B runs
+X2R = _os.environ.get("USIP_X2R", "1") not in ("0", "off")
 
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
@@ -513,10 +515,6 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                               _opt(stats), M, K, P, nb, _stream(X)),
                        "usip_mlp_narrow_forward_f32")
         return Y, stats
-    stats = None
-    if want_stats:
-        tiles = _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
-        stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
     bf16 = _matmul_mode == "bf16"
     fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3",
                "f32x2": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
@@ -525,6 +523,12 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     # two fp16 planes: only where the streamed operand's bound is known (see usip_mlp_gemm_x2h_f32)
     x2h = (x3p and _matmul_mode == "f32x2" and coef is not None and
            ((pro == 1 and coef.shape[0] >= 4) or (pro >= 2 and coef.shape[0] >= 5)))
+    # 128-wide layers: weight fragments resident in registers, persistent workgroups (usip_mlp_gemm_x2r_f32)
+    x2r = x2h and M <= 128 and K <= 128 and rowbias is None and X2R
+    stats = None
+    if want_stats:
+        tiles = _lib.lib().usip_mlp_gemm_x2r_tiles(P, nb) if x2r else _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
+        stats = torch.empty((2, M, tiles), dtype=torch.float32, device=X.device)
 
     def _key():
         wm, wn = (1, 4) if M <= 64 else (2, 2)
@@ -535,6 +539,8 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         if x3p:
             bm = _lib.lib().usip_mlp_x3p_tile_rows(M)
             bn = _lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), e)
+            if x2r:
+                return "gemm_x2r_kernel<%d, %d> |wg=%d" % (pro, e, min(512, nb * ((P + 63) // 64)))
             if x2h:
                 bn = 128
             return "gemm_x3p_kernel<%d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3,
@@ -556,9 +562,17 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         ntiles = nb * ((P + bn_ - 1) // bn_) * ((M + bm_ - 1) // bm_)
         moved = ntiles * ((K + 15) // 16) * ((2 if x2h else 3) * bm_ * 32 + 16 * bn_ * 4 * (2 if pro == 2 else 1)) \
             + 4.0 * nb * M * P
+        if x2r:                                               # the weight fragments stay in registers
+            moved = 4.0 * nb * P * (K * (2 if pro == 2 else 1) + M)
     with torch.cuda.device(X.device), prof.kernel("shared_mlp_gemm_%s %dx%d" % (tag, M, K),
                                                   4.0 * nb * P * (K * (2 if pro == 2 else 1) + M),
                                                   2.0 * M * K * nb * P, rocprof_key=_key, moved=moved):
+        if x2r:
+            _lib.check(_lib.lib().usip_mlp_gemm_x2r_f32(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
+                                                        _opt(coef), int(pro), _opt(bias), _opt(pool_dp), _opt(pool_arg),
+                                                        int(pool_group), y_ptr, int(y_rows), _opt(stats), M, K, P, nb,
+                                                        _stream(X)), "usip_mlp_gemm_x2r_f32")
+            return Y, stats
         if x3p:
             fn = "usip_mlp_gemm_x2h_f32" if x2h else "usip_mlp_gemm_x3p_f32"
             _lib.check(getattr(_lib.lib(), fn)(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
