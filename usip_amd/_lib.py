@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libusip_hip.so")
+# USIP_LIB=<path>: load another BUILD of the same library (same-box A/B of two builds, tools/ab_build.sh); never a fallback
+LIB_PATH = os.environ.get("USIP_LIB") or os.path.join(_HERE, "libusip_hip.so")
 _lib = None
 
 _f32p = ctypes.c_void_p

@@ -13,18 +13,27 @@
 
 namespace {
 
-__device__ __forceinline__ double block_sum(double v, double* red)
+// four block sums at once: wave sums by shuffles, then the waves' partials in fixed order (red: [4][16] doubles)
+__device__ __forceinline__ void block_sum4(double (&v)[4], double* red)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_down(v[i], off);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();                                   // red may still be read from the previous call
-    if (lane == 0) red[wave] = v;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[i * 16 + wave] = v[i];
+    }
     __syncthreads();
-    double s = 0.0;
     const int nw = (blockDim.x + 63) >> 6;
-    for (int w = 0; w < nw; ++w) s += red[w];
-    return s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double s = 0.0;
+        for (int w = 0; w < nw; ++w) s += red[i * 16 + w];
+        v[i] = s;
+    }
 }
 
 // one direction: sums of (log s + d/s), d, 1/s, d/s over B*M elements
@@ -34,7 +43,30 @@ __device__ __forceinline__ void side_sums(const float* __restrict__ d, const int
 {
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     const long long total = (long long)B * M;
-    for (long long e = threadIdx.x; e < total; e += blockDim.x) {
+    long long e = threadIdx.x;
+    // four elements per pass, their (dependent: arg -> sigma) loads issued together: the kernel is one workgroup and
+    // was a chain of 2 x 8 x two load latencies (26 us); the additions keep their order
+    for (; e + 3LL * blockDim.x < total; e += 4LL * blockDim.x) {
+        float so[4], st[4], dv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long ei = e + (long long)i * blockDim.x;
+            const int b = (int)(ei / M);
+            so[i] = s_own[ei];
+            st[i] = s_other[(long long)b * N + arg[ei]];
+            dv[i] = d[ei];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float s = (so[i] + st[i]) / 2.0f;
+            const float r = 1.0f / s, q = dv[i] / s;
+            t0 += (double)(logf(s) + q);
+            t1 += (double)dv[i];
+            t2 += (double)r;
+            t3 += (double)(r * dv[i]);
+        }
+    }
+    for (; e < total; e += blockDim.x) {
         const int b = (int)(e / M);
         const float s = (s_own[e] + s_other[(long long)b * N + arg[e]]) / 2.0f;
         const float dv = d[e];
@@ -44,8 +76,8 @@ __device__ __forceinline__ void side_sums(const float* __restrict__ d, const int
         t2 += (double)r;
         t3 += (double)(r * dv);            // the reference forms (1/s) * d for the weighted chamfer
     }
-    out[0] = block_sum(t0, red); out[1] = block_sum(t1, red);
-    out[2] = block_sum(t2, red); out[3] = block_sum(t3, red);
+    out[0] = t0; out[1] = t1; out[2] = t2; out[3] = t3;
+    block_sum4(out, red);
 }
 
 __global__ __launch_bounds__(1024) void chamfer_prob_fwd_kernel(
@@ -53,7 +85,7 @@ __global__ __launch_bounds__(1024) void chamfer_prob_fwd_kernel(
     const int* __restrict__ I, const float* __restrict__ ss, const float* __restrict__ sd,
     float* __restrict__ out, int B, int M, int N)
 {
-    __shared__ double red[16];
+    __shared__ double red[64];
     double f[4], g[4];
     side_sums(a, J, ss, sd, B, M, N, f, red);
     side_sums(c, I, sd, ss, B, N, M, g, red);

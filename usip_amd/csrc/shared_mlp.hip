@@ -493,10 +493,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     __shared__ double red[2][4];
     const int ch = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double s = 0.0, q = 0.0;
-    for (int t = threadIdx.x; t < ntn; t += 256) {
-        s += (double)stats[(long long)ch * ntn + t];
-        q += (double)stats[(long long)ntn * C + (long long)ch * ntn + t];
+    const float* ps = stats + (long long)ch * ntn;
+    const float* pq = stats + (long long)ntn * C + (long long)ch * ntn;
+    int t = threadIdx.x;
+    // eight loads in flight per pass (the kernel is a chain of load latencies: 5-6 us for 16 serial passes); the order
+    // of the additions is the same as with one load per pass
+    for (; t + 768 < ntn; t += 1024) {
+        const float s0 = ps[t], s1 = ps[t + 256], s2 = ps[t + 512], s3 = ps[t + 768];
+        const float q0 = pq[t], q1 = pq[t + 256], q2 = pq[t + 512], q3 = pq[t + 768];
+        s += (double)s0; s += (double)s1; s += (double)s2; s += (double)s3;
+        q += (double)q0; q += (double)q1; q += (double)q2; q += (double)q3;
     }
+    for (; t < ntn; t += 256) { s += (double)ps[t]; q += (double)pq[t]; }
     s = wave_sum(s); q = wave_sum(q);
     if (lane == 0) { red[0][wave] = s; red[1][wave] = q; }
     __syncthreads();
@@ -687,7 +695,21 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
     if (ch < C) {
         double s1 = 0.0, s2 = 0.0;
         float mx = 0.f;
-        for (int b = 0; b < nb; ++b) {
+        int b = 0;
+        // eight rows per pass, all loads issued before the first addition (one row per pass was a chain of nb load
+        // latencies: 8-10 us at nb = 16); same order of additions
+        for (; b + 7 < nb; b += 8) {
+            float u[8], v[8], w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                u[i] = partial[(long long)(b + i) * C + ch];
+                v[i] = partial[nrows + (long long)(b + i) * C + ch];
+                w[i] = want_bound ? partial[2 * nrows + (long long)(b + i) * C + ch] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1 += (double)u[i]; s2 += (double)v[i]; mx = fmaxf(mx, w[i]); }
+        }
+        for (; b < nb; ++b) {
             s1 += (double)partial[(long long)b * C + ch];
             s2 += (double)partial[nrows + (long long)b * C + ch];
             if (want_bound) mx = fmaxf(mx, partial[2 * nrows + (long long)b * C + ch]);
@@ -734,6 +756,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
     if (ch < C) {
         const int per = (rows + 15) / 16, r0 = grp * per, r1 = min(rows, r0 + per);
         int r = r0;
+        for (; r + 7 < r1; r += 8) {                               // 16 loads in flight; the four chains add in the same order
+            float u[8], v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { u[i] = partial[(long long)(r + i) * C + ch]; v[i] = partial[plane + (long long)(r + i) * C + ch]; }
+            a0 += (double)u[0]; b0 += (double)v[0]; a1 += (double)u[1]; b1 += (double)v[1];
+            a2 += (double)u[2]; b2 += (double)v[2]; a3 += (double)u[3]; b3 += (double)v[3];
+            a0 += (double)u[4]; b0 += (double)v[4]; a1 += (double)u[5]; b1 += (double)v[5];
+            a2 += (double)u[6]; b2 += (double)v[6]; a3 += (double)u[7]; b3 += (double)v[7];
+        }
         for (; r + 3 < r1; r += 4) {
             a0 += (double)partial[(long long)r * C + ch];           b0 += (double)partial[plane + (long long)r * C + ch];
             a1 += (double)partial[(long long)(r + 1) * C + ch];     b1 += (double)partial[plane + (long long)(r + 1) * C + ch];
