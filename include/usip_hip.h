@@ -370,7 +370,8 @@ int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int p
  * workspace: usip_mlp_narrow_backward_workspace(Cout, P, nb) floats.
  * red_partial (may be NULL; then xcoef must be the PRODUCING layer's full [4][64] forward coefficients -- scale, shift,
  *   mean, invstd): [2][usip_mlp_narrow_backward_blocks(Cout, P, nb)][64] partial BatchNorm-backward sums of that layer
- *   (sum dX*[relu on], sum dX*[relu on]*xhat), taken while the dX tile is in registers; usip_bn_backward_finalize_f32
+ *   (sum dX*[relu on], sum dX*[relu on]*xhat), taken while the dX tile is in registers, followed by [blocks] maxima of
+ *   |dX [relu on]| (2 * blocks * 64 + blocks floats in all); usip_bn_backward_finalize_f32
  *   turns partial sums (these, plus usip_bn_pool_backward_reduce_f32's when a max-pool also feeds that layer) into
  *   dgamma / dbeta / coef4 -- the separate reduction pass over (dZ, Y) of that layer disappears. */
 int usip_mlp_narrow_backward_supported(int Cin, int Cout, int P);
@@ -380,9 +381,34 @@ int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, const float* c
                                  const float* xcoef, const float* W, int ldw, float* dX, int dx_rows,
                                  float* workspace, float* dW, int lddw, float* red_partial, int Cin, int Cout,
                                  int P, int nb, void* stream);
+
+/* The same fused layer backward on the 16-bit matrix cores with f32x2 arithmetic (csrc/layer_bwd_x2.hip; no reference
+ * counterpart: the layers' backward is autograd's, models/layers.py:208-216, :293-303), for (Cin, Cout) = (64, 64), or
+ * (128, 128) in the pooled form, and P % 64 == 0 (usip_mlp_layer_backward_x2h_supported).  coef4 = the [5][Cout] array usip_bn_backward_reduce_f32 /
+ * usip_bn_backward_finalize_max_f32 write (row 4: bounds of |dY|); pool_dp / pool_arg (i32) [nb][Cout][P / pool_group]
+ * given and dZ NULL: the pooled form, dZ = (p % pool_group == arg) ? pool_dp : 0, (128, 128) only; xcoef = the producing
+ * layer's [4][Cin] (scale, shift, mean, invstd), training-mode statistics over exactly these nb * P samples; planes =
+ * usip_mlp_split2h_f32 image of W as the data-gradient operand (At = W [Cout][ldw], M = Cin, K = Cout).  workspace:
+ * usip_mlp_layer_backward_x2h_workspace floats.  red_partial (may be NULL): [2][blocks][Cin] partial sums of the
+ * producing layer's BatchNorm backward against dX followed by [blocks] maxima of |dX [relu on]|, blocks =
+ * usip_mlp_layer_backward_x2h_blocks. */
+int usip_mlp_layer_backward_x2h_supported(int Cin, int Cout, int P, int pooled);
+long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, int P, int nb);
+int usip_mlp_layer_backward_x2h_blocks(int Cin, int Cout, int P, int nb);
+int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
+                                    const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
+                                    const float* xcoef, const void* planes, float* dX, int dx_rows, float* workspace,
+                                    float* dW, int lddw, float* red_partial, int Cin, int Cout, int P, int nb,
+                                    void* stream);
 int usip_bn_backward_finalize_f32(const float* partial, int rows, int C, long long count, const float* coef_fwd,
                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef4,
                                   void* stream);
+/* The same with the fifth row of coef4 ([5][C]: bounds of |dY| per 64 channels, what the f32x2 kernels scale their
+ * operand by): the gradient is a sum of up to two parts whose maxima |dYhat| are given as arrays (max0[n0], max1[n1],
+ * max1 may be NULL) -- the bound uses max(max0) + max(max1). */
+int usip_bn_backward_finalize_max_f32(const float* partial, int rows, int C, long long count, const float* coef_fwd,
+                                      const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                      float* coef4, const float* max0, int n0, const float* max1, int n1, void* stream);
 /* bf16-multiply variant (see usip_mlp_gemm_bf16); same workspace, same deterministic fp32 reduction. */
 int usip_mlp_wgrad_bf16(const float* G, const float* G2, const float* coef, int pro, const float* X,
                         const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,

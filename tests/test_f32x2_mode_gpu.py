@@ -227,3 +227,107 @@ def test_f32x2_falls_back_where_no_bound_exists(x2_forced):
     assert torch.equal(ops.mlp_gemm(At, X)[0], y_raw)
     assert torch.equal(ops.mlp_gemm(At, X, pro=1, coef=coef2)[0], y_eval)
     ops.set_matmul_mode(prev)
+
+
+def _bn_layer_inputs(g, nb, C, P, scale=1.0):
+    """A pre-BatchNorm tensor with its training-mode forward coefficients [4, C] (scale, shift, mean, invstd)."""
+    x = (torch.randn(nb, C, P, generator=g) * scale + 0.3 * torch.randn(1, C, 1, generator=g)).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(C, generator=g)).to(DEV)
+    mean, var = x.mean((0, 2)), x.var((0, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    coef = torch.stack([gamma * invstd, beta - mean * gamma * invstd, mean, invstd]).contiguous()
+    return x, gamma, mean.contiguous(), invstd.contiguous(), coef
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 4096, 64, 0, 1.0), (3, 64, 64, 1024, 128, 64, 1.0), (1, 64, 64, 640, 64, 0, 1e-4),
+                                 (2, 64, 64, 2048, 64, 0, 1e3)])
+def test_fused_layer_backward_x2_equals_fp64_truth_and_the_separate_products(cfg):
+    """csrc/layer_bwd_x2.hip: data gradient, weight gradient and the producing layer's BatchNorm-backward sums of a
+    64-input layer from ONE pass over (dZ, Y, X) with f32x2 products against fp64 truth, against the generic kernels,
+    and bit for bit on a re-run; gradient magnitudes from 1e-4 to 1e3 (the operand scales come from bounds)."""
+    from usip_amd import ops
+    nb, Cin, Cout, P, Ctot, wcol, gscale = cfg
+    g = torch.Generator().manual_seed(Cin + Cout + P + wcol)
+    prev = ops.set_matmul_mode("f32x2")
+    try:
+        y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, Cout, P)
+        x, gamma_x, mean_x, invstd_x, xcoef = _bn_layer_inputs(g, nb, Cin, P)
+        dz = (torch.randn(nb, Cout, P, generator=g) * gscale).to(DEV)
+        w2 = (torch.randn(Cout, Ctot, generator=g) * (2.0 / Cin) ** 0.5).to(DEV)
+        _, _, coef4, _ = ops.bn_backward_reduce(dz, y, coef_y, mean_y, invstd_y, gamma_y, True)
+        assert coef4.shape[0] == 5
+        assert ops.layer_backward_x2_supported(Cin, Cout, P, (dz, y, x), coef4, xcoef)
+        dw_out = torch.full((Cout, Ctot), 7.0, device=DEV)
+        dx, dw, red = ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol=wcol, dw_out=dw_out, Cin=Cin, want_red=True)
+        c = [coef4[i].double().view(1, Cout, 1) for i in range(4)]
+        fma = lambda a_, b_, c_: (a_.double() * b_.double() + c_.double()).float()
+        dyh = torch.where(fma(y, c[0], c[1]) > 0, dz, torch.zeros_like(dz))
+        dy = fma(c[0], dyh, fma(c[2], y, c[3])).double()
+        ax = torch.relu(fma(x, xcoef[0].view(1, Cin, 1), xcoef[1].view(1, Cin, 1))).double()
+        wsub = w2[:, wcol:wcol + Cin].double()
+        want_dx = torch.einsum("oc,bop->bcp", wsub, dy)
+        want_dw = torch.einsum("bop,bcp->oc", dy, ax)
+        assert _rel(dx, want_dx) < 2e-6, _rel(dx, want_dx)
+        assert _rel(dw[:, wcol:wcol + Cin], want_dw) < 2e-6, _rel(dw[:, wcol:wcol + Cin], want_dw)
+        if Ctot > Cin:
+            keep = torch.ones(Ctot, dtype=torch.bool)
+            keep[wcol:wcol + Cin] = False
+            assert bool((dw[:, keep.to(DEV)] == 7.0).all())
+        # the producing layer's sums and the maximum, against its own reduction pass over (dX, X)
+        sums = red.sums
+        on = fma(x, xcoef[0].view(1, Cin, 1), xcoef[1].view(1, Cin, 1)) > 0
+        d = torch.where(on, dx, torch.zeros_like(dx)).double()
+        xhat = ((x.double() - mean_x.double().view(1, Cin, 1)) * invstd_x.double().view(1, Cin, 1))
+        assert _rel(sums[0].double().sum(0), d.sum((0, 2))) < 5e-6
+        assert _rel(sums[1].double().sum(0), (d * xhat).sum((0, 2))) < 5e-6
+        assert float(red.maxima.max()) == float(d.abs().max().float())
+        dg, db, c4 = ops.bn_backward_from_partials(red, nb * P, xcoef, mean_x, invstd_x)
+        dg2, db2, c42, _ = ops.bn_backward_reduce(dx, x, xcoef, mean_x, invstd_x, gamma_x, True)
+        assert c4.shape[0] == 5 and c42.shape[0] == 5
+        for a_, b_, n in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (c4[:4], c42[:4], "coef4")):
+            assert _rel(a_, b_) < 5e-6, (n, _rel(a_, b_))
+        assert float(c4[4, 0]) >= float(c42[4, 0]) * (1 - 1e-6) and float(c4[4, 0]) <= 64 * float(c42[4, 0])
+        dx3, dw3, red3 = ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol=wcol, Cin=Cin, want_red=True,
+                                                   dw_out=torch.full((Cout, Ctot), 7.0, device=DEV))
+        assert torch.equal(dx3, dx) and torch.equal(dw3, dw) and torch.equal(red3.flat, red.flat)
+    finally:
+        ops.set_matmul_mode(prev)
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 16, 1.0), (1, 64, 64, 1e-3), (3, 32, 16, 30.0)])
+def test_fused_pooled_layer_backward_x2_equals_fp64_truth(cfg):
+    """The pooled form (conv5 of the Ball detector: dZ = dpooled at the arg-max neighbour, zero elsewhere, never
+    materialised), 128 inputs and 128 outputs."""
+    from usip_amd import ops
+    nb, M, K, gscale = cfg
+    Cin = Cout = 128
+    P = M * K
+    if P % 64:
+        pytest.skip("positions must be a multiple of 64")
+    g = torch.Generator().manual_seed(M + K)
+    prev = ops.set_matmul_mode("f32x2")
+    try:
+        y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, Cout, P)
+        x, gamma_x, mean_x, invstd_x, xcoef = _bn_layer_inputs(g, nb, Cin, P)
+        w2 = (torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5).to(DEV)
+        pooled, arg = ops.group_max_act(y.view(nb, Cout, M, K), coef_y, True)
+        dpooled = (torch.randn(nb, Cout, M, generator=g) * gscale).to(DEV)
+        _, _, coef4 = ops.bn_pool_backward_reduce(dpooled, arg, y.view(nb, Cout, M, K), coef_y, mean_y, invstd_y, gamma_y, True)
+        assert coef4.shape[0] == 5
+        assert ops.layer_backward_x2_supported(Cin, Cout, P, (y, x), coef4, xcoef, pooled=True)
+        dx, dw = ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=(dpooled, arg, K))
+        dz = torch.zeros(nb, Cout, M, K, device=DEV).scatter_(3, arg.long().unsqueeze(3), dpooled.unsqueeze(3)).view(nb, Cout, P)
+        c = [coef4[i].double().view(1, Cout, 1) for i in range(4)]
+        fma = lambda a_, b_, c_: (a_.double() * b_.double() + c_.double()).float()
+        dyh = torch.where(fma(y, c[0], c[1]) > 0, dz, torch.zeros_like(dz))
+        dy = fma(c[0], dyh, fma(c[2], y, c[3])).double()
+        ax = torch.relu(fma(x, xcoef[0].view(1, Cin, 1), xcoef[1].view(1, Cin, 1))).double()
+        want_dx = torch.einsum("oc,bop->bcp", w2.double(), dy)
+        want_dw = torch.einsum("bop,bcp->oc", dy, ax)
+        assert _rel(dx, want_dx) < 2e-6, _rel(dx, want_dx)
+        assert _rel(dw, want_dw) < 2e-6, _rel(dw, want_dw)
+        dx3, dw3 = ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=(dpooled, arg, K))
+        assert torch.equal(dx3, dx) and torch.equal(dw3, dw)
+    finally:
+        ops.set_matmul_mode(prev)

@@ -248,8 +248,14 @@ def test_fused_narrow_backward_takes_the_producers_bn_sums(Cout):
     dx, _, red = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, want_red=True)
     dg, db, c4 = ops.bn_backward_from_partials(red, nb * P, xcoef, mean.contiguous(), invstd.contiguous())
     dg2, db2, c42, _ = ops.bn_backward_reduce(dx, x, xcoef, mean.contiguous(), invstd.contiguous(), gamma, True)
-    for a_, b_, n in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (c4, c42, "coef4")):
+    for a_, b_, n in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (c4[:4], c42[:4], "coef4")):
         assert _rel(a_, b_) < 5e-6, (n, _rel(a_, b_))
+    # the kernel also leaves the maxima of |dX [relu on]|: coef4 gets its fifth row, a bound of the producing layer's
+    # |dY| = |a1 dYhat + q1 x + q0| (what that layer's f32x2 backward scales its operand by)
+    assert c4.shape[0] == 5
+    on = (x * xcoef[0].view(1, Cin, 1) + xcoef[1].view(1, Cin, 1)) > 0
+    dyl = c4[0].view(1, Cin, 1) * torch.where(on, dx, torch.zeros_like(dx)) + c4[2].view(1, Cin, 1) * x + c4[3].view(1, Cin, 1)
+    assert float(c4[4, 0]) >= float(dyl.abs().max()) and float(c4[4, 0]) < 1e3 * float(dyl.abs().max())
     # plus a sparse pooling gradient at the arg-max of the activated producer output
     M = P // K
     pooled, arg = ops.group_max_act(x.view(nb, Cin, M, K), xcoef, True)
@@ -258,7 +264,7 @@ def test_fused_narrow_backward_takes_the_producers_bn_sums(Cout):
     dg3, db3, c43 = ops.bn_backward_from_partials([red, sparse], nb * P, xcoef, mean.contiguous(), invstd.contiguous())
     total = ops.group_max_backward_add_(dx.clone().view(nb, Cin, M, K), dpooled, arg).view(nb, Cin, P)
     dg4, db4, c44, _ = ops.bn_backward_reduce(total, x, xcoef, mean.contiguous(), invstd.contiguous(), gamma, True)
-    for a_, b_, n in ((dg3, dg4, "dgamma"), (db3, db4, "dbeta"), (c43, c44, "coef4")):
+    for a_, b_, n in ((dg3, dg4, "dgamma"), (db3, db4, "dbeta"), (c43[:4], c44[:4], "coef4")):
         assert _rel(a_, b_) < 5e-6, (n, _rel(a_, b_))
 
 

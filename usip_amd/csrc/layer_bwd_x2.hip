@@ -1,0 +1,428 @@
+// usip_amd/csrc/layer_bwd_x2.hip -- backward of a shared-MLP layer with <= 128 inputs and <= 128 outputs as ONE kernel,
+// f32x2 arithmetic (two fp16 planes per operand, three plane products: shared_mlp_x3.hip): conv2, conv3, the feature
+// half of conv4 and conv5 of RPN_Detector_Ball (models/networks.py:705-712; the layers' backward is autograd's in the
+// reference: models/layers.py:208-216, :293-303).
+//
+// These layers are HBM-bound and their (dZ, Y) pair used to be read two or three times per step (BatchNorm-backward
+// reduction, data-gradient GEMM, weight-gradient GEMM).  narrow_bwd.hip fused the two products for 64-input layers
+// with exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32) and ended up matrix-pipe bound at half the HBM rate (3.5-3.9 TB/s,
+// MFMA pipe 50-58 % busy).  Here the same fusion runs on the 16-bit matrix cores at 1/5 of the matrix time, with the
+// lessons of gemm_x2r_kernel: weight fragments of the data-gradient resident in registers, D[channel][position]
+// accumulators so that a store instruction writes two full 128-B lines, per-lane running sums instead of per-tile
+// reductions.  A workgroup walks the BP-position tiles of its segment of one cloud:
+//     dY        = BatchNorm'(ReLU'(dZ)) from (dZ, Y, coef4)    (POOL: dZ = (k == arg) ? dpooled : 0, never stored)
+//     dX[ci][p] = sum_co W[co][ci] dY[co][p]                    written tile by tile
+//     dW[co][ci]+= sum_p dY[co][p] act(X)[ci][p]               accumulated in registers over the segment
+//     RED: s1[ci] += dX [relu on], s2[ci] += dX [relu on] xhat, max |dX [relu on]|   (the producing layer's BatchNorm
+//          backward sums and the bound its own f32x2 backward needs; one partial per workgroup).  The tile of dX also
+//          goes to LDS and is summed by the X loader's threads (one channel, 8 positions each: two registers of state
+//          and per-thread coefficients) -- per-lane sums in the accumulator layout cost 32 registers and spilled.
+// The two products contract over different indices, so dY sits in LDS in both orientations: [position][co] chunks of 8
+// channels (B operand of dX; written as 16-B chunks) and [co][position] chunks of 8 positions (A operand of dW; written
+// as 2-B elements, lanes = consecutive positions); act(X) only as [ci][position] -- its loader thread owns 8 consecutive
+// positions of one channel and writes whole 16-B chunks.  Every image row is padded by 16 B (144- / 272- / 80-B strides):
+// conflict-free ds_read_b128 with every address = one base register + an immediate (XOR-swizzled rows cost a
+// register per address: the first build spilled).  Operand scales are exact powers of two from rigorous bounds (shared_mlp_x3.hip): dY from
+// row 4 of coef4, act(X) from the producer's batch statistics, W from the trailer of its split image.
+#include "mlp_common.h"
+#include "split_common.h"
+
+using namespace usip_mlp;
+
+namespace {
+
+struct LayerBwdArgs {
+    const float* dZ; const float* Y; const float* coef4;       // [nb][COUT][P] x2 (POOL: dZ unused), [5][COUT]
+    const float* pool_dp; const int* pool_arg; int pool_group; // POOL: [nb][COUT][P / pool_group] each
+    const float* X; int x_rows; const float* xcoef;            // [nb][x_rows][P] (rows [0, CIN) used), [4][CIN]
+    const uint4* planes;                                       // usip_mlp_split2h_f32 image of W as the dgrad operand (CIN rows, K = COUT)
+    float* dX; int dx_rows;                                    // [nb][dx_rows][P], rows [0, CIN) written
+    float* part;                                               // [nb * segs][COUT][CIN]
+    float* red;                                                // RED: [2][nb * segs][CIN] sums, then [nb * segs] maxima
+    int P, nb, seglen, segs;
+};
+
+// byte offset of (row, position) in a [rows][BP positions] fp16 image: rows of BP * 2 + 16 bytes
+template <int BP>
+__device__ __forceinline__ int rows_off(int row, int pos) { return row * (BP * 2 + 16) + pos * 2; }
+
+template <int CIN, int COUT, bool POOL, bool RED, int NW, int WPE = 2>
+__global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerBwdArgs a)
+{
+    constexpr int NT = 64 * NW;
+    constexpr int BP = (NW == 8) ? 64 : 32;                    // positions per tile
+    constexpr int GC = COUT * BP / NT;                         // output channels per (dZ, Y) loader thread: 8 or 16
+    constexpr bool EARLY = (GC == 8);                          // next tile's loads re-issued inside write_tile (16: register pressure)
+    constexpr int NCI = CIN / 32, NCO = COUT / 32, NPT = BP / 32;
+    constexpr int NDX = NCI * NPT;                             // 32 x 32 tiles of dX per position tile: one per wave
+    constexpr int NDW = NCO * NCI / NW;                        // 32 x 32 tiles of dW per wave (same co tile)
+    constexpr int KS = COUT / 16, PS = BP / 16;                // k-steps of dX (over co), of dW (over positions)
+    constexpr int XPC = BP / 8, XRP = NT / XPC, NPX = CIN / XRP;   // X loader: 8-position pieces per row, rows per pass, passes
+    constexpr int RB1 = COUT * 2 + 16, PL1 = BP * RB1;         // G1 [plane][position][COUT (+ 16 B)]
+    constexpr int RS2 = BP * 2 + 16;                           // G2 [plane][co][BP (+ 16 B)], X2 [plane][ci][BP (+ 16 B)]
+    constexpr int PL2 = COUT * RS2, PLX = CIN * RS2;
+    static_assert(NDX <= NW && (NCO * NCI) % NW == 0 && (GC == 8 || GC == 16) && CIN % XRP == 0 && (!RED || NPX == 1), "tile roles");
+    constexpr int XRS = BP + 4;                                // floats per row of the fp32 images (16 B of padding, as above)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PL1 + 2 * PL2 + 2 * PLX + (RED ? 2 * CIN * XRS * 4 : 16)];
+    __shared__ float cfG[4][COUT];
+    __shared__ float cfX[2][CIN];
+    __shared__ float redm[2][NW];
+    unsigned char* G1 = smem;
+    unsigned char* G2 = smem + 2 * PL1;
+    unsigned char* X2 = G2 + 2 * PL2;
+    float* XR = reinterpret_cast<float*>(X2 + 2 * PLX);        // RED: [CIN][BP] raw X
+    float* DX = XR + (RED ? CIN * XRS : 0);                    // RED: [CIN][BP] this tile of dX
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.x / a.segs, seg = blockIdx.x % a.segs;
+    const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
+    const int ntile = (pend - pbeg) / BP;
+
+    // operand scales
+    float bg = 0.f, bx = 0.f;
+    for (int i = tid; i < (COUT + 63) / 64; i += NT) bg = fmaxf(bg, a.coef4[4 * COUT + i]);
+    {
+        const float rn = sqrtf((float)a.nb * (float)a.P);
+        for (int k = tid; k < CIN; k += NT) {
+            const float c0 = a.xcoef[k], c1 = a.xcoef[CIN + k], mu = a.xcoef[2 * CIN + k], is = a.xcoef[3 * CIN + k];
+            bx = fmaxf(bx, fabsf(c0) / is * rn + fabsf(__builtin_fmaf(mu, c0, c1)));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { bg = fmaxf(bg, __shfl_xor(bg, off)); bx = fmaxf(bx, __shfl_xor(bx, off)); }
+    if (lane == 0) { redm[0][wave] = bg; redm[1][wave] = bx; }
+    __syncthreads();
+    bg = redm[0][0]; bx = redm[1][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) { bg = fmaxf(bg, redm[0][w]); bx = fmaxf(bx, redm[1][w]); }
+    const float sG = pow2_scale(bg, X2H_TOP), sX = pow2_scale(bx, X2H_TOP);
+    const float ws = __uint_as_float(a.planes[(long long)KS * 512].x);     // behind the image (one 128-row M tile)
+    const float dx_scale = 1.0f / (sG * ws), dw_scale = 1.0f / (sG * sX);
+    for (int i = tid; i < 4 * COUT; i += NT) cfG[i / COUT][i % COUT] = a.coef4[i] * sG;
+    for (int i = tid; i < 2 * CIN; i += NT) cfX[i / CIN][i % CIN] = a.xcoef[i] * sX;
+
+    // roles.  dX: wave w < NDX owns input tile w % NCI at position tile w / NCI, its weight fragments stay in registers.
+    // dW: wave w owns tiles T = w NDW + u: co tile T / NCI (the same for all u), ci tile T % NCI.
+    const bool does_dx = (NDX == NW) || wave < NDX;
+    const int dx_ci = wave % NCI, dx_pt = (wave / NCI) % NPT;
+    const int dw_co = (wave * NDW) / NCI;
+    bf16x8 fa[KS][2];
+    {
+        const int row = dx_ci * 32 + c;
+        const int chunk = row * 2 + ((kh ^ (row >> 3)) & 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[s][pl] = __builtin_bit_cast(bf16x8, a.planes[(long long)(s * 2 + pl) * 256 + chunk]);
+    }
+    f32x16 acc_dw[NDW];
+#pragma unroll
+    for (int u = 0; u < NDW; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dw[u][r] = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;                        // RED: the thread's channel (its X row), its 8 positions of every tile
+
+    // loaders.  (dZ, Y): thread -> position gp of the tile, the GC output channels [GC gg, GC gg + GC); buffer loads with
+    // the row as a scalar offset.  X: thread -> 8 consecutive positions (piece xq) of row xr0 (+ XRP per pass).
+    const int gp = tid % BP, gg = tid / BP;
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const unsigned cloud_bytes = (unsigned)COUT * (unsigned)a.P * 4u, pool_bytes = (unsigned)COUT * (unsigned)pgrp * 4u;
+    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((POOL ? a.Y : a.dZ) + (long long)b * COUT * a.P), 0, cloud_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Y + (long long)b * COUT * a.P), 0, cloud_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? a.pool_dp + (long long)b * COUT * pgrp : a.Y), 0, POOL ? pool_bytes : 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPa = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? (const float*)(a.pool_arg + (long long)b * COUT * pgrp) : a.Y), 0, POOL ? pool_bytes : 4u, 0x00020000);
+    const int xq = tid % XPC, xr0 = tid / XPC;
+    const float* xbase = a.X + ((long long)b * a.x_rows + xr0) * a.P + pbeg + xq * 8;
+    float rz[GC], ry[GC], rx[NPX][8];
+    int ra[POOL ? GC : 1], rkin = 0;
+    auto load_gy = [&](int t) {
+        const int p = pbeg + t * BP + gp;
+        const int voff = (int)(((unsigned)p + (unsigned)(GC * gg) * (unsigned)a.P) * 4u);
+        if (POOL) {
+            const int g = p / a.pool_group;
+            rkin = p - g * a.pool_group;
+            const int poff = (int)(((unsigned)g + (unsigned)(GC * gg) * (unsigned)pgrp) * 4u);
+#pragma unroll
+            for (int i = 0; i < GC; ++i) {
+                rz[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, poff, i * pgrp * 4, 0));
+                ra[POOL ? i : 0] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, poff, i * pgrp * 4, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < GC; ++i)
+                rz[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, voff, i * a.P * 4, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < GC; ++i)
+            ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, voff, i * a.P * 4, 0));
+    };
+    auto load_x = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            const float4* src = reinterpret_cast<const float4*>(xbase + (long long)q * XRP * a.P + (long long)t * BP);
+            const float4 u = src[0], v = src[1];
+            rx[q][0] = u.x; rx[q][1] = u.y; rx[q][2] = u.z; rx[q][3] = u.w;
+            rx[q][4] = v.x; rx[q][5] = v.y; rx[q][6] = v.z; rx[q][7] = v.w;
+        }
+    };
+    // One tile from the prefetched registers into LDS.  The loads of the NEXT tile (the last tile: a harmless repeat) are re-issued as soon as
+    // a register group has been consumed -- in front of the splits and the LDS writes, not behind them: with the loads
+    // issued after this phase a tile cost a full memory latency on top of it (4.3 us per 32-position tile).
+    auto write_tile = [&](int nxt) {
+        // act(X) first: its temporaries are dead before the 2 GC values of dY come to life
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) {
+            const int row = xr0 + q * XRP;
+            const float sc = cfX[0][row], sh = cfX[1][row];
+            if (RED) {
+                float4* dst = reinterpret_cast<float4*>(XR + row * XRS + xq * 8);
+                dst[0] = make_float4(rx[q][0], rx[q][1], rx[q][2], rx[q][3]);
+                dst[1] = make_float4(rx[q][4], rx[q][5], rx[q][6], rx[q][7]);
+            }
+            unsigned q0[4], q1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                split_pair_h(fmaxf(__builtin_fmaf(rx[q][2 * j], sc, sh), 0.f), fmaxf(__builtin_fmaf(rx[q][2 * j + 1], sc, sh), 0.f),
+                             q0[j], q1[j]);
+            const int off = rows_off<BP>(row, xq * 8);
+            *reinterpret_cast<uint4*>(X2 + off) = make_uint4(q0[0], q0[1], q0[2], q0[3]);
+            *reinterpret_cast<uint4*>(X2 + PLX + off) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+        }
+        if (EARLY) load_x(nxt);
+        float v[GC];
+        const int kin = rkin;
+#pragma unroll
+        for (int i = 0; i < GC; ++i) {
+            const int co = GC * gg + i;
+            float dz = rz[i];
+            if (POOL) dz = (ra[POOL ? i : 0] == kin) ? dz : 0.f;
+            v[i] = pro_apply<PRO_BN_BWD>(dz, ry[i], cfG[0][co], cfG[1][co], cfG[2][co], cfG[3][co]);
+        }
+        if (EARLY) load_gy(nxt);
+#pragma unroll
+        for (int h = 0; h < GC / 8; ++h) {
+            unsigned p0[4], p1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_pair_h(v[8 * h + 2 * j], v[8 * h + 2 * j + 1], p0[j], p1[j]);
+            const int off = gp * RB1 + ((GC / 8) * gg + h) * 16;
+            *reinterpret_cast<uint4*>(G1 + off) = make_uint4(p0[0], p0[1], p0[2], p0[3]);
+            *reinterpret_cast<uint4*>(G1 + PL1 + off) = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = GC * gg + 8 * h + 2 * j;
+                const int o0 = rows_off<BP>(co, gp), o1 = rows_off<BP>(co + 1, gp);
+                *reinterpret_cast<unsigned short*>(G2 + o0) = (unsigned short)(p0[j] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(G2 + o1) = (unsigned short)(p0[j] >> 16);
+                *reinterpret_cast<unsigned short*>(G2 + PL2 + o0) = (unsigned short)(p1[j] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(G2 + PL2 + o1) = (unsigned short)(p1[j] >> 16);
+            }
+        }
+        if (!EARLY) { load_gy(nxt); load_x(nxt); }
+    };
+
+    // RED: the thread's channel is its X row xr0; what it reads of XR it alone overwrites (in write_tile), and DX is
+    // rewritten only behind the next tile's first barrier: no barrier of its own
+    const float rsc = RED ? a.xcoef[xr0] : 0.f, rsh = RED ? a.xcoef[CIN + xr0] : 0.f;
+    const float rmu = RED ? a.xcoef[2 * CIN + xr0] : 0.f, ris = RED ? a.xcoef[3 * CIN + xr0] : 0.f;
+    auto red_pass = [&]() {
+        const float4* xs4 = reinterpret_cast<const float4*>(XR + xr0 * XRS + xq * 8);
+        const float4* ds4 = reinterpret_cast<const float4*>(DX + xr0 * XRS + xq * 8);
+        const float4 x0 = xs4[0], x1 = xs4[1], d0 = ds4[0], d1 = ds4[1];
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = (__builtin_fmaf(xv[i], rsc, rsh) > 0.f) ? dv[i] : 0.f;
+            s1 += d;
+            s2 = __builtin_fmaf(d, (xv[i] - rmu) * ris, s2);
+            mx = fmaxf(mx, fabsf(d));
+        }
+    };
+
+    float* dXb = a.dX + (long long)b * a.dx_rows * a.P;
+    if (ntile > 0) { load_gy(0); load_x(0); }
+    if (RED) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { XR[xr0 * XRS + xq * 8 + i] = 0.f; DX[xr0 * XRS + xq * 8 + i] = 0.f; }
+    }
+    __syncthreads();                                           // coefficients are in LDS
+    for (int t = 0; t < ntile; ++t) {
+        if (RED) red_pass();                                   // the previous tile (the first time: the zeros written above)
+        write_tile(min(t + 1, ntile - 1));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // (raw: the loads stay in flight across it)
+        if (does_dx) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int pos = dx_pt * 32 + c;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int off = pos * RB1 + (2 * s + kh) * 16;
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(G1 + off);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(G1 + PL1 + off);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][0]), b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][1]), b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][0]), b0, acc, 0, 0, 0);
+                if (KS == 8 && (s & 1)) __builtin_amdgcn_sched_barrier(0);     // keeps hipcc from hoisting all 16 fragment reads (spills)
+            }
+            // lane = position pos of the tile; register r = input channel 32 dx_ci + 8 (r >> 2) + 4 kh + (r & 3): a store
+            // instruction writes 32 consecutive positions of two rows
+            float* orow = dXb + pbeg + (long long)t * BP + pos;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = dx_ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                const float v = acc[r] * dx_scale;
+                orow[(long long)ci * a.P] = v;
+                if (RED) DX[ci * XRS + pos] = v;
+            }
+        }
+        // dW[co][ci] += sum_p dY[co][p] act(X)[ci][p]
+#pragma unroll
+        for (int s = 0; s < PS; ++s) {
+            const int offA = rows_off<BP>(dw_co * 32 + c, (2 * s + kh) * 8);
+            const f16x8 a0 = *reinterpret_cast<const f16x8*>(G2 + offA);
+            const f16x8 a1 = *reinterpret_cast<const f16x8*>(G2 + PL2 + offA);
+#pragma unroll
+            for (int u = 0; u < NDW; ++u) {
+                const int ci_t = (wave * NDW + u) % NCI;
+                const int offB = rows_off<BP>(ci_t * 32 + c, (2 * s + kh) * 8);
+                const f16x8 b0 = *reinterpret_cast<const f16x8*>(X2 + offB);
+                const f16x8 b1 = *reinterpret_cast<const f16x8*>(X2 + PLX + offB);
+                acc_dw[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_dw[u], 0, 0, 0);
+                acc_dw[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc_dw[u], 0, 0, 0);
+                acc_dw[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc_dw[u], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // everyone is done reading this tile's LDS
+    }
+    {
+        float* out = a.part + (long long)blockIdx.x * COUT * CIN;
+#pragma unroll
+        for (int u = 0; u < NDW; ++u) {
+            const int ci_t = (wave * NDW + u) % NCI;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = dw_co * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                out[row * CIN + ci_t * 32 + c] = acc_dw[u][r] * dw_scale;
+            }
+        }
+    }
+    if (RED) {
+        if (ntile > 0) red_pass();                             // the last tile (behind the loop's closing barrier)
+        // the XPC threads of a channel are neighbouring lanes; one partial per channel and workgroup
+#pragma unroll
+        for (int off = 1; off < XPC; off <<= 1) {
+            s1 += __shfl_xor(s1, off);
+            s2 += __shfl_xor(s2, off);
+            mx = fmaxf(mx, __shfl_xor(mx, off));
+        }
+        const long long nblk = (long long)a.nb * a.segs;
+        if (xq == 0) {
+            a.red[(long long)blockIdx.x * CIN + xr0] = s1;
+            a.red[(nblk + blockIdx.x) * CIN + xr0] = s2;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        __syncthreads();
+        float* rs = reinterpret_cast<float*>(smem);
+        if (lane == 0) rs[wave] = mx;
+        __syncthreads();
+        if (tid == 0) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) m = fmaxf(m, rs[w]);
+            a.red[2 * nblk * CIN + blockIdx.x] = m;
+        }
+    }
+}
+
+// Position segments per cloud (a multiple of 64 positions each): as many workgroups as the chip holds AT ONCE (two
+// 4-wave workgroups per CU, one 8-wave workgroup for the 128 x 128 form), so that the launch is a single round.
+void layer_bwd_plan(int Cin, int Cout, int P, int nb, int* seglen, int* segs)
+{
+    const long long slots = (Cin == 128 && Cout == 128) ? 256 : 512;
+    long long per_cloud = slots / nb;
+    if (per_cloud < 1) per_cloud = 1;
+    const long long tiles = (P + 63) / 64;
+    long long tps = (tiles + per_cloud - 1) / per_cloud;      // 64-position tiles per segment
+    if (tps < 4) tps = 4;
+    *seglen = (int)(tps * 64);
+    *segs = (int)((P + *seglen - 1) / *seglen);
+}
+
+}  // namespace
+
+// 1 when usip_mlp_layer_backward_x2h_f32 takes the shape: (Cin, Cout) = (64, 64), or (128, 128) in the pooled form (dZ
+// synthesised from dpooled / arg); positions a multiple of 64.  ((64, 128) and the plain (128, 128) form compile and
+// pass the tests, but the first needs 36 B of scratch with the sums for the producing layer and measured no faster
+// than narrow_bwd.hip -- 221 vs 225-233 us -- and the second has no caller.)
+extern "C" int usip_mlp_layer_backward_x2h_supported(int Cin, int Cout, int P, int pooled)
+{
+    if (P <= 0 || P % 64 != 0 || (long long)Cout * P >= (1LL << 30) || (long long)Cin * P >= (1LL << 30)) return 0;
+    if (pooled) return (Cin == 128 && Cout == 128) ? 1 : 0;
+    return (Cin == 64 && Cout == 64) ? 1 : 0;
+}
+
+extern "C" int usip_mlp_layer_backward_x2h_blocks(int Cin, int Cout, int P, int nb)
+{
+    int seglen, segs;
+    layer_bwd_plan(Cin, Cout, P, nb, &seglen, &segs);
+    return nb * segs;
+}
+
+extern "C" long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, int P, int nb)
+{
+    return (long long)usip_mlp_layer_backward_x2h_blocks(Cin, Cout, P, nb) * Cout * Cin;
+}
+
+// dX[b][ci][p] = sum_co W[co][ci] dY[b][co][p]  and  dW[co * lddw + ci] = sum_{b,p} dY[b][co][p] act(X)[b][ci][p]  with
+// f32x2 products; dY = BatchNorm'(ReLU'(dZ)) rebuilt from (dZ, Y, coef4) -- coef4 = the [5][Cout] array
+// usip_bn_backward_reduce_f32 / usip_bn_backward_finalize_f32 write with want_bound -- or, when pool_dp / pool_arg are
+// given (dZ = NULL), from dZ[b][co][p] = (p % pool_group == pool_arg[b][co][p / pool_group]) ? pool_dp[b][co][p /
+// pool_group] : 0; act(X) = relu(X xcoef[0] + xcoef[1]), xcoef = the PRODUCING layer's [4][Cin] (scale, shift, mean,
+// invstd) of a training-mode BatchNorm over exactly these nb * P samples.  planes: usip_mlp_split2h_f32 image of W as
+// the data-gradient operand (At = W [Cout][ldw] K-major, M = Cin, K = Cout).  X / dX point at the first of the Cin rows
+// inside [nb][x_rows][P] / [nb][dx_rows][P]; all pointers 16-B aligned.  workspace:
+// usip_mlp_layer_backward_x2h_workspace floats.  red_partial (may be NULL): receives [2][blocks][Cin] partial sums of the
+// producing layer's BatchNorm backward against dX, then [blocks] maxima of |dX [relu on]|
+// (usip_bn_backward_finalize_f32 with a maxima pointer turns them into that layer's [5][Cin] coef4).
+extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
+                                               const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
+                                               const float* xcoef, const void* planes, float* dX, int dx_rows,
+                                               float* workspace, float* dW, int lddw, float* red_partial, int Cin,
+                                               int Cout, int P, int nb, void* stream)
+{
+    const bool pooled = pool_dp != nullptr;
+    if (!usip_mlp_layer_backward_x2h_supported(Cin, Cout, P, pooled ? 1 : 0) || nb < 1 || x_rows < Cin || dx_rows < Cin ||
+        lddw < Cin)
+        return USIP_EINVAL;
+    if ((!pooled && !dZ) || !Y || !coef4 || !X || !xcoef || !planes || !dX || !workspace || !dW) return USIP_EINVAL;
+    if (pooled && (!pool_arg || pool_group < 1 || P % pool_group != 0)) return USIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(X) |
+         reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(planes)) & 15u)
+        return USIP_EINVAL;
+    int seglen, segs;
+    layer_bwd_plan(Cin, Cout, P, nb, &seglen, &segs);
+    LayerBwdArgs a{dZ, Y, coef4, pool_dp, pool_arg, pool_group, X, x_rows, xcoef, reinterpret_cast<const uint4*>(planes),
+                   dX, dx_rows, workspace, red_partial, P, nb, seglen, segs};
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)(nb * segs));
+    const bool red = red_partial != nullptr;
+    if (Cin == 64) {
+        if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4>), grid, dim3(256), 0, st, a);
+        else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        if (red) return USIP_EINVAL;
+        USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8>), grid, dim3(512), 0, st, a);
+    }
+    USIP_LAUNCH_CHECK();
+    return usip_mlp::launch_wgrad_reduce(workspace, dW, (long long)Cout * Cin, nb * segs, Cin, lddw, 0, st);
+}

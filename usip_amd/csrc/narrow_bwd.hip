@@ -24,7 +24,7 @@ struct NarrowArgs {
     float* dX; int dx_rows;                                // [nb][dx_rows][P], rows [0, CIN) written
     float* part;                                           // [nb * segs][COUT][CIN]
     int x_rows, P, nb, seglen, segs;
-    float* red;                                            // RED: [2][nb * segs][CIN] BatchNorm-backward sums of the INPUT layer
+    float* red;                                            // RED: [2][nb * segs][CIN] BatchNorm-backward sums of the INPUT layer, then [nb * segs] maxima
 };
 
 // RED (needs XPRO; xcoef is then the producing layer's [4][CIN] forward coefficients: scale, shift, mean, invstd): the
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
     const int c = lane & 31, kr = lane >> 5;
     float* dXb = a.dX + (long long)b * a.dx_rows * a.P;
     // RED: per-lane coefficients of the lane's input channel in the two roles
-    float wsc = 1.f, wsh = 0.f, rsc = 1.f, rsh = 0.f, rmu = 0.f, ris = 0.f, s1 = 0.f, s2 = 0.f;
+    float wsc = 1.f, wsh = 0.f, rsc = 1.f, rsh = 0.f, rmu = 0.f, ris = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
     if (RED) {
         wsc = a.xcoef[dw_ct * 32 + c]; wsh = a.xcoef[CIN + dw_ct * 32 + c];
         const int ci = (dx_ct & 1) * 32 + c;                  // waves without a dX tile (COUT = 128: 2, 3) stay in range
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
                     const float d = (__builtin_fmaf(xv, rsc, rsh) > 0.f) ? acc[r] : 0.f;
                     s1 += d;
                     s2 = __builtin_fmaf(d, (xv - rmu) * ris, s2);
+                    mx = fmaxf(mx, fabsf(d));                 // bound of the producing layer's dY for its f32x2 backward
                 }
             }
         }
@@ -194,6 +195,12 @@ __global__ __launch_bounds__(256) void narrow_bwd_kernel(const NarrowArgs a)
             a.red[(long long)blockIdx.x * CIN + tid] = t1;
             a.red[(nblk + blockIdx.x) * CIN + tid] = t2;
         }
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if (lane == 0) rs[wave] = mx;
+        __syncthreads();
+        if (tid == 0) a.red[2LL * a.nb * a.segs * CIN + blockIdx.x] = fmaxf(fmaxf(rs[0], rs[1]), fmaxf(rs[2], rs[3]));
     }
     if (does_dw) {
         float* out = a.part + (long long)blockIdx.x * COUT * CIN;
@@ -244,7 +251,8 @@ extern "C" int usip_mlp_narrow_backward_supported(int Cin, int Cout, int P)
 // act(X) = relu(X * xcoef[0] + xcoef[1]) (xcoef may be NULL: X is used as is).  X points at the first of the 64 input
 // rows inside a [nb][x_rows][P] tensor, dX likewise inside [nb][dx_rows][P]; all pointers 16-B aligned.
 // red_partial (may be NULL; needs xcoef = the producing layer's [4][64] forward coefficients): receives
-// [2][usip_mlp_narrow_backward_blocks(Cout, P, nb)][64] partial BatchNorm-backward sums of dX against X (see RED above).
+// [2][blocks][64] partial BatchNorm-backward sums of dX against X (see RED above) and behind them [blocks] maxima of
+// |dX [relu on]|, blocks = usip_mlp_narrow_backward_blocks(Cout, P, nb).
 extern "C" int usip_mlp_narrow_backward_blocks(int Cout, int P, int nb)
 {
     int seglen, segs;

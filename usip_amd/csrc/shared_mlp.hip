@@ -746,9 +746,19 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
     const float* __restrict__ partial, int rows, int C, double count, const float* __restrict__ coef_fwd,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, float* __restrict__ coef4)
+    float* __restrict__ dbeta, float* __restrict__ coef4, const float* __restrict__ max0, int n0,
+    const float* __restrict__ max1, int n1)
 {
     __shared__ double red[2][16][64];
+    __shared__ float rmax[2][16];
+    if (max0) {                                               // maxima of |dYhat| of the gradient's (up to two) parts
+        float m0 = 0.f, m1 = 0.f;
+        for (int i = threadIdx.x; i < n0; i += 1024) m0 = fmaxf(m0, max0[i]);
+        for (int i = threadIdx.x; i < n1; i += 1024) m1 = fmaxf(m1, max1[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, off)); m1 = fmaxf(m1, __shfl_xor(m1, off)); }
+        if ((threadIdx.x & 63) == 0) { rmax[0][threadIdx.x >> 6] = m0; rmax[1][threadIdx.x >> 6] = m1; }
+    }
     const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int ch = blockIdx.x * 64 + cl;
     const long long plane = (long long)rows * C;
@@ -776,6 +786,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
     red[0][grp][cl] = (a0 + a1) + (a2 + a3);
     red[1][grp][cl] = (b0 + b1) + (b2 + b3);
     __syncthreads();
+    float bound = 0.f;
     if (grp == 0 && ch < C) {
         double s1 = 0, s2 = 0;
 #pragma unroll
@@ -789,6 +800,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
         coef4[C + ch] = a0f;
         coef4[2 * C + ch] = -a1f * c2m * is;
         coef4[3 * C + ch] = a1f * (c2m * is * mu - c1m);
+        if (max0) {
+            float m0 = 0.f, m1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { m0 = fmaxf(m0, rmax[0][w]); m1 = fmaxf(m1, rmax[1][w]); }
+            bound = fabsf(a1f) * ((m0 + m1) + fabsf(c1m) + fabsf(c2m) * (float)sqrt(count));     // as bn_bwd_finalize_kernel
+        }
+    }
+    if (max0 && grp == 0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bound = fmaxf(bound, __shfl_down(bound, off));
+        if (cl == 0) coef4[4 * C + blockIdx.x] = bound;
     }
 }
 
@@ -1132,7 +1154,24 @@ extern "C" int usip_bn_backward_finalize_f32(const float* partial, int rows, int
 {
     if (!partial || rows < 1 || C < 1 || count < 1 || !coef_fwd || !mean || !invstd || !coef4) return USIP_EINVAL;
     USIP_LAUNCH(bn_bwd_finalize_rows_kernel, dim3(usip_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial,
-                rows, C, (double)count, coef_fwd, mean, invstd, dgamma, dbeta, coef4);
+                rows, C, (double)count, coef_fwd, mean, invstd, dgamma, dbeta, coef4, (const float*)nullptr, 0,
+                (const float*)nullptr, 0);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+// The same, also writing row 4 of coef4 ([5][C]): the gradient whose sums these are is the sum of up to two parts with
+// maxima max0[n0], max1[n1] (max1 may be NULL) of |dYhat|; |dYhat| <= max(max0) + max(max1).
+extern "C" int usip_bn_backward_finalize_max_f32(const float* partial, int rows, int C, long long count,
+                                                 const float* coef_fwd, const float* mean, const float* invstd,
+                                                 float* dgamma, float* dbeta, float* coef4, const float* max0, int n0,
+                                                 const float* max1, int n1, void* stream)
+{
+    if (!partial || rows < 1 || C < 1 || count < 1 || !coef_fwd || !mean || !invstd || !coef4 || !max0 || n0 < 1 ||
+        n1 < 0 || (n1 > 0 && !max1))
+        return USIP_EINVAL;
+    USIP_LAUNCH(bn_bwd_finalize_rows_kernel, dim3(usip_ceil_div(C, 64)), dim3(1024), 0, (hipStream_t)stream, partial,
+                rows, C, (double)count, coef_fwd, mean, invstd, dgamma, dbeta, coef4, max0, n0, max1, max1 ? n1 : 0);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

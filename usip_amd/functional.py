@@ -525,11 +525,17 @@ class _SharedMLPLayer(torch.autograd.Function):
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
         x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
-        if (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
-                and ops.narrow_backward_supported(x.shape[1], w2.shape[0], x.shape[2], (dz, y, x))):
+        x2 = (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
+              and ops.layer_backward_x2_supported(x.shape[1], w2.shape[0], x.shape[2], (dz, y, x), coef4, xcoef))
+        if x2 or (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
+                  and ops.narrow_backward_supported(x.shape[1], w2.shape[0], x.shape[2], (dz, y, x))):
             red = FUSED_NARROW_RED and xcoef is not None and xcoef.shape[0] >= 4   # input = lazy activation of a train-mode BN layer
-            res = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
-                                          dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
+            if x2:                                           # f32x2 with the operand bounds at hand: csrc/layer_bwd_x2.hip
+                res = ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2.contiguous(), Cin=x.shape[1],
+                                                dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
+            else:
+                res = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
+                                              dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
             dx, dw = res[0], res[1]
             if red:
                 _register_pre_bn_sums(dx, [res[2]])
@@ -593,6 +599,15 @@ class _SharedMLPLayerMax(torch.autograd.Function):
                                                            dbeta_out=sink[3] if sink else None, yarg=yarg)
         pool = (dpooled, arg, K)
         dx = dw = None
+        if (FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[3]
+                and ops.layer_backward_x2_supported(Cin, Cout, M * K, (y, x3), coef4, xcoef, pooled=True)):
+            # f32x2: data and weight gradient from ONE pass over (Y, X) -- csrc/layer_bwd_x2.hip
+            dx, dw = ops.mlp_layer_backward_x2(None, y, coef4, x3, xcoef, w2.contiguous(), Cin=Cin, pool=pool,
+                                               dw_out=sink[0].view(w2.shape) if sink else None)
+            db = torch.zeros_like(gamma) if (ctx.needs_input_grad[4] and not sink) else None
+            if sink:
+                dw = db = dgamma = dbeta = None
+            return (dx.view(ctx.x_shape), None, None, dw, db, dgamma, dbeta) + (None,) * 5
         if ctx.needs_input_grad[0]:
             dx = _dgrad(x3, w2.contiguous(), None, pro=3, X2=y, coef=coef4, pool=pool)
             dx = dx.view(ctx.x_shape)

@@ -706,6 +706,17 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     return dW
 
 
+class RedSums:
+    """What a fused layer backward leaves for the layer that produced its input: `sums` [2, blocks, C] partial
+    BatchNorm-backward sums and `maxima` [blocks] of |dX [relu on]| -- views of one flat buffer."""
+
+    def __init__(self, flat: torch.Tensor, C: int):
+        blocks = flat.numel() // (2 * C + 1)
+        self.flat = flat
+        self.sums = flat[:2 * blocks * C].view(2, blocks, C)
+        self.maxima = flat[2 * blocks * C:]
+
+
 def narrow_backward_supported(Cin: int, Cout: int, P: int, tensors=()) -> bool:
     """True when usip_mlp_narrow_backward_f32 takes this layer.  `tensors`: the (dZ, Y, X) the call would pass --
     the kernel needs them 16-byte aligned (an offset view handed over by autograd is not) and addresses elements
@@ -725,8 +736,9 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
     """Fused backward of a narrow layer (csrc/narrow_bwd.hip): -> (dx [nb,Cin,P], dW[, red]).
     dz, y [nb,Cout,P]; x [nb,Cin,P]; w2 [Cout, Ctot] contiguous, the layer's inputs are its columns [wcol, wcol+Cin);
     dw_out ([Cout, Ctot] contiguous) receives the weight gradient in the same columns.
-    want_red (xcoef = the producing layer's [4,Cin] forward coefficients): also returns red [2, blocks, Cin], partial
-    BatchNorm-backward sums of the producing layer against dx (see bn_backward_from_partials)."""
+    want_red (xcoef = the producing layer's [4,Cin] forward coefficients): also returns a RedSums: partial
+    BatchNorm-backward sums [2, blocks, Cin] of the producing layer against dx and the workgroups' maxima of
+    |dx [relu on]| (see bn_backward_from_partials)."""
     nb, Cout, P = dz.shape
     dev = dz.device
     for t, n in ((dz, "dz"), (y, "y"), (x, "x"), (w2, "w2"), (coef4, "coef4")):
@@ -739,7 +751,8 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
     if want_red:
         if xcoef is None or xcoef.shape[0] < 4:
             raise RuntimeError("mlp_narrow_backward: want_red needs the producing layer's [4, Cin] coefficients")
-        red = torch.empty((2, int(_lib.lib().usip_mlp_narrow_backward_blocks(Cout, P, nb)), Cin), dtype=torch.float32, device=dev)
+        blocks = int(_lib.lib().usip_mlp_narrow_backward_blocks(Cout, P, nb))
+        red = torch.empty(2 * blocks * Cin + blocks, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("shared_mlp_narrow_bwd %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * (2 * Cout + 2 * Cin), 4.0 * Cout * Cin * nb * P,
                                              rocprof_key="narrow_bwd_kernel<%d, %s, %s> |wg=%d" % (
@@ -750,36 +763,114 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
             ctypes.c_void_p(w2.data_ptr() + 4 * int(wcol)), int(ldw), _ptr(dx), Cin, _ptr(ws),
             ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)), int(dW.shape[1]), _opt(red), Cin, Cout, P, nb, _stream(dz)),
             "usip_mlp_narrow_backward_f32")
-    return (dx, dW, red) if want_red else (dx, dW)
+    return (dx, dW, RedSums(red, Cin)) if want_red else (dx, dW)
+
+
+def layer_backward_x2_supported(Cin: int, Cout: int, P: int, tensors=(), coef4=None, xcoef=None, pooled: bool = False) -> bool:
+    """True when usip_mlp_layer_backward_x2h_f32 takes this layer: f32x2 mode, a supported shape, the bounds the two
+    fp16 planes need (coef4 with its fifth row, the producing layer's four-row coefficients), aligned contiguous tensors."""
+    if _matmul_mode != "f32x2" or not LAYER_BWD_X2:
+        return False
+    if coef4 is None or coef4.shape[0] < 5 or xcoef is None or xcoef.shape[0] < 4:
+        return False
+    if not _lib.lib().usip_mlp_layer_backward_x2h_supported(int(Cin), int(Cout), int(P), 1 if pooled else 0):
+        return False
+    for t in tensors:
+        if t is None:
+            continue
+        if t.data_ptr() % 16 != 0 or t.numel() >= 2 ** 32 or not t.is_contiguous():
+            return False
+    return True
+
+
+# f32x2 mode: the fused layer backward on the 16-bit matrix cores; USIP_LAYER_BWD_X2=0 for A/B runs
+LAYER_BWD_X2 = _os.environ.get("USIP_LAYER_BWD_X2", "1") not in ("0", "off")
+
+
+def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64, want_red: bool = False,
+                          pool=None):
+    """Fused backward of a <= 128-wide layer with f32x2 products (csrc/layer_bwd_x2.hip): -> (dx [nb,Cin,P], dW[, red]).
+    Arguments as mlp_narrow_backward; coef4 [5,Cout] (with bounds), xcoef [4,Cin]; pool = (dpooled [nb,Cout,G],
+    arg i32 [nb,Cout,G], group) with dz None for the pooled form.  red: a RedSums (partial sums [2, blocks, Cin] and the
+    workgroups' maxima of |dx [relu on]|)."""
+    nb, Cout, P = y.shape
+    dev = y.device
+    for t, n in ((y, "y"), (x, "x"), (w2, "w2"), (coef4, "coef4"), (xcoef, "xcoef")):
+        _need(t, n, torch.float32)
+    ldw = w2.shape[1]
+    dW = dw_out if dw_out is not None else torch.empty_like(w2)
+    dx = torch.empty((nb, Cin, P), dtype=torch.float32, device=dev)
+    lib = _lib.lib()
+    blocks = int(lib.usip_mlp_layer_backward_x2h_blocks(Cin, Cout, P, nb))
+    ws = torch.empty(int(lib.usip_mlp_layer_backward_x2h_workspace(Cin, Cout, P, nb)), dtype=torch.float32, device=dev)
+    red = torch.empty(2 * blocks * Cin + blocks, dtype=torch.float32, device=dev) if want_red else None
+    planes = weight_planes(w2, wcol, Cin, Cout, 2)             # W as the data-gradient operand: K-major [Cout][ldw]
+    pdp = parg = None
+    group = 0
+    if pool is not None:
+        pdp, parg, group = pool
+        _need(pdp, "dpooled", torch.float32)
+        _need(parg, "arg", torch.int32)
+    else:
+        _need(dz, "dz", torch.float32)
+    with torch.cuda.device(dev), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
+                                             4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin),
+                                             4.0 * Cout * Cin * nb * P,
+                                             rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d> |wg=%d" % (
+                                                 Cin, Cout, "true" if pool is not None else "false",
+                                                 "true" if want_red else "false", 8 if Cin == 128 else 4, blocks)):
+        _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
+            _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
+            ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
+            int(dW.shape[1]), _opt(red), Cin, Cout, P, nb, _stream(y)), "usip_mlp_layer_backward_x2h_f32")
+    return (dx, dW, RedSums(red, Cin)) if want_red else (dx, dW)
 
 
 def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bool, yarg=None):
     """Partial BatchNorm-backward sums [2, nb, C] of a gradient that is dpooled at the arg-max positions and zero
-    elsewhere (the sparse half of a layer output that feeds a max-pool AND another layer)."""
+    elsewhere (the sparse half of a layer output that feeds a max-pool AND another layer).  In f32x2 mode a RedSums
+    whose maxima [nb * C] are those of |dpooled [relu on]| per cloud and channel."""
     nb, C, M, K = Y4.shape
-    partial = torch.empty((2, nb, C), dtype=torch.float32, device=Y4.device)
+    want_max = _matmul_mode == "f32x2"
+    partial = torch.empty((3 if want_max else 2) * nb * C, dtype=torch.float32, device=Y4.device)
     with torch.cuda.device(Y4.device), prof.kernel("bn_backward_reduce_pooled", 4.0 * nb * C * M * 3):
         _lib.check(_lib.lib().usip_bn_pool_backward_reduce_f32(_ptr(dpooled), _ptr(arg), _ptr(Y4), _opt(yarg),
                                                                _ptr(coef_fwd), _ptr(mean), _ptr(invstd), None,
                                                                int(bool(relu)), _ptr(partial), None, None, None, nb, C,
-                                                               M, K, 0, _stream(Y4)), "usip_bn_pool_backward_reduce_f32")
-    return partial
+                                                               M, K, 1 if want_max else 0, _stream(Y4)),
+                   "usip_bn_pool_backward_reduce_f32")
+    if want_max:
+        r = RedSums.__new__(RedSums)
+        r.flat, r.sums, r.maxima = partial, partial[:2 * nb * C].view(2, nb, C), partial[2 * nb * C:]
+        return r
+    return partial.view(2, nb, C)
 
 
 def bn_backward_from_partials(partials, count: int, coef_fwd, mean, invstd, dgamma_out=None, dbeta_out=None):
-    """(dgamma, dbeta, coef4) from partial sums [2, rows, C] (one tensor or a list of them: all are summed)."""
-    if isinstance(partials, (list, tuple)):
-        partials = torch.cat(list(partials), dim=1).contiguous() if len(partials) > 1 else partials[0]
-    _, rows, C = partials.shape
-    dev = partials.device
+    """(dgamma, dbeta, coef4) from partial sums [2, rows, C] (one tensor / RedSums or a list of them: all are summed).
+    When every part is a RedSums (at most two) coef4 gets its fifth row, the bound of |dY| the f32x2 kernels need:
+    |dYhat| <= the sum of the parts' maxima."""
+    parts = list(partials) if isinstance(partials, (list, tuple)) else [partials]
+    maxima = [p.maxima for p in parts] if all(isinstance(p, RedSums) for p in parts) and len(parts) <= 2 else None
+    sums = [p.sums if isinstance(p, RedSums) else p for p in parts]
+    sums = torch.cat(sums, dim=1).contiguous() if len(sums) > 1 else sums[0]
+    _, rows, C = sums.shape
+    dev = sums.device
     dgamma = dgamma_out if dgamma_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
     dbeta = dbeta_out if dbeta_out is not None else torch.empty(C, dtype=torch.float32, device=dev)
-    coef4 = torch.empty((4, C), dtype=torch.float32, device=dev)
+    coef4 = torch.empty((5 if maxima else 4, C), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), prof.kernel("bn_backward_finalize", 8.0 * rows * C):
-        _lib.check(_lib.lib().usip_bn_backward_finalize_f32(_ptr(partials), int(rows), int(C), int(count), _ptr(coef_fwd),
-                                                            _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta),
-                                                            _ptr(coef4), _stream(partials)),
-                   "usip_bn_backward_finalize_f32")
+        if maxima:
+            m1 = maxima[1] if len(maxima) > 1 else None
+            _lib.check(_lib.lib().usip_bn_backward_finalize_max_f32(
+                _ptr(sums), int(rows), int(C), int(count), _ptr(coef_fwd), _ptr(mean), _ptr(invstd), _ptr(dgamma),
+                _ptr(dbeta), _ptr(coef4), _ptr(maxima[0]), int(maxima[0].numel()), _opt(m1),
+                0 if m1 is None else int(m1.numel()), _stream(sums)), "usip_bn_backward_finalize_max_f32")
+        else:
+            _lib.check(_lib.lib().usip_bn_backward_finalize_f32(_ptr(sums), int(rows), int(C), int(count), _ptr(coef_fwd),
+                                                                _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta),
+                                                                _ptr(coef4), _stream(sums)),
+                       "usip_bn_backward_finalize_f32")
     return dgamma, dbeta, coef4
 
 
