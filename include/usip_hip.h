@@ -291,13 +291,15 @@ int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const float* X2, c
                           const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
                           const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
                           int M, int K, int P, int nb, void* stream);
-/* The same for the 128-wide layers (M <= 128, K <= 128, no row bias) with the weight fragments resident in registers
- * and persistent workgroups over 64-position tiles: a CU moves the streamed operand in and the output out, not the
- * weight planes again for every tile.  stats: [2][M][usip_mlp_gemm_x2r_tiles(P, nb)]. */
+/* The same for the 128-wide layers (M <= 128, K <= 128; a row bias only with pro 1 and rb_group a multiple of 32) with
+ * the weight fragments resident in registers and persistent workgroups over 64-position tiles: a CU moves the streamed
+ * operand in and the output out, not the weight planes again for every tile.
+ * stats: [2][M][usip_mlp_gemm_x2r_tiles(P, nb)]. */
 int usip_mlp_gemm_x2r_tiles(int P, int nb);
 int usip_mlp_gemm_x2r_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
-                          const float* bias, const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                          float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream);
+                          const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
+                          const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats, int M, int K,
+                          int P, int nb, void* stream);
 
 /* K-major copies of many weight matrices in one launch: for every t < ntensors, table[5t..5t+4] =
  * (source offset, rows, cols, destination offset, index of its first 32 x 32 tile), offsets in floats into src / dst;

@@ -80,6 +80,44 @@ def test_gemm_forward_f32x2_is_fp32_accurate(shape, scale, heavy, x2_forced):
     assert _rel(s[1], (Y.double() ** 2).sum((0, 2))) < 1e-5
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 128, 2048, 64, False), (1, 64, 128, 1088, 32, False), (3, 128, 128, 640, 64, False),
+                                 (2, 128, 128, 4096, 64, True)])
+def test_register_resident_gemm_with_row_bias(cfg):
+    """gemm_x2r_kernel with a per-neighbourhood row bias (a pooled-concat layer's feature half): values against fp64,
+    statistics against the output, ragged last tile (1088 = 17 x 64); the 64-input launches reach it only with the
+    split kernels forced (the streaming fp32 kernel keeps them otherwise)."""
+    from usip_amd import _lib, ops
+    nb, K, M, P, G, natural = cfg
+    g = torch.Generator().manual_seed(K + M + P + G)
+    prev = ops.set_matmul_mode("f32x2")
+    prev_narrow = ops.NARROW_FWD
+    if not natural:
+        _lib.lib().usip_set_tuning(b"gemm_split3", 2)
+        ops.NARROW_FWD = False
+    try:
+        At = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+        X = (torch.randn(nb, K, P, generator=g) * 3.0 + 1.0).to(DEV)
+        gamma, beta = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV), (0.3 * torch.randn(K, generator=g)).to(DEV)
+        bias = (0.1 * torch.randn(M, generator=g)).to(DEV)
+        rb = torch.randn(nb, M, P // G, generator=g).to(DEV)
+        coef = _bn_coef(X, gamma, beta)
+        xin = torch.relu(_fma(X, coef[0].view(1, K, 1), coef[1].view(1, K, 1)))
+        Y, stats = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef, rowbias=rb, rb_group=G)
+        want = (torch.matmul(At.double().t().unsqueeze(0), xin.double()) + bias.double().view(1, M, 1)
+                + rb.double().repeat_interleave(G, dim=2))
+        assert _rel(Y, want) < 2e-6, _rel(Y, want)
+        s = stats.double().sum(-1)
+        assert _rel(s[0], Y.double().sum((0, 2))) < 1e-5 and _rel(s[1], (Y.double() ** 2).sum((0, 2))) < 1e-5
+        if not natural:                                     # it really was the register-resident kernel
+            assert stats.shape[2] == _lib.lib().usip_mlp_gemm_x2r_tiles(P, nb)
+        Y2, _ = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef, rowbias=rb, rb_group=G)
+        assert torch.equal(Y, Y2)
+    finally:
+        _lib.lib().usip_set_tuning(b"gemm_split3", 0)
+        ops.NARROW_FWD = prev_narrow
+        ops.set_matmul_mode(prev)
+
+
 @pytest.mark.parametrize("shape", [s for s in SHAPES if s[1] <= 512])
 @pytest.mark.parametrize("gscale", [1.0, 1e-12, 1e-6, 1e4])
 def test_gemm_backward_f32x2_is_fp32_accurate(shape, gscale, x2_forced):

@@ -45,6 +45,9 @@ for Cin, Cout in ((64, 64), (64, 128)):
     w2 = torch.randn(Cout, Cin, device=dev) * (2.0 / Cin) ** 0.5
     coef4 = ops.bn_backward_reduce(dz, y, cy, my, iy, gy, True)[2]
     t_old = timed(lambda: ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, want_red=True))
+    if not ops.layer_backward_x2_supported(Cin, Cout, P, (dz, y, x), coef4, xcoef):
+        print("%3d -> %3d: narrow_bwd (fp32 MFMA) %7.1f us | layer_bwd_x2 does not take this shape" % (Cin, Cout, t_old), flush=True)
+        continue
     t_new = timed(lambda: ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, Cin=Cin, want_red=True))
     gb = 4.0 * nb * P * (2 * Cout + 2 * Cin) / 1e9
     print("%3d -> %3d: narrow_bwd (fp32 MFMA) %7.1f us %5.2f TB/s | layer_bwd_x2 %7.1f us %5.2f TB/s" % (

@@ -70,8 +70,8 @@ SIGNATURES = {
     "usip_mlp_gemm_x3p_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_x2r_tiles": ([_int, _int], _int),
-    "usip_mlp_gemm_x2r_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _i32p, _int, _f32p, _int, _f32p,
-                               _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_gemm_x2r_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int, _f32p,
+                               _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_split2h_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
     "usip_mlp_gemm_x2h_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),

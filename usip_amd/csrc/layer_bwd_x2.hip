@@ -46,11 +46,13 @@ struct LayerBwdArgs {
 template <int BP>
 __device__ __forceinline__ int rows_off(int row, int pos) { return row * (BP * 2 + 16) + pos * 2; }
 
-template <int CIN, int COUT, bool POOL, bool RED, int NW, int WPE = 2>
-__global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerBwdArgs a)
+// DB: two LDS buffers and ONE barrier per tile -- the next tile is written while this one is multiplied (gemm_x2r_kernel's
+// pipeline); without it a tile is written, a barrier, multiplied, a barrier (the forms that also keep fp32 images of X
+// and dX for the producing layer's sums have no room for a second buffer).
+template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB>
+__global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwdArgs a)
 {
     constexpr int NT = 64 * NW;
-    constexpr int BP = (NW == 8) ? 64 : 32;                    // positions per tile
     constexpr int GC = COUT * BP / NT;                         // output channels per (dZ, Y) loader thread: 8 or 16
     constexpr bool EARLY = (GC == 8);                          // next tile's loads re-issued inside write_tile (16: register pressure)
     constexpr int NCI = CIN / 32, NCO = COUT / 32, NPT = BP / 32;
@@ -61,16 +63,15 @@ __global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerB
     constexpr int RB1 = COUT * 2 + 16, PL1 = BP * RB1;         // G1 [plane][position][COUT (+ 16 B)]
     constexpr int RS2 = BP * 2 + 16;                           // G2 [plane][co][BP (+ 16 B)], X2 [plane][ci][BP (+ 16 B)]
     constexpr int PL2 = COUT * RS2, PLX = CIN * RS2;
-    static_assert(NDX <= NW && (NCO * NCI) % NW == 0 && (GC == 8 || GC == 16) && CIN % XRP == 0 && (!RED || NPX == 1), "tile roles");
+    constexpr int BUF = 2 * PL1 + 2 * PL2 + 2 * PLX;           // one buffer: both planes of the three images
+    static_assert(NDX <= NW && (NCO * NCI) % NW == 0 && (GC == 8 || GC == 16) && CIN % XRP == 0 && (!RED || NPX == 1) &&
+                  !(RED && DB), "tile roles");
     constexpr int XRS = BP + 4;                                // floats per row of the fp32 images (16 B of padding, as above)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PL1 + 2 * PL2 + 2 * PLX + (RED ? 2 * CIN * XRS * 4 : 16)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * BUF + (RED ? 2 * CIN * XRS * 4 : 16)];
     __shared__ float cfG[4][COUT];
     __shared__ float cfX[2][CIN];
     __shared__ float redm[2][NW];
-    unsigned char* G1 = smem;
-    unsigned char* G2 = smem + 2 * PL1;
-    unsigned char* X2 = G2 + 2 * PL2;
-    float* XR = reinterpret_cast<float*>(X2 + 2 * PLX);        // RED: [CIN][BP] raw X
+    float* XR = reinterpret_cast<float*>(smem + (DB ? 2 : 1) * BUF);   // RED: [CIN][BP] raw X
     float* DX = XR + (RED ? CIN * XRS : 0);                    // RED: [CIN][BP] this tile of dX
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerB
     // One tile from the prefetched registers into LDS.  The loads of the NEXT tile (the last tile: a harmless repeat) are re-issued as soon as
     // a register group has been consumed -- in front of the splits and the LDS writes, not behind them: with the loads
     // issued after this phase a tile cost a full memory latency on top of it (4.3 us per 32-position tile).
-    auto write_tile = [&](int nxt) {
+    auto write_tile = [&](int buf, int nxt) {
+        unsigned char* G1 = smem + buf * BUF;
+        unsigned char* G2 = G1 + 2 * PL1;
+        unsigned char* X2 = G2 + 2 * PL2;
         // act(X) first: its temporaries are dead before the 2 GC values of dY come to life
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
@@ -252,15 +256,12 @@ __global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerB
         for (int i = 0; i < 8; ++i) { XR[xr0 * XRS + xq * 8 + i] = 0.f; DX[xr0 * XRS + xq * 8 + i] = 0.f; }
     }
     __syncthreads();                                           // coefficients are in LDS
-    for (int t = 0; t < ntile; ++t) {
-        if (RED) red_pass();                                   // the previous tile (the first time: the zeros written above)
-        write_tile(min(t + 1, ntile - 1));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // (raw: the loads stay in flight across it)
+    // the two products of one tile from LDS buffer `buf`; returns the tile of dX in acc
+    auto multiply = [&](int buf, f32x16& acc) {
+        const unsigned char* G1 = smem + buf * BUF;
+        const unsigned char* G2 = G1 + 2 * PL1;
+        const unsigned char* X2 = G2 + 2 * PL2;
         if (does_dx) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int pos = dx_pt * 32 + c;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -271,16 +272,6 @@ __global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerB
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][1]), b0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][0]), b0, acc, 0, 0, 0);
                 if (KS == 8 && (s & 1)) __builtin_amdgcn_sched_barrier(0);     // keeps hipcc from hoisting all 16 fragment reads (spills)
-            }
-            // lane = position pos of the tile; register r = input channel 32 dx_ci + 8 (r >> 2) + 4 kh + (r & 3): a store
-            // instruction writes 32 consecutive positions of two rows
-            float* orow = dXb + pbeg + (long long)t * BP + pos;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ci = dx_ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                const float v = acc[r] * dx_scale;
-                orow[(long long)ci * a.P] = v;
-                if (RED) DX[ci * XRS + pos] = v;
             }
         }
         // dW[co][ci] += sum_p dY[co][p] act(X)[ci][p]
@@ -300,8 +291,51 @@ __global__ __launch_bounds__(64 * NW, WPE) void layer_bwd_x2_kernel(const LayerB
                 acc_dw[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc_dw[u], 0, 0, 0);
             }
         }
+    };
+    // lane = position pos of the tile; register r = input channel 32 dx_ci + 8 (r >> 2) + 4 kh + (r & 3): a store
+    // instruction writes 32 consecutive positions of two rows
+    auto store_dx = [&](int t, const f32x16& acc) {
+        if (!does_dx) return;
+        const int pos = dx_pt * 32 + c;
+        float* orow = dXb + pbeg + (long long)t * BP + pos;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = dx_ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const float v = acc[r] * dx_scale;
+            orow[(long long)ci * a.P] = v;
+            if (RED) DX[ci * XRS + pos] = v;
+        }
+    };
+    if (DB) {
+        if (ntile > 0) write_tile(0, min(1, ntile - 1));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                          // everyone is done reading this tile's LDS
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int t = 0; t < ntile; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            multiply(cur, acc);
+            if (t + 1 < ntile) write_tile(cur ^ 1, min(t + 2, ntile - 1));   // the next tile, while the MFMAs drain
+            store_dx(t, acc);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // (raw: the loads stay in flight across it)
+            cur ^= 1;
+        }
+    } else {
+        for (int t = 0; t < ntile; ++t) {
+            if (RED) red_pass();                               // the previous tile (the first time: the zeros written above)
+            write_tile(0, min(t + 1, ntile - 1));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // (raw: the loads stay in flight across it)
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            multiply(0, acc);
+            store_dx(t, acc);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // everyone is done reading this tile's LDS
+        }
     }
     {
         float* out = a.part + (long long)blockIdx.x * COUT * CIN;
@@ -417,11 +451,13 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
     dim3 grid((unsigned)(nb * segs));
     const bool red = red_partial != nullptr;
     if (Cin == 64) {
-        if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4>), grid, dim3(256), 0, st, a);
-        else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4>), grid, dim3(256), 0, st, a);
+        if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
+        else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4, 32, false>), grid, dim3(256), 0, st, a);
     } else {
         if (red) return USIP_EINVAL;
-        USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8>), grid, dim3(512), 0, st, a);
+        // (the single-buffer form with 64-position tiles measured the same, 224-230 us at 16 x 32768 positions, and
+        // sits on the edge of spilling: 252-256 VGPRs)
+        USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true>), grid, dim3(512), 0, st, a);
     }
     USIP_LAUNCH_CHECK();
     return usip_mlp::launch_wgrad_reduce(workspace, dW, (long long)Cout * Cin, nb * segs, Cin, lddw, 0, st);

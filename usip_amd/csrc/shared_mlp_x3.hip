@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   the loads, was what the CU was short of).  BatchNorm statistics are per-lane running sums over all the
 //   workgroup's tiles, reduced over the 32 positions of a half-wave once at the end: one partial per channel and
 //   WORKGROUP, no LDS, no barrier in the epilogue.
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool RB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x2r_kernel(const GemmArgs a, const uint4* __restrict__ planes)
 {
     constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
@@ -670,6 +670,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(16))) unsigned char Bs[2][2][PLB];   // [buffer][plane]
     __shared__ float cf[NCOEF][128];
     __shared__ float redm[4];
+    // RB: the tile's row bias (rowbias[b][channel][position / rb_group], rb_group a multiple of 32: one value per channel
+    // and 32-position half of the tile), fetched with the tile's first slab, double-buffered by the tile's parity
+    __shared__ float rbs[RB ? 2 : 1][RB ? 128 : 1][2];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -732,9 +735,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // raw operands of one slab step: TWO register sets, so that the loads of step q+3 are issued while step q is
     // multiplied (with one set -- 4 KiB in flight per wave, 32 KiB per CU at two 4-wave workgroups -- the kernel ran at
     // the 8 B/clk per CU that 32 KiB cover at ~2 us of loaded latency: 144 us for conv5's forward)
-    struct Raw { float x[16]; float y[TWO ? 16 : 1]; int arg[POOL ? 16 : 1]; int xkin; };
+    struct Raw { float x[16]; float y[TWO ? 16 : 1]; int arg[POOL ? 16 : 1]; int xkin; float rb; };
+    const int ngrp = RB ? a.P / a.rb_group : 0;
     auto load_slab = [&](int tile, int sl, Raw& r) {
         const int b = tile / tpc, p0 = (tile - b * tpc) * BN;
+        if (RB && sl == 0) {                                   // thread -> (channel tid >> 1, half tid & 1)
+            const int ch = min(tid >> 1, a.M - 1), pp = min(p0 + (tid & 1) * 32, a.P - 1);
+            r.rb = a.rowbias[((long long)b * a.M + ch) * ngrp + pp / a.rb_group];
+        }
         const unsigned xpc = (unsigned)min(p0 + xp, a.P - 1);
         const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
             (void*)((POOL ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
@@ -760,7 +768,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (TWO) r.y[TWO ? i : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX2, xoff, kc * a.P * 4, 0));
         }
     };
-    auto store_slab = [&](int buf, int sl, const Raw& r) {
+    auto store_slab = [&](int buf, int sl, const Raw& r, int par) {
+        if (RB && sl == 0) rbs[RB ? par : 0][RB ? tid >> 1 : 0][tid & 1] = r.rb;
         const int kb = sl * SLAB + xkg * 16;
         float v[16];
 #pragma unroll
@@ -804,7 +813,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_slab(tile_of(0), slab_of(0), rA);
     if (DIST == 2 && nsteps > 1) load_slab(tile_of(1), slab_of(1), rB);
     __syncthreads();                                           // cf visible
-    store_slab(0, slab_of(0), rA);
+    store_slab(0, slab_of(0), rA, 0);
     if (nsteps > DIST) load_slab(tile_of(DIST), slab_of(DIST), rA);
     __syncthreads();
     int cur = 0;
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if (q + 1 < nsteps) {
-            store_slab(cur ^ 1, slab_of(q + 1), nxt);
+            store_slab(cur ^ 1, slab_of(q + 1), nxt, ((q + 1) / nslab) & 1);
             if (q + 1 + DIST < nsteps) load_slab(tile_of(q + 1 + DIST), slab_of(q + 1 + DIST), nxt);
         }
         if (sl == nslab - 1) {
@@ -853,7 +862,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ch = wave * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    const float v = __builtin_fmaf(acc[j][r], out_scale, bsh[ch]);
+                    float v = __builtin_fmaf(acc[j][r], out_scale, bsh[ch]);
+                    if (RB) v += rbs[RB ? (q / nslab) & 1 : 0][RB ? ch : 0][j];
                     if (pok && ch < a.M) {
                         yb[(long long)ch * a.P + pp] = v;
                         if (EPI == EPI_STATS) { s1[EPI == EPI_STATS ? r : 0] += v; s2[EPI == EPI_STATS ? r : 0] = __builtin_fmaf(v, v, s2[EPI == EPI_STATS ? r : 0]); }
@@ -1052,8 +1062,8 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
     return launch_x3p<4, 2, 2>(a, pl, pro, st);
 }
 
-// f32x2 for the 128-wide layers with register-resident weight fragments (gemm_x2r_kernel): M <= 128, K <= 128, no row
-// bias; `planes` = the usip_mlp_split2h_f32 image; stats: [2][M][usip_mlp_gemm_x2r_tiles(P, nb)] (one partial per workgroup).
+// f32x2 for the 128-wide layers with register-resident weight fragments (gemm_x2r_kernel): M <= 128, K <= 128, a row
+// bias only with pro 1 and rb_group a multiple of 32; `planes` = the usip_mlp_split2h_f32 image; stats: [2][M][usip_mlp_gemm_x2r_tiles(P, nb)] (one partial per workgroup).
 // Otherwise the contract of usip_mlp_gemm_x2h_f32.
 extern "C" int usip_mlp_gemm_x2r_tiles(int P, int nb)
 {
@@ -1062,9 +1072,11 @@ extern "C" int usip_mlp_gemm_x2r_tiles(int P, int nb)
 }
 
 extern "C" int usip_mlp_gemm_x2r_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
-                                     const float* bias, const float* pool_dp, const int32_t* pool_arg, int pool_group,
-                                     float* Y, int y_rows, float* stats, int M, int K, int P, int nb, void* stream)
+                                     const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
+                                     const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats, int M,
+                                     int K, int P, int nb, void* stream)
 {
+    if (rowbias && (pro != PRO_AFFINE_RELU || rb_group < 32 || rb_group % 32 != 0 || P % rb_group != 0)) return USIP_EINVAL;
     if (M < 1 || M > 128 || K < 1 || K > 128 || P < 0 || nb < 0) return USIP_EINVAL;
     if (pro != PRO_AFFINE_RELU && pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) return USIP_EINVAL;
     if ((long long)P * nb == 0) return USIP_OK;
@@ -1075,13 +1087,16 @@ extern "C" int usip_mlp_gemm_x2r_f32(const void* planes, const float* X, const f
     if ((long long)K * P >= (1LL << 30)) return USIP_EINVAL;
     if (y_rows == 0) y_rows = M;
     if (y_rows < M) return USIP_EINVAL;
-    GemmArgs a{nullptr, 0, X, X2, coef, bias, Y, stats, M, K, P, nb, nullptr, 1, pool_dp, pool_arg, pool_group,
-               0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
+    GemmArgs a{nullptr, 0, X, X2, coef, bias, Y, stats, M, K, P, nb, rowbias, rowbias ? rb_group : 1, pool_dp, pool_arg,
+               pool_group, 0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
     const long long total = (long long)nb * ((P + 63) / 64);
     const unsigned grid = (unsigned)(total < 512 ? total : 512);             // two workgroups per CU, persistent
     hipStream_t st = (hipStream_t)stream;
     const uint4* pl = reinterpret_cast<const uint4*>(planes);
-    if (pro == PRO_AFFINE_RELU) {
+    if (pro == PRO_AFFINE_RELU && rowbias) {
+        if (stats) USIP_LAUNCH((gemm_x2r_kernel<PRO_AFFINE_RELU, EPI_STATS, true>), dim3(grid), dim3(256), 0, st, a, pl);
+        else USIP_LAUNCH((gemm_x2r_kernel<PRO_AFFINE_RELU, EPI_NONE, true>), dim3(grid), dim3(256), 0, st, a, pl);
+    } else if (pro == PRO_AFFINE_RELU) {
         if (stats) USIP_LAUNCH((gemm_x2r_kernel<PRO_AFFINE_RELU, EPI_STATS>), dim3(grid), dim3(256), 0, st, a, pl);
         else USIP_LAUNCH((gemm_x2r_kernel<PRO_AFFINE_RELU, EPI_NONE>), dim3(grid), dim3(256), 0, st, a, pl);
     } else if (pro == PRO_BN_BWD) {

@@ -498,6 +498,10 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         y_ptr = ctypes.c_void_p(out.data_ptr() + 4 * int(out_row_offset) * P)
     a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
     # narrow layers (64 inputs, 64 / 128 outputs) at many positions: the streaming kernel (csrc/narrow_fwd.hip)
+    # (f32x2 mode, measured r03: sending the 64 -> 128 layer -- the feature half of conv4, with its row bias -- to the
+    # register-resident f32x2 kernel instead of the streaming fp32 kernel changes nothing inside the step, 5.32-5.35 ms
+    # both ways, although it is 79-107 vs 82 us stand-alone depending on the box; the streaming kernel keeps it)
+    rb_ok = rowbias is None or (rb_group % 32 == 0 and P % rb_group == 0)
     nf_blocks = 0
     if (NARROW_FWD and _matmul_mode != "bf16" and not a_trans and pool is None and X2 is None and pro in (0, 1)
             and K == 64 and M in (64, 128) and X.data_ptr() % 16 == 0
@@ -524,7 +528,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     x2h = (x3p and _matmul_mode == "f32x2" and coef is not None and
            ((pro == 1 and coef.shape[0] >= 4) or (pro >= 2 and coef.shape[0] >= 5)))
     # 128-wide layers: weight fragments resident in registers, persistent workgroups (usip_mlp_gemm_x2r_f32)
-    x2r = x2h and M <= 128 and K <= 128 and rowbias is None and X2R
+    x2r = x2h and M <= 128 and K <= 128 and X2R and (rowbias is None or (pro == 1 and rb_ok and rb_group >= 32))
     stats = None
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_x2r_tiles(P, nb) if x2r else _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
@@ -540,7 +544,8 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
             bm = _lib.lib().usip_mlp_x3p_tile_rows(M)
             bn = _lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), e)
             if x2r:
-                return "gemm_x2r_kernel<%d, %d> |wg=%d" % (pro, e, min(512, nb * ((P + 63) // 64)))
+                return "gemm_x2r_kernel<%d, %d, %s> |wg=%d" % (pro, e, "true" if rowbias is not None else "false",
+                                                               min(512, nb * ((P + 63) // 64)))
             if x2h:
                 bn = 128
             return "gemm_x3p_kernel<%d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3,
@@ -569,9 +574,10 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                   2.0 * M * K * nb * P, rocprof_key=_key, moved=moved):
         if x2r:
             _lib.check(_lib.lib().usip_mlp_gemm_x2r_f32(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
-                                                        _opt(coef), int(pro), _opt(bias), _opt(pool_dp), _opt(pool_arg),
-                                                        int(pool_group), y_ptr, int(y_rows), _opt(stats), M, K, P, nb,
-                                                        _stream(X)), "usip_mlp_gemm_x2r_f32")
+                                                        _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
+                                                        _opt(pool_dp), _opt(pool_arg), int(pool_group), y_ptr,
+                                                        int(y_rows), _opt(stats), M, K, P, nb, _stream(X)),
+                       "usip_mlp_gemm_x2r_f32")
             return Y, stats
         if x3p:
             fn = "usip_mlp_gemm_x2h_f32" if x2h else "usip_mlp_gemm_x3p_f32"
