@@ -255,22 +255,23 @@ int usip_mlp_narrow_forward_f32(const float* At, int lda, const float* X, const 
 
 /* The same f32x3 product with the MATRIX operand split ahead of time (once per optimizer step instead of once per
  * workgroup and stage): usip_mlp_split3_f32 turns the K-major operand At (A[m][k] = At[k*lda + m], M x K) into the
- * image the kernel copies straight into LDS -- per (128-row tile, 16-k stage) three contiguous 4 KiB bf16 planes,
- * zero padded -- usip_mlp_split3_bytes(M, K) bytes, 16-B aligned.  usip_mlp_gemm_x3p_f32 then has the contract of
- * usip_mlp_gemm_f32 with `planes` in place of (At, lda); K <= 640. */
-int usip_mlp_x3p_tile_rows(int M);                 /* rows per tile (128 or 256): profiling aid */
+ * image the kernel copies straight into LDS -- per (tile_rows-row tile, 16-k stage) three contiguous bf16 planes, zero
+ * padded -- usip_mlp_split3_bytes(M, K) bytes, 16-B aligned; tile_rows = usip_mlp_x3p_tile_rows(M, P, nb) of the launch
+ * the image is for.  usip_mlp_gemm_x3p_f32 then has the contract of usip_mlp_gemm_f32 with `planes` in place of
+ * (At, lda); K <= 640. */
+int usip_mlp_x3p_tile_rows(int M, int P, int nb);  /* rows per tile (128 or 256) of a launch over nb x P positions */
 /* All weight operands of a step in one launch: descs (DEVICE memory, n entries, At / planes as for
- * usip_mlp_split3_f32) with first_block = running sum of usip_mlp_split3_blocks(M, K) over the entries before. */
+ * usip_mlp_split3_f32) with first_block = running sum of usip_mlp_split3_blocks(M, K, tile_rows) over the entries before. */
 typedef struct usip_split3_desc {
     const float* At; void* planes; int32_t lda, M, K, first_block;
-    int32_t tile_rows, reserved;                      /* usip_mlp_x3p_tile_rows(M); reserved: 2 = two fp16 planes (below) */
+    int32_t tile_rows, reserved;                      /* rows per tile of the image (128 / 256); reserved: 2 = two fp16 planes (below) */
 } usip_split3_desc;
-int usip_mlp_split3_blocks(int M, int K);
+int usip_mlp_split3_blocks(int M, int K, int tile_rows);
 int usip_mlp_split3_multi_f32(const usip_split3_desc* descs_device, int n, int total_blocks, void* stream);
 /* Positions per tile the same kernel uses for this launch: 128 (256 only under the x3_gemm_tile measurement knob). */
 int usip_mlp_x3p_tile_cols(int M, int P, int nb, int pro, int with_stats);
 long long usip_mlp_split3_bytes(int M, int K);
-int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream);
+int usip_mlp_split3_f32(const float* At, int lda, int M, int K, int tile_rows, void* planes, void* stream);
 int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
                           const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
                           const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
@@ -286,7 +287,7 @@ int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const float* X2, c
  *          want_bound (row 4: bounds of |dY| per 64 channels).
  * pro 0 (no bound available) is not offered: callers use usip_mlp_gemm_x3p_f32.  Otherwise the contract of
  * usip_mlp_gemm_x3p_f32. */
-int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, void* planes, void* stream);
+int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, int tile_rows, void* planes, void* stream);
 int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
                           const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
                           const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,

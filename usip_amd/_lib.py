@@ -41,7 +41,7 @@ SIGNATURES = {
     "usip_rigid_transform_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
     "usip_detector_loss_combine_f32": ([_f32p, _f32p, _flt, _f32p, ctypes.c_longlong, _stream], _int),
     "usip_fill_scaled_f32": ([_f32p, _flt, _f32p, ctypes.c_longlong, _stream], _int),
-    "usip_mlp_split3_blocks": ([_int, _int], _int),
+    "usip_mlp_split3_blocks": ([_int, _int, _int], _int),
     "usip_mlp_split3_multi_f32": ([ctypes.c_void_p, _int, _int, _stream], _int),
     "usip_bn_group_dy_sum_f32": ([_f32p, _f32p, _f32p, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_csr_by_index_i32": ([_i32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
@@ -63,16 +63,16 @@ SIGNATURES = {
     "usip_mlp_gemm_f32x3": ([_f32p, _int, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                              _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_f32x3_used": ([_int, _int, _int, _int], _int),
-    "usip_mlp_x3p_tile_rows": ([_int], _int),
+    "usip_mlp_x3p_tile_rows": ([_int, _int, _int], _int),
     "usip_mlp_x3p_tile_cols": ([_int, _int, _int, _int, _int], _int),
     "usip_mlp_split3_bytes": ([_int, _int], ctypes.c_longlong),
-    "usip_mlp_split3_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
+    "usip_mlp_split3_f32": ([_f32p, _int, _int, _int, _int, ctypes.c_void_p, _stream], _int),
     "usip_mlp_gemm_x3p_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_x2r_tiles": ([_int, _int], _int),
     "usip_mlp_gemm_x2r_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int, _f32p,
                                _int, _f32p, _int, _int, _int, _int, _stream], _int),
-    "usip_mlp_split2h_f32": ([_f32p, _int, _int, _int, ctypes.c_void_p, _stream], _int),
+    "usip_mlp_split2h_f32": ([_f32p, _int, _int, _int, _int, ctypes.c_void_p, _stream], _int),
     "usip_mlp_gemm_x2h_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3_used": ([_int, _int, _int, _int], _int),

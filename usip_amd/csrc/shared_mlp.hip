@@ -847,7 +847,10 @@ static bool x3_gemm_pays(int M, int K, int P, int nb)
     const long long tiles = (long long)nb * ((P + 127) / 128) * ((M + 127) / 128);
     if ((long long)K * P >= (1LL << 30)) return false;        // the split kernels address a cloud with 32-bit byte offsets
     if (t == 2) return M > 64 && K >= 16;
-    return M >= 128 && K >= 128 && tiles >= 512;
+    // 128 tiles of 128 x 128 (r03; 512 in r02): with 128-row tiles for small launches (usip_mlp_x3p_tile_rows) the
+    // second-stage and head layers -- 16 x 512 positions -- run 1.3-2.1x faster on the split kernel than on fp32 MFMAs
+    // (73 -> 36 us for 640 -> 512); in the step 5.195 -> 5.145 ms, same box, two runs each
+    return M >= 128 && K >= 128 && tiles >= (t >= 16 ? t : 128);     // t >= 16: measurement, the tile threshold itself
 }
 
 static int mlp_gemm_impl(int mode, const float* At, int lda, const float* X, const float* X2,
@@ -948,7 +951,10 @@ static bool x3_wgrad_pays(int M, int N, int P, int nb)
     const int t = usip_tuning_value(USIP_TUNE_GEMM_SPLIT3);
     if (t == 1) return false;
     if (t == 2) return M > 64 || N > 64;
-    return M >= 128 && N >= 128 && (long long)nb * P >= 32768;
+    // few positions (the head: 16 x 512): only the largest products pay -- 512 x 640 runs 102 -> 52 us, 512 x 512
+    // 66 -> 50, everything smaller is at the 256 x 256-tile kernel's floor of ~48 us (its 256 partial tiles)
+    const bool few_ok = (long long)M * N >= 512LL * 512 && usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 3;
+    return M >= 128 && N >= 128 && ((long long)nb * P >= 32768 || few_ok);
 }
 extern "C" int usip_mlp_wgrad_f32x3_used(int M, int N, int P, int nb) { return x3_wgrad_pays(M, N, P, nb) ? 1 : 0; }
 

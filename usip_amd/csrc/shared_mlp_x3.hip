@@ -901,11 +901,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 }  // namespace
 
-// Rows of the tile usip_mlp_gemm_x3p_f32 uses for an M-row operand (= rows per block of the split image).
-extern "C" int usip_mlp_x3p_tile_rows(int M)
+// Rows of the tile usip_mlp_gemm_x3p_f32 / _x2h_f32 use for an M-row operand in a launch over nb clouds of P positions
+// (= rows per block of the split image the launch expects).  256-row tiles halve the operand preparation per MFMA, but
+// the launch still has to fill the chip: the second-stage and head layers (512 positions per cloud) are 128-192
+// workgroups of 256 x 128 -- with 128-row tiles 640 -> 512 over 16 x 512 positions runs in 36 instead of 46 us (fp32
+// MFMA kernel: 73).
+extern "C" int usip_mlp_x3p_tile_rows(int M, int P, int nb)
 {
     const int t = usip_tuning_value(USIP_TUNE_X3_GEMM_TILE);        // measurement: 1 = always 128-row tiles
-    return (M > 128 && t != 1) ? 256 : 128;
+    if (M <= 128 || t == 1) return 128;
+    const long long wide = (long long)((M + 255) / 256) * nb * ((P + 127) / 128);
+    return wide >= 256 ? 256 : 128;
 }
 
 
@@ -913,14 +919,15 @@ extern "C" int usip_mlp_x3p_tile_rows(int M)
 extern "C" long long usip_mlp_split3_bytes(int M, int K)
 {
     if (M < 1 || K < 1) return 0;
-    const int bm = usip_mlp_x3p_tile_rows(M);
+    const int bm = M > 128 ? 256 : 128;                        // covers either tiling of the rows
     return (long long)((M + bm - 1) / bm) * ((K + XBK - 1) / XBK) * 3 * bm * 32;      // sized for three planes
 }
 
-extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void* planes, void* stream)
+extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, int tile_rows, void* planes, void* stream)
 {
     if (!At || !planes || M < 1 || K < 1 || lda < M || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
-    const int bm = usip_mlp_x3p_tile_rows(M);
+    if (tile_rows != 128 && tile_rows != 256) return USIP_EINVAL;
+    const int bm = tile_rows;
     const int ksteps = (K + XBK - 1) / XBK, mts = (M + bm - 1) / bm;
     USIP_LAUNCH(split3_tiles_kernel, dim3((unsigned)(mts * ksteps)), dim3(2 * bm), 0, (hipStream_t)stream, At, lda, M, K,
                 reinterpret_cast<uint4*>(planes), ksteps, bm, 3);
@@ -930,10 +937,11 @@ extern "C" int usip_mlp_split3_f32(const float* At, int lda, int M, int K, void*
 
 // The two-plane fp16 image of the same operand for usip_mlp_gemm_x2h_f32 (same buffer size: usip_mlp_split3_bytes):
 // per stage two planes, and behind the image one float = the power of two the operand was multiplied by.
-extern "C" int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, void* planes, void* stream)
+extern "C" int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, int tile_rows, void* planes, void* stream)
 {
     if (!At || !planes || M < 1 || K < 1 || lda < M || (reinterpret_cast<uintptr_t>(planes) & 15u)) return USIP_EINVAL;
-    const int bm = usip_mlp_x3p_tile_rows(M);
+    if (tile_rows != 128 && tile_rows != 256) return USIP_EINVAL;
+    const int bm = tile_rows;
     const int ksteps = (K + XBK - 1) / XBK, mts = (M + bm - 1) / bm;
     usip_split3_desc d{At, planes, lda, M, K, 0, bm, 2};
     USIP_LAUNCH(absmax_one_kernel, dim3(X2H_PARTS), dim3(256), 0, (hipStream_t)stream, d);
@@ -944,10 +952,10 @@ extern "C" int usip_mlp_split2h_f32(const float* At, int lda, int M, int K, void
     return USIP_OK;
 }
 
-extern "C" int usip_mlp_split3_blocks(int M, int K)
+extern "C" int usip_mlp_split3_blocks(int M, int K, int tile_rows)
 {
-    if (M < 1 || K < 1) return 0;
-    const int bm = usip_mlp_x3p_tile_rows(M);
+    if (M < 1 || K < 1 || (tile_rows != 128 && tile_rows != 256)) return 0;
+    const int bm = tile_rows;
     return ((M + bm - 1) / bm) * ((K + XBK - 1) / XBK);
 }
 
@@ -995,7 +1003,7 @@ static int launch_x3p(const GemmArgs& a, const uint4* pl, int pro, hipStream_t s
 // Contract of usip_mlp_gemm_f32 otherwise; K <= 640, P % 4 == 0 not required.
 extern "C" int usip_mlp_x3p_tile_cols(int M, int P, int nb, int pro, int with_stats)
 {
-    if (usip_mlp_x3p_tile_rows(M) == 128 || with_stats) return 128;
+    if (usip_mlp_x3p_tile_rows(M, P, nb) == 128 || with_stats) return 128;
     const int knob = usip_tuning_value(USIP_TUNE_X3_GEMM_TILE);
     const long long wide_tiles = (long long)((M + 255) / 256) * ((P + 255) / 256) * nb;
     return (knob == 4 || (knob == 5 && pro >= 2 && wide_tiles >= 256)) ? 256 : 128;
@@ -1021,7 +1029,7 @@ extern "C" int usip_mlp_gemm_x3p_f32(const void* planes, const float* X, const f
                0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const uint4* pl = reinterpret_cast<const uint4*>(planes);
-    if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2>(a, pl, pro, st);
+    if (usip_mlp_x3p_tile_rows(M, P, nb) == 128) return launch_x3p<2, 2>(a, pl, pro, st);
     // 256 x 256 tiles (8 waves, one workgroup per CU) are a measurement option (knob 4: every launch without
     // statistics -- their partial layout is per 128 positions; 5: data-gradient launches only).  r02r: alone on the
     // GPU the data-gradient launches gain 8 % (123 -> 113 us at 256 x 256 x 131072), inside the step the same choice
@@ -1057,7 +1065,7 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
                0, y_rows, (P % 4 == 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0) ? 1 : 0};
     hipStream_t st = (hipStream_t)stream;
     const uint4* pl = reinterpret_cast<const uint4*>(planes);
-    if (usip_mlp_x3p_tile_rows(M) == 128) return launch_x3p<2, 2, 2>(a, pl, pro, st);
+    if (usip_mlp_x3p_tile_rows(M, P, nb) == 128) return launch_x3p<2, 2, 2>(a, pl, pro, st);
     if (usip_mlp_x3p_tile_cols(M, P, nb, pro, stats != nullptr) == 256) return launch_x3p<4, 4, 2>(a, pl, pro, st);
     return launch_x3p<4, 2, 2>(a, pl, pro, st);
 }

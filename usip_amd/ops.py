@@ -400,18 +400,20 @@ def matmul_mode() -> str:
 PLANES_CACHE = None
 
 
-def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int, npl: int = 3) -> torch.Tensor:
+def weight_planes(At: torch.Tensor, a_offset: int, M: int, K: int, npl: int = 3, P: int = 0, nb: int = 1) -> torch.Tensor:
     """Split image (uint8 tensor) of the M x K operand A[m][k] = At[k, a_offset + m]: three bf16 planes for
-    usip_mlp_gemm_x3p_f32 (npl 3) or two fp16 planes + scale for usip_mlp_gemm_x2h_f32 (npl 2)."""
+    usip_mlp_gemm_x3p_f32 (npl 3) or two fp16 planes + scale for usip_mlp_gemm_x2h_f32 (npl 2), tiled for a launch over
+    nb clouds of P positions (usip_mlp_x3p_tile_rows: small launches take 128-row tiles)."""
     lda = At.shape[1]
-    key = (At.data_ptr(), lda, int(a_offset), int(M), int(K), int(npl))
+    rows = int(_lib.lib().usip_mlp_x3p_tile_rows(int(M), int(P), int(nb)))
+    key = (At.data_ptr(), lda, int(a_offset), int(M), int(K), int(npl), rows)
     if PLANES_CACHE is not None and key in PLANES_CACHE:
         return PLANES_CACHE[key][1]
     nbytes = int(_lib.lib().usip_mlp_split3_bytes(M, K))
     planes = torch.empty(nbytes, dtype=torch.uint8, device=At.device)
     fn = "usip_mlp_split2h_f32" if npl == 2 else "usip_mlp_split3_f32"
     with torch.cuda.device(At.device), prof.kernel("weight_split3", 4.0 * M * K + nbytes):
-        _lib.check(getattr(_lib.lib(), fn)(ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset)), lda, M, K,
+        _lib.check(getattr(_lib.lib(), fn)(ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset)), lda, M, K, rows,
                                            _ptr(planes), _stream(At)), fn)
     if PLANES_CACHE is not None:
         PLANES_CACHE[key] = (At, planes)      # holding At keeps its storage (the key) from being reused meanwhile
@@ -429,13 +431,12 @@ class PlanesPlan:
         spans = [(t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()) for t in storages if t is not None]
         self.entries, rows, blocks = {}, [], 0
         for key, (At, planes) in cache.items():
-            ptr, lda, off, M, K, npl = key
+            ptr, lda, off, M, K, npl, trows = key
             if not any(lo <= ptr < hi for lo, hi in spans):
                 continue
             self.entries[key] = (At, planes)
-            rows.append((ptr + 4 * off, planes.data_ptr(), lda, M, K, blocks, int(_lib.lib().usip_mlp_x3p_tile_rows(M)),
-                         2 if npl == 2 else 0))
-            blocks += int(_lib.lib().usip_mlp_split3_blocks(M, K))
+            rows.append((ptr + 4 * off, planes.data_ptr(), lda, M, K, blocks, trows, 2 if npl == 2 else 0))
+            blocks += int(_lib.lib().usip_mlp_split3_blocks(M, K, trows))
         self.blocks = blocks
         dt = np.dtype([("At", "<u8"), ("planes", "<u8"), ("lda", "<i4"), ("M", "<i4"), ("K", "<i4"), ("first", "<i4"),
                        ("tile_rows", "<i4"), ("reserved", "<i4")])
@@ -541,7 +542,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         if bf16:
             return "gemm_bf16_kernel<%d, %d, 16, %d, %d, 1> |wg=%d" % (wm, wn, pro, e, tiles * ((M + wm * 64 - 1) // (wm * 64)))
         if x3p:
-            bm = _lib.lib().usip_mlp_x3p_tile_rows(M)
+            bm = _lib.lib().usip_mlp_x3p_tile_rows(M, P, nb)
             bn = _lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), e)
             if x2r:
                 return "gemm_x2r_kernel<%d, %d, %s> |wg=%d" % (pro, e, "true" if rowbias is not None else "false",
@@ -559,10 +560,10 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         return "gemm_kernel<%d, %d, 16, %d, %d, %s, %d> |wg=%d" % (wm, wn, pro, e, "true" if P % 4 == 0 else "false", tm,
                                                                    tiles * ((M + bm - 1) // bm))
 
-    planes = weight_planes(At, a_offset, M, K, 2 if x2h else 3) if x3p else None
+    planes = weight_planes(At, a_offset, M, K, 2 if x2h else 3, P, nb) if x3p else None
     moved = 0.0
     if x3p:      # bytes into the CUs: per (tile, 16-k stage) the weight planes (L2) + the streamed operand, + the output
-        bm_ = int(_lib.lib().usip_mlp_x3p_tile_rows(M))
+        bm_ = int(_lib.lib().usip_mlp_x3p_tile_rows(M, P, nb))
         bn_ = 128 if x2h else int(_lib.lib().usip_mlp_x3p_tile_cols(M, P, nb, int(pro), 1 if want_stats else 0))
         ntiles = nb * ((P + bn_ - 1) // bn_) * ((M + bm_ - 1) // bm_)
         moved = ntiles * ((K + 15) // 16) * ((2 if x2h else 3) * bm_ * 32 + 16 * bn_ * 4 * (2 if pro == 2 else 1)) \
@@ -810,7 +811,7 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     blocks = int(lib.usip_mlp_layer_backward_x2h_blocks(Cin, Cout, P, nb))
     ws = torch.empty(int(lib.usip_mlp_layer_backward_x2h_workspace(Cin, Cout, P, nb)), dtype=torch.float32, device=dev)
     red = torch.empty(2 * blocks * Cin + blocks, dtype=torch.float32, device=dev) if want_red else None
-    planes = weight_planes(w2, wcol, Cin, Cout, 2)             # W as the data-gradient operand: K-major [Cout][ldw]
+    planes = weight_planes(w2, wcol, Cin, Cout, 2, P, nb)      # W as the data-gradient operand: K-major [Cout][ldw]
     pdp = parg = None
     group = 0
     if pool is not None:
