@@ -333,10 +333,11 @@ def test_fused_layer_backward_x2_equals_fp64_truth_and_the_separate_products(cfg
         ops.set_matmul_mode(prev)
 
 
-@pytest.mark.parametrize("cfg", [(2, 128, 16, 1.0), (1, 64, 64, 1e-3), (3, 32, 16, 30.0)])
+@pytest.mark.parametrize("cfg", [(2, 128, 16, 1.0), (1, 64, 64, 1e-3), (3, 32, 16, 30.0), (2, 66, 32, 1.0), (1, 9, 64, 5.0)])
 def test_fused_pooled_layer_backward_x2_equals_fp64_truth(cfg):
     """The pooled form (conv5 of the Ball detector: dZ = dpooled at the arg-max neighbour, zero elsewhere, never
-    materialised), 128 inputs and 128 outputs."""
+    materialised), 128 inputs and 128 outputs; neighbourhoods of 16 (two per tile: per-thread loads of the pooled pair)
+    and of 32 / 64 positions (one per tile: the pair handed over through LDS), odd tile counts included."""
     from usip_amd import ops
     nb, M, K, gscale = cfg
     Cin = Cout = 128

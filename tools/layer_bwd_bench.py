@@ -52,9 +52,9 @@ for Cin, Cout in ((64, 64), (64, 128)):
     gb = 4.0 * nb * P * (2 * Cout + 2 * Cin) / 1e9
     print("%3d -> %3d: narrow_bwd (fp32 MFMA) %7.1f us %5.2f TB/s | layer_bwd_x2 %7.1f us %5.2f TB/s" % (
         Cin, Cout, t_old, gb / t_old * 1e3, t_new, gb / t_new * 1e3), flush=True)
-# conv5: pooled form, 128 -> 128, K = 16 neighbours
+# conv5: pooled form, 128 -> 128, K = 64 neighbours (the step's; 16 as the first argument for the other code path)
 Cin = Cout = 128
-K = 16
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 M = P // K
 y, gy, my, iy, cy = bn_inputs(nb, Cout, P)
 x, gx, mx, ix, xcoef = bn_inputs(nb, Cin, P)

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 dev = "cuda:0"
 Cin, Cout = int(sys.argv[1]), int(sys.argv[2])
 pooled = len(sys.argv) > 3
-nb, P, K = 16, 32768, 16
+nb, P, K = 16, 32768, 64
 
 
 def bn_inputs(nb, C, P):

@@ -37,9 +37,9 @@ struct LayerBwdArgs {
     const float* X; int x_rows; const float* xcoef;            // [nb][x_rows][P] (rows [0, CIN) used), [4][CIN]
     const uint4* planes;                                       // usip_mlp_split2h_f32 image of W as the dgrad operand (CIN rows, K = COUT)
     float* dX; int dx_rows;                                    // [nb][dx_rows][P], rows [0, CIN) written
-    float* part;                                               // [nb * segs][COUT][CIN]
-    float* red;                                                // RED: [2][nb * segs][CIN] sums, then [nb * segs] maxima
-    int P, nb, seglen, segs;
+    float* part;                                               // [workgroups][COUT][CIN]
+    float* red;                                                // RED: [2][workgroups][CIN] sums, then [workgroups] maxima
+    int P, nb;
 };
 
 // byte offset of (row, position) in a [rows][BP positions] fp16 image: rows of BP * 2 + 16 bytes
@@ -49,7 +49,10 @@ __device__ __forceinline__ int rows_off(int row, int pos) { return row * (BP * 2
 // DB: two LDS buffers and ONE barrier per tile -- the next tile is written while this one is multiplied (gemm_x2r_kernel's
 // pipeline); without it a tile is written, a barrier, multiplied, a barrier (the forms that also keep fp32 images of X
 // and dX for the producing layer's sums have no room for a second buffer).
-template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB>
+// PG (pooled form, pool_group a multiple of the tile): the tile lies inside ONE neighbourhood, so its (dpooled, arg) pair
+// per channel -- 2 COUT values -- is fetched by 2 COUT threads one tile ahead and handed over through LDS, instead of 2 GC
+// broadcast loads per thread and tile (r03: those tiny requests were a third of the kernel's L2 traffic).
+template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG = false>
 __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwdArgs a)
 {
     constexpr int NT = 64 * NW;
@@ -71,15 +74,22 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     __shared__ float cfG[4][COUT];
     __shared__ float cfX[2][CIN];
     __shared__ float redm[2][NW];
+    __shared__ unsigned poolv[PG ? 2 : 1][2][PG ? COUT : 1];    // PG: [tile parity][dpooled | arg][channel]
+    static_assert(!PG || (POOL && DB && 2 * COUT <= NT), "PG");
     float* XR = reinterpret_cast<float*>(smem + (DB ? 2 : 1) * BUF);   // RED: [CIN][BP] raw X
     float* DX = XR + (RED ? CIN * XRS : 0);                    // RED: [CIN][BP] this tile of dX
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, kh = lane >> 5;
-    const int b = blockIdx.x / a.segs, seg = blockIdx.x % a.segs;
-    const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
-    const int ntile = (pend - pbeg) / BP;
+    // Tiles are dealt round-robin: workgroup w takes tiles w, w + G, w + 2 G, ... of the nb * P / BP tiles, so that at any
+    // moment the G workgroups stream G consecutive tiles -- the same DRAM pages of every channel row (r03: with one
+    // contiguous 2048-position segment per workgroup every 128-B access of the chip hit a different page of a different
+    // row: 3.5-4.0 TB/s where gemm_x2r_kernel, which interleaves, reaches 4.6-4.8).
+    const int tpc = a.P / BP, G = gridDim.x;
+    const int total = a.nb * tpc;
+    const int ntile = blockIdx.x < total ? (total - blockIdx.x + G - 1) / G : 0;
+    auto cloud_of = [&](int t, int& p0) { const int T = blockIdx.x + t * G; const int bb = T / tpc; p0 = (T - bb * tpc) * BP; return bb; };
 
     // operand scales
     float bg = 0.f, bx = 0.f;
@@ -130,22 +140,22 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     const int gp = tid % BP, gg = tid / BP;
     const int pgrp = POOL ? a.P / a.pool_group : 0;
     const unsigned cloud_bytes = (unsigned)COUT * (unsigned)a.P * 4u, pool_bytes = (unsigned)COUT * (unsigned)pgrp * 4u;
-    const __amdgpu_buffer_rsrc_t rZ = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((POOL ? a.Y : a.dZ) + (long long)b * COUT * a.P), 0, cloud_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.Y + (long long)b * COUT * a.P), 0, cloud_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rPd = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(POOL ? a.pool_dp + (long long)b * COUT * pgrp : a.Y), 0, POOL ? pool_bytes : 4u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rPa = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(POOL ? (const float*)(a.pool_arg + (long long)b * COUT * pgrp) : a.Y), 0, POOL ? pool_bytes : 4u, 0x00020000);
+    auto rsrc_Z = [&](int bb) { return __builtin_amdgcn_make_buffer_rsrc((void*)((POOL ? a.Y : a.dZ) + (long long)bb * COUT * a.P), 0, cloud_bytes, 0x00020000); };
+    auto rsrc_Y = [&](int bb) { return __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (long long)bb * COUT * a.P), 0, cloud_bytes, 0x00020000); };
+    auto rsrc_Pd = [&](int bb) { return __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? a.pool_dp + (long long)bb * COUT * pgrp : a.Y), 0, POOL ? pool_bytes : 4u, 0x00020000); };
+    auto rsrc_Pa = [&](int bb) { return __builtin_amdgcn_make_buffer_rsrc((void*)(POOL ? (const float*)(a.pool_arg + (long long)bb * COUT * pgrp) : a.Y), 0, POOL ? pool_bytes : 4u, 0x00020000); };
     const int xq = tid % XPC, xr0 = tid / XPC;
-    const float* xbase = a.X + ((long long)b * a.x_rows + xr0) * a.P + pbeg + xq * 8;
     float rz[GC], ry[GC], rx[NPX][8];
     int ra[POOL ? GC : 1], rkin = 0;
     auto load_gy = [&](int t) {
-        const int p = pbeg + t * BP + gp;
+        int p0;
+        const int bb = cloud_of(t, p0);
+        const int p = p0 + gp;
+        const __amdgpu_buffer_rsrc_t rZ = rsrc_Z(bb), rY = rsrc_Y(bb), rPd = rsrc_Pd(bb), rPa = rsrc_Pa(bb);
         const int voff = (int)(((unsigned)p + (unsigned)(GC * gg) * (unsigned)a.P) * 4u);
-        if (POOL) {
+        if (PG) {
+            // (the pair comes through poolv)
+        } else if (POOL) {
             const int g = p / a.pool_group;
             rkin = p - g * a.pool_group;
             const int poff = (int)(((unsigned)g + (unsigned)(GC * gg) * (unsigned)pgrp) * 4u);
@@ -164,9 +174,12 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, voff, i * a.P * 4, 0));
     };
     auto load_x = [&](int t) {
+        int p0;
+        const int bb = cloud_of(t, p0);
+        const float* xbase = a.X + ((long long)bb * a.x_rows + xr0) * a.P + p0 + xq * 8;
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
-            const float4* src = reinterpret_cast<const float4*>(xbase + (long long)q * XRP * a.P + (long long)t * BP);
+            const float4* src = reinterpret_cast<const float4*>(xbase + (long long)q * XRP * a.P);
             const float4 u = src[0], v = src[1];
             rx[q][0] = u.x; rx[q][1] = u.y; rx[q][2] = u.z; rx[q][3] = u.w;
             rx[q][4] = v.x; rx[q][5] = v.y; rx[q][6] = v.z; rx[q][7] = v.w;
@@ -175,7 +188,18 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     // One tile from the prefetched registers into LDS.  The loads of the NEXT tile (the last tile: a harmless repeat) are re-issued as soon as
     // a register group has been consumed -- in front of the splits and the LDS writes, not behind them: with the loads
     // issued after this phase a tile cost a full memory latency on top of it (4.3 us per 32-position tile).
-    auto write_tile = [&](int buf, int nxt) {
+    unsigned pzn = 0;                                          // PG: this thread's value (dpooled or arg of one channel) of the tile after next
+    const int pch = tid % COUT, pwhich = tid / COUT;           // PG: threads [0, COUT) fetch dpooled, [COUT, 2 COUT) arg
+    auto load_pool = [&](int t) {
+        if (PG && tid < 2 * COUT) {
+            int p0;
+            const int bb = cloud_of(t, p0);
+            const int g = p0 / a.pool_group;
+            const int off = (int)(((unsigned)pch * (unsigned)pgrp + (unsigned)g) * 4u);
+            pzn = pwhich ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_Pa(bb), off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(rsrc_Pd(bb), off, 0, 0);
+        }
+    };
+    auto write_tile = [&](int buf, int nxt, int tcur) {
         unsigned char* G1 = smem + buf * BUF;
         unsigned char* G2 = G1 + 2 * PL1;
         unsigned char* X2 = G2 + 2 * PL2;
@@ -200,13 +224,20 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         }
         if (EARLY) load_x(nxt);
         float v[GC];
-        const int kin = rkin;
+        int p0cur;
+        (void)cloud_of(tcur, p0cur);
+        const int kin = PG ? (p0cur + gp) % a.pool_group : rkin;
 #pragma unroll
         for (int i = 0; i < GC; ++i) {
             const int co = GC * gg + i;
             float dz = rz[i];
-            if (POOL) dz = (ra[POOL ? i : 0] == kin) ? dz : 0.f;
+            if (PG) dz = ((int)poolv[PG ? tcur & 1 : 0][1][PG ? co : 0] == kin) ? __uint_as_float(poolv[PG ? tcur & 1 : 0][0][PG ? co : 0]) : 0.f;
+            else if (POOL) dz = (ra[POOL ? i : 0] == kin) ? dz : 0.f;
             v[i] = pro_apply<PRO_BN_BWD>(dz, ry[i], cfG[0][co], cfG[1][co], cfG[2][co], cfG[3][co]);
+        }
+        if (PG) {                                              // hand the next tile's pair over, fetch the one after
+            if (tid < 2 * COUT) poolv[PG ? (tcur + 1) & 1 : 0][PG ? pwhich : 0][PG ? pch : 0] = pzn;
+            load_pool(min(tcur + 2, ntile - 1));
         }
         if (EARLY) load_gy(nxt);
 #pragma unroll
@@ -249,8 +280,12 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         }
     };
 
-    float* dXb = a.dX + (long long)b * a.dx_rows * a.P;
     if (ntile > 0) { load_gy(0); load_x(0); }
+    if (PG && ntile > 0) {
+        load_pool(0);
+        if (tid < 2 * COUT) poolv[0][PG ? pwhich : 0][PG ? pch : 0] = pzn;
+        load_pool(min(1, ntile - 1));
+    }
     if (RED) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { XR[xr0 * XRS + xq * 8 + i] = 0.f; DX[xr0 * XRS + xq * 8 + i] = 0.f; }
@@ -297,7 +332,9 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     auto store_dx = [&](int t, const f32x16& acc) {
         if (!does_dx) return;
         const int pos = dx_pt * 32 + c;
-        float* orow = dXb + pbeg + (long long)t * BP + pos;
+        int p0;
+        const int bb = cloud_of(t, p0);
+        float* orow = a.dX + (long long)bb * a.dx_rows * a.P + p0 + pos;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = dx_ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
@@ -307,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         }
     };
     if (DB) {
-        if (ntile > 0) write_tile(0, min(1, ntile - 1));
+        if (ntile > 0) write_tile(0, min(1, ntile - 1), 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         int cur = 0;
@@ -316,7 +353,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             multiply(cur, acc);
-            if (t + 1 < ntile) write_tile(cur ^ 1, min(t + 2, ntile - 1));   // the next tile, while the MFMAs drain
+            if (t + 1 < ntile) write_tile(cur ^ 1, min(t + 2, ntile - 1), t + 1);   // the next tile, while the MFMAs drain
             store_dx(t, acc);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // (raw: the loads stay in flight across it)
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     } else {
         for (int t = 0; t < ntile; ++t) {
             if (RED) red_pass();                               // the previous tile (the first time: the zeros written above)
-            write_tile(0, min(t + 1, ntile - 1));
+            write_tile(0, min(t + 1, ntile - 1), t);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // (raw: the loads stay in flight across it)
             f32x16 acc;
@@ -358,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             s2 += __shfl_xor(s2, off);
             mx = fmaxf(mx, __shfl_xor(mx, off));
         }
-        const long long nblk = (long long)a.nb * a.segs;
+        const long long nblk = G;
         if (xq == 0) {
             a.red[(long long)blockIdx.x * CIN + xr0] = s1;
             a.red[(nblk + blockIdx.x) * CIN + xr0] = s2;
@@ -378,18 +415,13 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     }
 }
 
-// Position segments per cloud (a multiple of 64 positions each): as many workgroups as the chip holds AT ONCE (two
-// 4-wave workgroups per CU, one 8-wave workgroup for the 128 x 128 form), so that the launch is a single round.
-void layer_bwd_plan(int Cin, int Cout, int P, int nb, int* seglen, int* segs)
+// Workgroups: as many as the chip holds AT ONCE (two 4-wave workgroups per CU, one 8-wave workgroup for the 128 x 128
+// form), so that the launch is a single round; every workgroup takes every G-th 32-position tile.
+int layer_bwd_blocks(int Cin, int Cout, int P, int nb)
 {
     const long long slots = (Cin == 128 && Cout == 128) ? 256 : 512;
-    long long per_cloud = slots / nb;
-    if (per_cloud < 1) per_cloud = 1;
-    const long long tiles = (P + 63) / 64;
-    long long tps = (tiles + per_cloud - 1) / per_cloud;      // 64-position tiles per segment
-    if (tps < 4) tps = 4;
-    *seglen = (int)(tps * 64);
-    *segs = (int)((P + *seglen - 1) / *seglen);
+    const long long total = (long long)nb * (P / 32);
+    return (int)(total < slots ? total : slots);
 }
 
 }  // namespace
@@ -407,9 +439,7 @@ extern "C" int usip_mlp_layer_backward_x2h_supported(int Cin, int Cout, int P, i
 
 extern "C" int usip_mlp_layer_backward_x2h_blocks(int Cin, int Cout, int P, int nb)
 {
-    int seglen, segs;
-    layer_bwd_plan(Cin, Cout, P, nb, &seglen, &segs);
-    return nb * segs;
+    return layer_bwd_blocks(Cin, Cout, P, nb);
 }
 
 extern "C" long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, int P, int nb)
@@ -443,12 +473,11 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
     if ((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(X) |
          reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(planes)) & 15u)
         return USIP_EINVAL;
-    int seglen, segs;
-    layer_bwd_plan(Cin, Cout, P, nb, &seglen, &segs);
+    const int blocks = layer_bwd_blocks(Cin, Cout, P, nb);
     LayerBwdArgs a{dZ, Y, coef4, pool_dp, pool_arg, pool_group, X, x_rows, xcoef, reinterpret_cast<const uint4*>(planes),
-                   dX, dx_rows, workspace, red_partial, P, nb, seglen, segs};
+                   dX, dx_rows, workspace, red_partial, P, nb};
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)(nb * segs));
+    dim3 grid((unsigned)blocks);
     const bool red = red_partial != nullptr;
     if (Cin == 64) {
         if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
@@ -457,8 +486,11 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
         if (red) return USIP_EINVAL;
         // (the single-buffer form with 64-position tiles measured the same, 224-230 us at 16 x 32768 positions, and
         // sits on the edge of spilling: 252-256 VGPRs)
-        USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true>), grid, dim3(512), 0, st, a);
+        if (pool_group % 32 == 0)
+            USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true, true>), grid, dim3(512), 0, st, a);
+        else
+            USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true, false>), grid, dim3(512), 0, st, a);
     }
     USIP_LAUNCH_CHECK();
-    return usip_mlp::launch_wgrad_reduce(workspace, dW, (long long)Cout * Cin, nb * segs, Cin, lddw, 0, st);
+    return usip_mlp::launch_wgrad_reduce(workspace, dW, (long long)Cout * Cin, blocks, Cin, lddw, 0, st);
 }
