@@ -751,13 +751,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
 {
     __shared__ double red[2][16][64];
     __shared__ float rmax[2][16];
-    if (max0) {                                               // maxima of |dYhat| of the gradient's (up to two) parts
-        float m0 = 0.f, m1 = 0.f;
+    // maxima of |dYhat| of the gradient's (up to two) parts: loaded first, reduced BEHIND the row sums (reducing them
+    // here put two more load latencies in front of the row loop: 10 -> 16.7 us)
+    float m0 = 0.f, m1 = 0.f;
+    if (max0) {
         for (int i = threadIdx.x; i < n0; i += 1024) m0 = fmaxf(m0, max0[i]);
         for (int i = threadIdx.x; i < n1; i += 1024) m1 = fmaxf(m1, max1[i]);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, off)); m1 = fmaxf(m1, __shfl_xor(m1, off)); }
-        if ((threadIdx.x & 63) == 0) { rmax[0][threadIdx.x >> 6] = m0; rmax[1][threadIdx.x >> 6] = m1; }
     }
     const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int ch = blockIdx.x * 64 + cl;
@@ -785,6 +784,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
     }
     red[0][grp][cl] = (a0 + a1) + (a2 + a3);
     red[1][grp][cl] = (b0 + b1) + (b2 + b3);
+    if (max0) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, off)); m1 = fmaxf(m1, __shfl_xor(m1, off)); }
+        if ((threadIdx.x & 63) == 0) { rmax[0][threadIdx.x >> 6] = m0; rmax[1][threadIdx.x >> 6] = m1; }
+    }
     __syncthreads();
     float bound = 0.f;
     if (grp == 0 && ch < C) {
@@ -801,10 +805,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
         coef4[2 * C + ch] = -a1f * c2m * is;
         coef4[3 * C + ch] = a1f * (c2m * is * mu - c1m);
         if (max0) {
-            float m0 = 0.f, m1 = 0.f;
+            float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) { m0 = fmaxf(m0, rmax[0][w]); m1 = fmaxf(m1, rmax[1][w]); }
-            bound = fabsf(a1f) * ((m0 + m1) + fabsf(c1m) + fabsf(c2m) * (float)sqrt(count));     // as bn_bwd_finalize_kernel
+            for (int w = 0; w < 16; ++w) { t0 = fmaxf(t0, rmax[0][w]); t1 = fmaxf(t1, rmax[1][w]); }
+            bound = fabsf(a1f) * ((t0 + t1) + fabsf(c1m) + fabsf(c2m) * (float)sqrt(count));     // as bn_bwd_finalize_kernel
         }
     }
     if (max0 && grp == 0) {
