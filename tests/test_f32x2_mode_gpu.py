@@ -81,11 +81,11 @@ def test_gemm_forward_f32x2_is_fp32_accurate(shape, scale, heavy, x2_forced):
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 128, 2048, 64, False), (1, 64, 128, 1088, 32, False), (3, 128, 128, 640, 64, False),
-                                 (2, 128, 128, 4096, 64, True)])
+                                 (2, 128, 128, 4096, 64, True), (16, 64, 128, 4096, 64, True)])
 def test_register_resident_gemm_with_row_bias(cfg):
     """gemm_x2r_kernel with a per-neighbourhood row bias (a pooled-concat layer's feature half): values against fp64,
-    statistics against the output, ragged last tile (1088 = 17 x 64); the 64-input launches reach it only with the
-    split kernels forced (the streaming fp32 kernel keeps them otherwise)."""
+    statistics against the output, ragged last tile (1088 = 17 x 64); small 64-input launches reach it only with the
+    split kernels forced (the streaming fp32 kernel keeps them), the step-sized one (16 x 4096 positions) on its own."""
     from usip_amd import _lib, ops
     nb, K, M, P, G, natural = cfg
     g = torch.Generator().manual_seed(K + M + P + G)
@@ -108,7 +108,7 @@ def test_register_resident_gemm_with_row_bias(cfg):
         assert _rel(Y, want) < 2e-6, _rel(Y, want)
         s = stats.double().sum(-1)
         assert _rel(s[0], Y.double().sum((0, 2))) < 1e-5 and _rel(s[1], (Y.double() ** 2).sum((0, 2))) < 1e-5
-        if not natural:                                     # it really was the register-resident kernel
+        if not natural or nb * P >= 65536:                  # it really was the register-resident kernel
             assert stats.shape[2] == _lib.lib().usip_mlp_gemm_x2r_tiles(P, nb)
         Y2, _ = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef, rowbias=rb, rb_group=G)
         assert torch.equal(Y, Y2)

@@ -458,6 +458,7 @@ class PlanesPlan:
 NARROW_FWD = _os.environ.get("USIP_NARROW_FWD", "1") not in ("0", "off")
 # f32x2 mode: the 128-wide layers on the register-resident-weights kernel; USIP_X2R=0 for A/B runs
 X2R = _os.environ.get("USIP_X2R", "1") not in ("0", "off")
+X2R_NARROW = _os.environ.get("USIP_X2R_NARROW", "1") not in ("0", "off")
 
 
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
@@ -499,12 +500,15 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
         y_ptr = ctypes.c_void_p(out.data_ptr() + 4 * int(out_row_offset) * P)
     a_ptr = ctypes.c_void_p(At.data_ptr() + 4 * int(a_offset))
     # narrow layers (64 inputs, 64 / 128 outputs) at many positions: the streaming kernel (csrc/narrow_fwd.hip)
-    # (f32x2 mode, measured r03: sending the 64 -> 128 layer -- the feature half of conv4, with its row bias -- to the
-    # register-resident f32x2 kernel instead of the streaming fp32 kernel changes nothing inside the step, 5.32-5.35 ms
-    # both ways, although it is 79-107 vs 82 us stand-alone depending on the box; the streaming kernel keeps it)
+    # f32x2 mode: the 64 -> 128 layer (the feature half of conv4, with its row bias) goes to the register-resident f32x2
+    # kernel -- the streaming kernel's fp32 MFMAs make it matrix-bound there (stand-alone 79-146 us depending on the box
+    # against 82-109; in the step the same or better).  USIP_X2R_NARROW=0 for A/B runs.
     rb_ok = rowbias is None or (rb_group % 32 == 0 and P % rb_group == 0)
+    x2r_direct = (X2R and X2R_NARROW and _matmul_mode == "f32x2" and pro == 1 and coef is not None and coef.shape[0] >= 4
+                  and M == 128 and K == 64 and not a_trans and pool is None and X2 is None and rb_ok
+                  and nb * P >= 65536 and K * P < 2 ** 30)
     nf_blocks = 0
-    if (NARROW_FWD and _matmul_mode != "bf16" and not a_trans and pool is None and X2 is None and pro in (0, 1)
+    if (NARROW_FWD and not x2r_direct and _matmul_mode != "bf16" and not a_trans and pool is None and X2 is None and pro in (0, 1)
             and K == 64 and M in (64, 128) and X.data_ptr() % 16 == 0
             and (rowbias is None or (rb_group % 32 == 0 and P % rb_group == 0))):
         nf_blocks = int(_lib.lib().usip_mlp_narrow_forward_blocks(M, K, P, nb))
@@ -523,7 +527,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     bf16 = _matmul_mode == "bf16"
     fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3",
                "f32x2": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
-    x3 = _x3_family() and bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb))
+    x3 = _x3_family() and (x2r_direct or bool(_lib.lib().usip_mlp_gemm_f32x3_used(M, K, P, nb)))
     x3p = x3 and not a_trans and K <= (512 if pro >= 2 else 640)       # weight operand split ahead of time
     # two fp16 planes: only where the streamed operand's bound is known (see usip_mlp_gemm_x2h_f32)
     x2h = (x3p and _matmul_mode == "f32x2" and coef is not None and
