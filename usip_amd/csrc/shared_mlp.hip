@@ -955,9 +955,9 @@ static bool x3_wgrad_pays(int M, int N, int P, int nb)
     const int t = usip_tuning_value(USIP_TUNE_GEMM_SPLIT3);
     if (t == 1) return false;
     if (t == 2) return M > 64 || N > 64;
-    // few positions (the head: 16 x 512): only the largest products pay -- 512 x 640 runs 102 -> 52 us, 512 x 512
-    // 66 -> 50, everything smaller is at the 256 x 256-tile kernel's floor of ~48 us (its 256 partial tiles)
-    const bool few_ok = (long long)M * N >= 512LL * 512 && usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 3;
+    // few positions (the head: 16 x 512): with position segments down to 128 (wgrad_x3_plan) 512 x 640 runs 102 -> 42 us,
+    // 512 x 512 66 -> 40, 256 x 512 39 -> 29; 256 x 256 is a tie (27 us) and stays on the fp32 kernel
+    const bool few_ok = (long long)M * N >= 256LL * 512 && usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 3;
     return M >= 128 && N >= 128 && ((long long)nb * P >= 32768 || few_ok);
 }
 extern "C" int usip_mlp_wgrad_f32x3_used(int M, int N, int P, int nb) { return x3_wgrad_pays(M, N, P, nb) ? 1 : 0; }

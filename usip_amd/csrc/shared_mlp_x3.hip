@@ -1134,7 +1134,13 @@ void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* til
     if (per_cloud < 1) per_cloud = 1;
     long long sl = (P + per_cloud - 1) / per_cloud;
     sl = ((sl + 31) / 32) * 32;
-    if (sl < 512) sl = 512;
+    // >= 512 positions per segment (a workgroup writes a 256 KiB partial tile) -- unless that leaves the chip half
+    // empty: the head's products (512 positions per cloud, 16 clouds x 6 tiles = 96 workgroups) take 256 or 128
+    // (knob x3_wgrad_tile = 4: always 512)
+    long long floor_sl = 512;
+    if (usip_tuning_value(USIP_TUNE_X3_WGRAD_TILE) != 4)
+        while (floor_sl > 128 && (long long)(*tiles) * nb * ((P + floor_sl - 1) / floor_sl) < 192) floor_sl /= 2;
+    if (sl < floor_sl) sl = floor_sl;
     *seglen = (int)sl;
     *segs = (int)((P + sl - 1) / sl);
 }
