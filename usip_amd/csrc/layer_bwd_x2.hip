@@ -1,7 +1,8 @@
 // usip_amd/csrc/layer_bwd_x2.hip -- backward of a shared-MLP layer with <= 128 inputs and <= 128 outputs as ONE kernel,
-// f32x2 arithmetic (two fp16 planes per operand, three plane products: shared_mlp_x3.hip): conv2, conv3, the feature
-// half of conv4 and conv5 of RPN_Detector_Ball (models/networks.py:705-712; the layers' backward is autograd's in the
-// reference: models/layers.py:208-216, :293-303).
+// f32x2 arithmetic (two fp16 planes per operand, three plane products: shared_mlp_x3.hip): conv2, conv3 and the pooled
+// conv5 of RPN_Detector_Ball (models/networks.py:705-712; the layers' backward is autograd's in the reference:
+// models/layers.py:208-216, :293-303).  (The feature half of conv4, 64 -> 128, compiles from the same template but
+// needs scratch and stays on narrow_bwd.hip.)
 //
 // These layers are HBM-bound and their (dZ, Y) pair used to be read two or three times per step (BatchNorm-backward
 // reduction, data-gradient GEMM, weight-gradient GEMM).  narrow_bwd.hip fused the two products for 64-input layers
@@ -9,10 +10,10 @@
 // MFMA pipe 50-58 % busy).  Here the same fusion runs on the 16-bit matrix cores at 1/5 of the matrix time, with the
 // lessons of gemm_x2r_kernel: weight fragments of the data-gradient resident in registers, D[channel][position]
 // accumulators so that a store instruction writes two full 128-B lines, per-lane running sums instead of per-tile
-// reductions.  A workgroup walks the BP-position tiles of its segment of one cloud:
+// reductions.  A workgroup walks every G-th BP-position tile (round-robin: the chip streams consecutive tiles):
 //     dY        = BatchNorm'(ReLU'(dZ)) from (dZ, Y, coef4)    (POOL: dZ = (k == arg) ? dpooled : 0, never stored)
 //     dX[ci][p] = sum_co W[co][ci] dY[co][p]                    written tile by tile
-//     dW[co][ci]+= sum_p dY[co][p] act(X)[ci][p]               accumulated in registers over the segment
+//     dW[co][ci]+= sum_p dY[co][p] act(X)[ci][p]               accumulated in registers over the workgroup's tiles
 //     RED: s1[ci] += dX [relu on], s2[ci] += dX [relu on] xhat, max |dX [relu on]|   (the producing layer's BatchNorm
 //          backward sums and the bound its own f32x2 backward needs; one partial per workgroup).  The tile of dX also
 //          goes to LDS and is summed by the X loader's threads (one channel, 8 positions each: two registers of state
@@ -51,7 +52,8 @@ __device__ __forceinline__ int rows_off(int row, int pos) { return row * (BP * 2
 // and dX for the producing layer's sums have no room for a second buffer).
 // PG (pooled form, pool_group a multiple of the tile): the tile lies inside ONE neighbourhood, so its (dpooled, arg) pair
 // per channel -- 2 COUT values -- is fetched by 2 COUT threads one tile ahead and handed over through LDS, instead of 2 GC
-// broadcast loads per thread and tile (r03: those tiny requests were a third of the kernel's L2 traffic).
+// broadcast loads per thread and tile (those tiny requests were a third of the kernel's L2 requests; the hand-over
+// changed nothing in time but frees 15 registers).
 template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG = false>
 __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwdArgs a)
 {
