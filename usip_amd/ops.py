@@ -827,10 +827,11 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     with torch.cuda.device(dev), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin),
                                              4.0 * Cout * Cin * nb * P,
-                                             rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s> |wg=%d" % (
+                                             rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s, %s> |wg=%d" % (
                                                  Cin, Cout, "true" if pool is not None else "false",
                                                  "true" if want_red else "false", 8 if Cin == 128 else 4,
-                                                 "true" if Cin == 128 else "false", blocks)):
+                                                 "true" if Cin == 128 else "false",
+                                                 "true" if (pool is not None and group % 32 == 0) else "false", blocks)):
         _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
             _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
             ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
