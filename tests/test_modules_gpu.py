@@ -412,7 +412,7 @@ def test_full_size_step_properties(matmul_mode_natural):
     kp1 = st.last["keypoints"].detach().clone()
     x = torch.cat((batch["src_pc"], batch["dst_pc"]), 0)
     node = torch.cat((batch["src_node"], batch["dst_node"]), 0)
-    ball = st.detector.last_indices["ball_idx"]
+    ball = st.detector.last_indices["ball_idx"].long()
     dist = ops.pairwise_dist(node.contiguous(), x.contiguous())
     inside = dist <= 2.0
     n_in = inside.sum(-1)

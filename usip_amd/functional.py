@@ -327,6 +327,7 @@ class _DetectorLossCombine(torch.autograd.Function):
         ctx.shape, ctx.alpha = tuple(d.shape), float(alpha)
         loss, on_src, on_dst = out[0], out[1], out[2]
         ctx.mark_non_differentiable(on_src, on_dst)
+        ctx.set_materialize_grads(False)                      # no zero-filled gradients for the two logging outputs
         return loss, on_src, on_dst
 
     @staticmethod

@@ -85,7 +85,7 @@ class RPN_Detector(_DetectorTail):
             both, first_idx = self.first_pointnet.forward_som_pooled(feat_in, epoch, min_idx32, count, csr, M, True)
             second_max, second_idx = self.second_pointnet.forward_som_pooled(both, epoch, min_idx32, count, csr, M,
                                                                              False)
-            self.last_indices.update(first_idx=first_idx.long(), second_idx=second_idx.long())
+            self.last_indices.update(first_idx=first_idx, second_idx=second_idx)     # int32 (the kernels' own)
             keypoints, sigmas = self._tail(cluster_mean, second_max, epoch)
             self.last_indices["knn_I"] = self.knnlayer_1.last_knn_I
             return cluster_mean, keypoints, sigmas, None
@@ -154,9 +154,8 @@ class RPN_Detector_Ball(_DetectorTail):
                                                 self.conv5.norm)          # conv5 + max over K fused :709-710
         else:
             second_max = Fh.group_max(self.conv5(h, defer=True))
-        ball_idx = ball_idx32.long()
         keypoints, sigmas = self._tail(node, second_max, epoch)
-        self.last_indices = {idx_name: ball_idx, "knn_I": self.knnlayer_1.last_knn_I}
+        self.last_indices = {idx_name: ball_idx32, "knn_I": self.knnlayer_1.last_knn_I}   # int32 (the kernels' own)
         return node, keypoints, sigmas, None
 
 
