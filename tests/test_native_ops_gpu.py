@@ -438,3 +438,35 @@ def test_knn_points_degenerate_clouds_take_the_exact_path():
     allsame = np.zeros((1, 3, 4096), np.float32)                           # every distance equal: rows are 0..K-1
     got = ops.knn_points(torch.zeros(1, 3, 4, device=DEV) + 1.0, torch.from_numpy(allsame).to(DEV), K).cpu()
     assert torch.equal(got, torch.arange(K, dtype=torch.int32).expand(1, 4, K))
+
+
+@pytest.mark.gpu
+def test_nearest_first_index_when_squared_distances_differ_but_distances_tie():
+    """usip_nearest_f32 scans the squared distances without taking a sqrt and settles value and FIRST index afterwards
+    (csrc/nearest.hip).  The case that scan cannot settle on its own: two candidates of the SAME lane (indices 64 apart)
+    whose squared distances differ by one ulp but whose correctly rounded square roots are equal, the later one being the
+    closer -- torch.min over the distances returns the EARLIER index.  Also: the same pair in different lanes, exact
+    duplicates across candidate chunks, and random clouds; everything against the oracle's torch.norm + torch.min."""
+    from usip_amd import ops
+    from oracle import detector as od
+    g = torch.Generator().manual_seed(77)
+    B, Ma, Nb = 2, 70, 4096
+    a = torch.randn(B, 3, Ma, generator=g) * 0.2
+    b = torch.randn(B, 3, Nb, generator=g)
+    b = b / b.norm(dim=1, keepdim=True) * (3.0 + torch.rand(B, 1, Nb, generator=g))     # everything at distance >= 2.5
+    near = torch.tensor([1.25, 3.0 * 2.0 ** -13, 0.0])        # squared distance 1.5625 + 1 ulp, distance 1.25
+    exact = torch.tensor([1.25, 0.0, 0.0])                    # squared distance 1.5625,        distance 1.25
+    a[0, :, 0] = 0.0
+    b[0, :, 5], b[0, :, 5 + 64] = near, exact                 # same lane: the later candidate has the smaller square
+    a[0, :, 1] = torch.tensor([10.0, 0.0, 0.0])
+    b[0, :, 200], b[0, :, 200 + 33] = near + a[0, :, 1], exact + a[0, :, 1]              # different lanes
+    a[0, :, 2] = torch.tensor([0.0, -10.0, 0.0])
+    b[0, :, 100] = b[0, :, 1124] = b[0, :, 3000] = torch.tensor([0.5, -10.0, 0.0])       # duplicates in three chunks
+    a[1, :, 3] = torch.tensor([0.0, 0.0, 10.0])
+    b[1, :, 900 + 64], b[1, :, 900] = near + a[1, :, 3], exact + a[1, :, 3]              # same lane, closer one first
+    d, arg = ops.nearest(a.to(DEV), b.to(DEV))
+    want_d, want_arg = torch.min(od.pairwise_norm(a, b), dim=2)
+    assert int(want_arg[0, 0]) == 5 and float(want_d[0, 0]) == 1.25                       # the fixture is what it claims
+    assert np.array_equal(d.cpu().numpy(), want_d.numpy())
+    assert np.array_equal(arg.cpu().numpy(), want_arg.numpy())
+    assert int(arg[0, 1]) == 200 and int(arg[0, 2]) == 100 and int(arg[1, 3]) == 900

@@ -50,20 +50,79 @@ __global__ __launch_bounds__(256) void nearest_kernel(
         qy[r] = usip_f32x2{ay[2 * r], ay[2 * r + 1]};
         qz[r] = usip_f32x2{az[2 * r], az[2 * r + 1]};
     }
-    for (int j = jbeg + lane; j < jend; j += 64) {
-        const float bx = bb[j], by = bb[Nb + j], bz = bb[2 * Nb + j];
-        const usip_f32x2 cx = {bx, bx}, cy = {by, by}, cz = {bz, bz};
+    // The reference-exact rule -- the correctly rounded sqrt of every candidate that improves a lane's running minimum of
+    // the SQUARED distance, first index kept on equal distances -- cost 70 of the kernel's 95 us: some lane of the wave
+    // improves in more than half of the iterations, and hipcc predicates the sqrt into all of them.  Instead (r03):
+    //   * one branch-free scan keeps, per lane and query, the strict running minimum s0 of the squared distance with its
+    //     index j0 and the minimum it replaced, s1.  min_j sqrt(s_j) = sqrt(min_j s_j) (the rounded sqrt is monotone), and
+    //     every candidate whose sqrt rounds to that value has s_j <= smin (1 + 2^-22 + ...): only candidates with
+    //     s_j <= thr = smin (1 + 2^-20) can be the answer.  The FIRST of them is a strict running minimum of its lane
+    //     (everything before it in the lane lies above thr), and the qualifying running minima of a lane are the tail
+    //     of its sequence: if s1 > thr the lane's only qualifying candidate is (s0, j0);
+    //   * a wave in which some lane has s1 <= thr as well (two candidates within 1e-6 of the minimum in one lane, or an
+    //     empty / all-NaN chunk) settles the question by the exact scan below.
+    // UNR candidates per lane and iteration, all their loads issued before the first is used (one candidate per iteration
+    // was a chain of L2 latencies); the tail repeats the chunk's last candidate, which is never a strict improvement.
+    constexpr int UNR = 4;
+    float s1[R];
 #pragma unroll
-        for (int r2 = 0; r2 < R / 2; ++r2) {
-            const usip_f32x2 s2 = usip_sqdist2(qx[r2], qy[r2], qz[r2], cx, cy, cz);   // two queries per packed instruction
+    for (int r = 0; r < R; ++r) { best_s[r] = __builtin_inff(); s1[r] = __builtin_inff(); }
+    for (int j0 = jbeg + lane; j0 < jend; j0 += 64 * UNR) {
+        float bx[UNR], by[UNR], bz[UNR];
+        int jj[UNR];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = 2 * r2 + h;
-                const float s = h ? s2.y : s2.x;
-                if (s < best_s[r]) {
-                    best_s[r] = s;
-                    const float d = sqrtf(s);
-                    if (d < best_d[r]) { best_d[r] = d; best_j[r] = j; }
+        for (int u = 0; u < UNR; ++u) {
+            jj[u] = min(j0 + 64 * u, jend - 1);
+            bx[u] = bb[jj[u]]; by[u] = bb[Nb + jj[u]]; bz[u] = bb[2 * Nb + jj[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const usip_f32x2 cx = {bx[u], bx[u]}, cy = {by[u], by[u]}, cz = {bz[u], bz[u]};
+#pragma unroll
+            for (int r2 = 0; r2 < R / 2; ++r2) {
+                const usip_f32x2 s2 = usip_sqdist2(qx[r2], qy[r2], qz[r2], cx, cy, cz);   // two queries per packed instruction
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = 2 * r2 + h;
+                    const float sq = h ? s2.y : s2.x;
+                    const bool lt = sq < best_s[r];                                // false for NaN
+                    s1[r] = lt ? best_s[r] : s1[r];
+                    best_s[r] = lt ? sq : best_s[r];
+                    best_j[r] = lt ? jj[u] : best_j[r];
+                }
+            }
+        }
+    }
+    float thr[R];
+    bool ambiguous = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float m = best_s[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off));
+        thr[r] = m * 1.00000095367431640625f;                  // 1 + 2^-20
+        ambiguous = ambiguous || s1[r] <= thr[r];
+        if (best_s[r] <= thr[r]) best_d[r] = sqrtf(best_s[r]);  // this lane's candidate (j0 is its index already)
+        else best_j[r] = 0x7fffffff;
+    }
+    if (__any(ambiguous)) {
+        // exact scan of the chunk: every candidate with s <= thr, in ascending order within a lane
+#pragma unroll
+        for (int r = 0; r < R; ++r) { best_d[r] = __builtin_inff(); best_j[r] = 0x7fffffff; }
+        for (int j = jbeg + lane; j < jend; j += 64) {
+            const float bx = bb[j], by = bb[Nb + j], bz = bb[2 * Nb + j];
+            const usip_f32x2 cx = {bx, bx}, cy = {by, by}, cz = {bz, bz};
+#pragma unroll
+            for (int r2 = 0; r2 < R / 2; ++r2) {
+                const usip_f32x2 s2 = usip_sqdist2(qx[r2], qy[r2], qz[r2], cx, cy, cz);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = 2 * r2 + h;
+                    const float sq = h ? s2.y : s2.x;
+                    if (sq <= thr[r]) {
+                        const float d = sqrtf(sq);
+                        if (d < best_d[r]) { best_d[r] = d; best_j[r] = j; }
+                    }
                 }
             }
         }
