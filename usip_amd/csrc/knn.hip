@@ -12,8 +12,11 @@
 
 namespace {
 
-constexpr int CPL = 16;              // candidates per lane -> N <= 1024
+constexpr int CPL_MAX = 16;          // candidates per lane -> N <= 1024
 
+// CPL = candidate slots per lane: 4, 8 or 16 for N <= 256, 512, 1024 (every selection round scans all slots; with the
+// node counts of the path -- 512 -- half of 16 slots were never candidates)
+template <int CPL>
 __global__ __launch_bounds__(256) void knn_kernel(
     const float* __restrict__ query, const float* __restrict__ database, int32_t* __restrict__ out,
     int M, int N, int K)
@@ -65,9 +68,11 @@ extern "C" int usip_knn_f32(const float* query, const float* database, int32_t* 
 {
     if (B < 0 || M < 0 || N < 1 || K < 1 || K > N) return USIP_EINVAL;
     if ((long long)B * M == 0) return USIP_OK;
-    if (!query || !database || !idx || B > 65535 || N > 64 * CPL) return USIP_EINVAL;
-    USIP_LAUNCH(knn_kernel, dim3(usip_ceil_div(M, 4), B), dim3(256), 0, (hipStream_t)stream,
-                query, database, idx, M, N, K);
+    if (!query || !database || !idx || B > 65535 || N > 64 * CPL_MAX) return USIP_EINVAL;
+    const dim3 grid(usip_ceil_div(M, 4), B), block(256);
+    if (N <= 256) USIP_LAUNCH(knn_kernel<4>, grid, block, 0, (hipStream_t)stream, query, database, idx, M, N, K);
+    else if (N <= 512) USIP_LAUNCH(knn_kernel<8>, grid, block, 0, (hipStream_t)stream, query, database, idx, M, N, K);
+    else USIP_LAUNCH(knn_kernel<16>, grid, block, 0, (hipStream_t)stream, query, database, idx, M, N, K);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
