@@ -394,15 +394,17 @@ int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, const float* c
  * usip_mlp_split2h_f32 image of W as the data-gradient operand (At = W [Cout][ldw], M = Cin, K = Cout).  workspace:
  * usip_mlp_layer_backward_x2h_workspace floats.  red_partial (may be NULL): [2][blocks][Cin] partial sums of the
  * producing layer's BatchNorm backward against dX followed by [blocks] maxima of |dX [relu on]|, blocks =
- * usip_mlp_layer_backward_x2h_blocks. */
+ * usip_mlp_layer_backward_x2h_blocks.  group_sums (may be NULL; pooled form with red_partial, pool_group % 32 == 0):
+ * [2][nb * Cin][P / pool_group] = per neighbourhood sum_k dX [relu on] and sum_k X, the `gsum` of
+ * usip_bn_backward_reduce_f32 for a producing layer that is a pooled-concat layer (conv4 behind conv5). */
 int usip_mlp_layer_backward_x2h_supported(int Cin, int Cout, int P, int pooled);
 long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, int P, int nb);
 int usip_mlp_layer_backward_x2h_blocks(int Cin, int Cout, int P, int nb);
 int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
                                     const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
                                     const float* xcoef, const void* planes, float* dX, int dx_rows, float* workspace,
-                                    float* dW, int lddw, float* red_partial, int Cin, int Cout, int P, int nb,
-                                    void* stream);
+                                    float* dW, int lddw, float* red_partial, float* group_sums, int Cin, int Cout,
+                                    int P, int nb, void* stream);
 int usip_bn_backward_finalize_f32(const float* partial, int rows, int C, long long count, const float* coef_fwd,
                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef4,
                                   void* stream);

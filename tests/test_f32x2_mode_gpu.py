@@ -370,3 +370,50 @@ def test_fused_pooled_layer_backward_x2_equals_fp64_truth(cfg):
         assert torch.equal(dx3, dx) and torch.equal(dw3, dw)
     finally:
         ops.set_matmul_mode(prev)
+
+
+@pytest.mark.parametrize("cfg", [(2, 128, 32, 1.0), (1, 64, 64, 1e-3), (3, 33, 64, 30.0), (1, 6, 128, 5.0), (5, 2, 32, 1.0)])
+def test_fused_pooled_layer_backward_x2_also_leaves_the_producing_layers_sums(cfg):
+    """The pooled form with the sums for the layer that produced X (conv4 of the Ball detector, a pooled-concat layer):
+    BatchNorm-backward partials, the maxima for the bound, and the per-neighbourhood sums of dX [relu on] and X, against
+    that layer's own stand-alone pass bn_backward_reduce(group=K) over the dX the kernel wrote; dX / dW unchanged by the
+    extra outputs; odd tile and neighbourhood counts per workgroup."""
+    from usip_amd import ops
+    nb, M, K, gscale = cfg
+    Cin = Cout = 128
+    P = M * K
+    g = torch.Generator().manual_seed(7 * M + K)
+    prev = ops.set_matmul_mode("f32x2")
+    try:
+        y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, Cout, P)
+        x, gamma_x, mean_x, invstd_x, xcoef = _bn_layer_inputs(g, nb, Cin, P)
+        w2 = (torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5).to(DEV)
+        pooled, arg = ops.group_max_act(y.view(nb, Cout, M, K), coef_y, True)
+        dpooled = (torch.randn(nb, Cout, M, generator=g) * gscale).to(DEV)
+        _, _, coef4 = ops.bn_pool_backward_reduce(dpooled, arg, y.view(nb, Cout, M, K), coef_y, mean_y, invstd_y, gamma_y, True)
+        dx0, dw0 = ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=(dpooled, arg, K))
+        dx, dw, red = ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=(dpooled, arg, K),
+                                                want_red=True, want_gsum=True)
+        assert _rel(dx, dx0) < 1e-6 and _rel(dw, dw0) < 1e-6
+        dg2, db2, c42, gsum2 = ops.bn_backward_reduce(dx, x, xcoef, mean_x, invstd_x, gamma_x, True, group=K)
+        assert red.gsum.shape == gsum2.shape == (2, nb, Cin, M)
+        on = (x.double() * xcoef[0].double().view(1, Cin, 1) + xcoef[1].double().view(1, Cin, 1)).float() > 0
+        d = torch.where(on, dx, torch.zeros_like(dx)).double()
+        want_g0 = d.view(nb, Cin, M, K).sum(3)
+        want_g1 = x.double().view(nb, Cin, M, K).sum(3)
+        assert _rel(red.gsum[0], want_g0) < 2e-6, _rel(red.gsum[0], want_g0)
+        assert _rel(red.gsum[1], want_g1) < 2e-6, _rel(red.gsum[1], want_g1)
+        assert _rel(red.gsum[0], gsum2[0]) < 2e-6 and _rel(red.gsum[1], gsum2[1]) < 2e-6
+        assert float(red.maxima.max()) == float(d.abs().max().float())
+        dg, db, c4 = ops.bn_backward_from_partials(red, nb * P, xcoef, mean_x, invstd_x)
+        assert c4.shape[0] == 5 and c42.shape[0] == 5
+        for a_, b_, n in ((dg, dg2, "dgamma"), (db, db2, "dbeta"), (c4[:4], c42[:4], "coef4")):
+            assert _rel(a_, b_) < 5e-6, (n, _rel(a_, b_))
+        nbe = Cin // 64                                   # row 4 holds one bound per 64 channels
+        assert bool((c4[4, :nbe] >= c42[4, :nbe] * (1 - 1e-6)).all()) and bool((c4[4, :nbe] <= 64 * c42[4, :nbe]).all())
+        dx3, dw3, red3 = ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=(dpooled, arg, K),
+                                                   want_red=True, want_gsum=True)
+        assert torch.equal(dx3, dx) and torch.equal(dw3, dw) and torch.equal(red3.flat, red.flat)
+        assert torch.equal(red3.gsum, red.gsum)
+    finally:
+        ops.set_matmul_mode(prev)

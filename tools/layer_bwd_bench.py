@@ -66,6 +66,11 @@ pool = (dpooled, arg, K)
 t_d = timed(lambda: ops.mlp_gemm(w2, None, pro=3, X2=y, coef=coef4, tag="dgrad", pool=pool))
 t_w = timed(lambda: ops.mlp_wgrad(None, x, pro=3, G2=y, coef4=coef4, xcoef=xcoef, pool=pool))
 t_new = timed(lambda: ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=pool))
+if K % 32 == 0:
+    t_red = timed(lambda: ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=pool, want_red=True, want_gsum=True))
+    dx = ops.mlp_layer_backward_x2(None, y, coef4, x, xcoef, w2, Cin=Cin, pool=pool)[0]
+    t_pass = timed(lambda: ops.bn_backward_reduce(dx, x, xcoef, mx, ix, gx, True, group=K))
+    print("128 -> 128 pooled with the producing layer's sums: %7.1f us (the stand-alone pass it replaces: %7.1f us)" % (t_red, t_pass), flush=True)
 gb = 4.0 * nb * P * (Cout + 2 * Cin) / 1e9
 print("128 -> 128 pooled: dgrad %7.1f us + wgrad %7.1f us = %7.1f us | layer_bwd_x2 %7.1f us %5.2f TB/s" % (
     t_d, t_w, t_d + t_w, t_new, gb / t_new * 1e3), flush=True)

@@ -25,6 +25,8 @@
 // conflict-free ds_read_b128 with every address = one base register + an immediate (XOR-swizzled rows cost a
 // register per address: the first build spilled).  Operand scales are exact powers of two from rigorous bounds (shared_mlp_x3.hip): dY from
 // row 4 of coef4, act(X) from the producer's batch statistics, W from the trailer of its split image.
+#include <type_traits>
+
 #include "mlp_common.h"
 #include "split_common.h"
 
@@ -40,6 +42,7 @@ struct LayerBwdArgs {
     float* dX; int dx_rows;                                    // [nb][dx_rows][P], rows [0, CIN) written
     float* part;                                               // [workgroups][COUT][CIN]
     float* red;                                                // RED: [2][workgroups][CIN] sums, then [workgroups] maxima
+    float* gsum;                                               // RED + POOL, may be null: [2][nb * CIN][P / pool_group] per-neighbourhood sums
     int P, nb;
 };
 
@@ -54,12 +57,14 @@ __device__ __forceinline__ int rows_off(int row, int pos) { return row * (BP * 2
 // per channel -- 2 COUT values -- is fetched by 2 COUT threads one tile ahead and handed over through LDS, instead of 2 GC
 // broadcast loads per thread and tile (those tiny requests were a third of the kernel's L2 requests; the hand-over
 // changed nothing in time but frees 15 registers).
-template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG = false>
+// SPLIT: the first half of the waves does the data gradient (and holds the weight fragments), the second half the weight
+// gradient (and holds its accumulators) -- the two register-hungry roles no longer add up in every wave.
+template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwdArgs a)
 {
     constexpr int NT = 64 * NW;
     constexpr int GC = COUT * BP / NT;                         // output channels per (dZ, Y) loader thread: 8 or 16
-    constexpr bool EARLY = (GC == 8);                          // next tile's loads re-issued inside write_tile (16: register pressure)
+    constexpr bool EARLY = (GC == 8) && !(RED && DB);          // next tile's loads re-issued inside write_tile (else: register pressure)
     constexpr int NCI = CIN / 32, NCO = COUT / 32, NPT = BP / 32;
     constexpr int NDX = NCI * NPT;                             // 32 x 32 tiles of dX per position tile: one per wave
     constexpr int NDW = NCO * NCI / NW;                        // 32 x 32 tiles of dW per wave (same co tile)
@@ -70,16 +75,18 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     constexpr int PL2 = COUT * RS2, PLX = CIN * RS2;
     constexpr int BUF = 2 * PL1 + 2 * PL2 + 2 * PLX;           // one buffer: both planes of the three images
     static_assert(NDX <= NW && (NCO * NCI) % NW == 0 && (GC == 8 || GC == 16) && CIN % XRP == 0 && (!RED || NPX == 1) &&
-                  !(RED && DB), "tile roles");
+                  true, "tile roles");
     constexpr int XRS = BP + 4;                                // floats per row of the fp32 images (16 B of padding, as above)
     __shared__ __attribute__((aligned(16))) unsigned char smem[(DB ? 2 : 1) * BUF + (RED ? 2 * CIN * XRS * 4 : 16)];
     __shared__ float cfG[4][COUT];
     __shared__ float cfX[2][CIN];
     __shared__ float redm[2][NW];
     __shared__ unsigned poolv[PG ? 2 : 1][2][PG ? COUT : 1];    // PG: [tile parity][dpooled | arg][channel]
-    static_assert(!PG || (POOL && DB && 2 * COUT <= NT), "PG");
-    float* XR = reinterpret_cast<float*>(smem + (DB ? 2 : 1) * BUF);   // RED: [CIN][BP] raw X
-    float* DX = XR + (RED ? CIN * XRS : 0);                    // RED: [CIN][BP] this tile of dX
+    static_assert(!PG || (POOL && 2 * COUT <= NT), "PG");
+    // RED: the tile of dX for the sums' pass -- one buffer behind an fp32 copy of the X tile (XR), or, with two LDS buffers
+    // per tile (DB), two dX buffers and the raw X tile kept in registers instead
+    float* XR = reinterpret_cast<float*>(smem + (DB ? 2 : 1) * BUF);
+    float* DX = XR + ((RED && !DB) ? CIN * XRS : 0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,10 +95,17 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     // moment the G workgroups stream G consecutive tiles -- the same DRAM pages of every channel row (r03: with one
     // contiguous 2048-position segment per workgroup every 128-B access of the chip hit a different page of a different
     // row: 3.5-4.0 TB/s where gemm_x2r_kernel, which interleaves, reaches 4.6-4.8).
+    // (With per-neighbourhood sums the unit dealt is a RUN of pool_group / BP tiles: a neighbourhood stays in one workgroup.)
     const int tpc = a.P / BP, G = gridDim.x;
-    const int total = a.nb * tpc;
-    const int ntile = blockIdx.x < total ? (total - blockIdx.x + G - 1) / G : 0;
-    auto cloud_of = [&](int t, int& p0) { const int T = blockIdx.x + t * G; const int bb = T / tpc; p0 = (T - bb * tpc) * BP; return bb; };
+    const int tpg = (RED && POOL && a.gsum) ? a.pool_group / BP : 1;
+    const int total = a.nb * tpc / tpg;                        // runs
+    const int ntile = blockIdx.x < total ? ((total - blockIdx.x + G - 1) / G) * tpg : 0;
+    auto cloud_of = [&](int t, int& p0) {
+        const int T = (blockIdx.x + (t / tpg) * G) * tpg + t % tpg;
+        const int bb = T / tpc;
+        p0 = (T - bb * tpc) * BP;
+        return bb;
+    };
 
     // operand scales
     float bg = 0.f, bx = 0.f;
@@ -117,25 +131,11 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     for (int i = tid; i < 2 * CIN; i += NT) cfX[i / CIN][i % CIN] = a.xcoef[i] * sX;
 
     // roles.  dX: wave w < NDX owns input tile w % NCI at position tile w / NCI, its weight fragments stay in registers.
-    // dW: wave w owns tiles T = w NDW + u: co tile T / NCI (the same for all u), ci tile T % NCI.
-    const bool does_dx = (NDX == NW) || wave < NDX;
+    // dW: a wave owns NDWR consecutive tiles T (co tile T / NCI, ci tile T % NCI); see `run` below.
     const int dx_ci = wave % NCI, dx_pt = (wave / NCI) % NPT;
-    const int dw_co = (wave * NDW) / NCI;
-    bf16x8 fa[KS][2];
-    {
-        const int row = dx_ci * 32 + c;
-        const int chunk = row * 2 + ((kh ^ (row >> 3)) & 1);
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) fa[s][pl] = __builtin_bit_cast(bf16x8, a.planes[(long long)(s * 2 + pl) * 256 + chunk]);
-    }
-    f32x16 acc_dw[NDW];
-#pragma unroll
-    for (int u = 0; u < NDW; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_dw[u][r] = 0.f;
     float s1 = 0.f, s2 = 0.f, mx = 0.f;                        // RED: the thread's channel (its X row), its 8 positions of every tile
+    float rxk[(RED && DB) ? 2 : 1][8];                         // RED + DB: the raw X of the tiles in the two LDS buffers
+    float gd = 0.f, gy = 0.f;                                  // per-neighbourhood sums of the current run (a.gsum)
 
     // loaders.  (dZ, Y): thread -> position gp of the tile, the GC output channels [GC gg, GC gg + GC); buffer loads with
     // the row as a scalar offset.  X: thread -> 8 consecutive positions (piece xq) of row xr0 (+ XRP per pass).
@@ -206,11 +206,15 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         unsigned char* G2 = G1 + 2 * PL1;
         unsigned char* X2 = G2 + 2 * PL2;
         // act(X) first: its temporaries are dead before the 2 GC values of dY come to life
+        if (RED && DB) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) rxk[(RED && DB) ? (tcur & 1) : 0][i] = rx[0][i];
+        }
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
             const int row = xr0 + q * XRP;
             const float sc = cfX[0][row], sh = cfX[1][row];
-            if (RED) {
+            if (RED && !DB) {
                 float4* dst = reinterpret_cast<float4*>(XR + row * XRS + xq * 8);
                 dst[0] = make_float4(rx[q][0], rx[q][1], rx[q][2], rx[q][3]);
                 dst[1] = make_float4(rx[q][4], rx[q][5], rx[q][6], rx[q][7]);
@@ -267,18 +271,45 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     // rewritten only behind the next tile's first barrier: no barrier of its own
     const float rsc = RED ? a.xcoef[xr0] : 0.f, rsh = RED ? a.xcoef[CIN + xr0] : 0.f;
     const float rmu = RED ? a.xcoef[2 * CIN + xr0] : 0.f, ris = RED ? a.xcoef[3 * CIN + xr0] : 0.f;
-    auto red_pass = [&]() {
-        const float4* xs4 = reinterpret_cast<const float4*>(XR + xr0 * XRS + xq * 8);
-        const float4* ds4 = reinterpret_cast<const float4*>(DX + xr0 * XRS + xq * 8);
-        const float4 x0 = xs4[0], x1 = xs4[1], d0 = ds4[0], d1 = ds4[1];
-        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-        const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    // tp = the tile the pass is for (DB: selects the dX buffer and the register copy of X; with a.gsum: the tile's place in
+    // its run of tpg tiles = one neighbourhood, whose sums are written behind the run's last tile)
+    auto red_pass = [&](int tp) {
+        const float* dbase = DX + ((RED && DB) ? (tp & 1) * CIN * XRS : 0) + xr0 * XRS + xq * 8;
+        const float* xbase_l = XR + xr0 * XRS + xq * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float d = (__builtin_fmaf(xv[i], rsc, rsh) > 0.f) ? dv[i] : 0.f;
-            s1 += d;
-            s2 = __builtin_fmaf(d, (xv[i] - rmu) * ris, s2);
-            mx = fmaxf(mx, fabsf(d));
+        for (int h = 0; h < 2; ++h) {                          // four positions at a time (registers)
+            const float4 d4 = reinterpret_cast<const float4*>(dbase)[h];
+            float4 x4;
+            if (RED && DB) {
+                const int k = (RED && DB) ? (tp & 1) : 0;
+                x4 = make_float4(rxk[k][4 * h], rxk[k][4 * h + 1], rxk[k][4 * h + 2], rxk[k][4 * h + 3]);
+            } else {
+                x4 = reinterpret_cast<const float4*>(xbase_l)[h];
+            }
+            const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = (__builtin_fmaf(xv[i], rsc, rsh) > 0.f) ? dv[i] : 0.f;
+                s1 += d;
+                s2 = __builtin_fmaf(d, (xv[i] - rmu) * ris, s2);
+                mx = fmaxf(mx, fabsf(d));
+                if (POOL) { gd += d; gy += xv[i]; }
+            }
+        }
+        if (POOL && a.gsum && tp >= 0 && (tp % tpg) == tpg - 1) {
+            // the XPC threads of a channel are neighbouring lanes: the neighbourhood's sums, written by the first of them
+            float u = gd, v = gy;
+#pragma unroll
+            for (int off = 1; off < XPC; off <<= 1) { u += __shfl_xor(u, off); v += __shfl_xor(v, off); }
+            if (xq == 0) {
+                int p0;
+                const int bb = cloud_of(tp, p0);
+                const int ngrp = a.P / a.pool_group;
+                const long long rowid = (long long)bb * CIN + xr0;
+                a.gsum[rowid * ngrp + p0 / a.pool_group] = u;
+                a.gsum[((long long)a.nb * CIN + rowid) * ngrp + p0 / a.pool_group] = v;
+            }
+            gd = 0.f; gy = 0.f;
         }
     };
 
@@ -288,39 +319,61 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         if (tid < 2 * COUT) poolv[0][PG ? pwhich : 0][PG ? pch : 0] = pzn;
         load_pool(min(1, ntile - 1));
     }
-    if (RED) {
+    if (RED && !DB) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { XR[xr0 * XRS + xq * 8 + i] = 0.f; DX[xr0 * XRS + xq * 8 + i] = 0.f; }
     }
     __syncthreads();                                           // coefficients are in LDS
+    auto run = [&](auto dxr, auto ndwr, const int dw_first) {
+    constexpr bool DXR = decltype(dxr)::value;                 // this wave may own a dX tile (then: if wave < NDX)
+    constexpr int NDWR = decltype(ndwr)::value;                // dW tiles of this wave: dw_first .. dw_first + NDWR - 1
+    static_assert(NDWR <= NCI || NDWR % NCI == 0, "a wave's dW tiles share a co tile, or cover whole co rows");
+    const bool does_dx = DXR && ((NDX == NW) || wave < NDX);
+    bf16x8 fa[DXR ? KS : 1][2];
+    if (DXR) {
+        const int row = dx_ci * 32 + c;
+        const int chunk = row * 2 + ((kh ^ (row >> 3)) & 1);
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) fa[DXR ? s : 0][pl] = __builtin_bit_cast(bf16x8, a.planes[(long long)(s * 2 + pl) * 256 + chunk]);
+    }
+    f32x16 acc_dw[NDWR > 0 ? NDWR : 1];
+#pragma unroll
+    for (int u = 0; u < (NDWR > 0 ? NDWR : 1); ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_dw[u][r] = 0.f;
     // the two products of one tile from LDS buffer `buf`; returns the tile of dX in acc
     auto multiply = [&](int buf, f32x16& acc) {
         const unsigned char* G1 = smem + buf * BUF;
         const unsigned char* G2 = G1 + 2 * PL1;
         const unsigned char* X2 = G2 + 2 * PL2;
-        if (does_dx) {
+        if (DXR && does_dx) {
             const int pos = dx_pt * 32 + c;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const int off = pos * RB1 + (2 * s + kh) * 16;
                 const f16x8 b0 = *reinterpret_cast<const f16x8*>(G1 + off);
                 const f16x8 b1 = *reinterpret_cast<const f16x8*>(G1 + PL1 + off);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][0]), b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][1]), b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[s][0]), b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[DXR ? s : 0][0]), b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[DXR ? s : 0][1]), b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[DXR ? s : 0][0]), b0, acc, 0, 0, 0);
                 if (KS == 8 && (s & 1)) __builtin_amdgcn_sched_barrier(0);     // keeps hipcc from hoisting all 16 fragment reads (spills)
             }
         }
         // dW[co][ci] += sum_p dY[co][p] act(X)[ci][p]
 #pragma unroll
         for (int s = 0; s < PS; ++s) {
-            const int offA = rows_off<BP>(dw_co * 32 + c, (2 * s + kh) * 8);
-            const f16x8 a0 = *reinterpret_cast<const f16x8*>(G2 + offA);
-            const f16x8 a1 = *reinterpret_cast<const f16x8*>(G2 + PL2 + offA);
+            f16x8 a0, a1;
 #pragma unroll
-            for (int u = 0; u < NDW; ++u) {
-                const int ci_t = (wave * NDW + u) % NCI;
-                const int offB = rows_off<BP>(ci_t * 32 + c, (2 * s + kh) * 8);
+            for (int u = 0; u < NDWR; ++u) {
+                const int T = dw_first + u;
+                if ((NDWR <= NCI) ? (u == 0) : (u % NCI == 0)) {           // a new co tile: its dY^T fragments
+                    const int offA = rows_off<BP>((T / NCI) * 32 + c, (2 * s + kh) * 8);
+                    a0 = *reinterpret_cast<const f16x8*>(G2 + offA);
+                    a1 = *reinterpret_cast<const f16x8*>(G2 + PL2 + offA);
+                }
+                const int offB = rows_off<BP>((T % NCI) * 32 + c, (2 * s + kh) * 8);
                 const f16x8 b0 = *reinterpret_cast<const f16x8*>(X2 + offB);
                 const f16x8 b1 = *reinterpret_cast<const f16x8*>(X2 + PLX + offB);
                 acc_dw[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc_dw[u], 0, 0, 0);
@@ -332,7 +385,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     // lane = position pos of the tile; register r = input channel 32 dx_ci + 8 (r >> 2) + 4 kh + (r & 3): a store
     // instruction writes 32 consecutive positions of two rows
     auto store_dx = [&](int t, const f32x16& acc) {
-        if (!does_dx) return;
+        if (!(DXR && does_dx)) return;
         const int pos = dx_pt * 32 + c;
         int p0;
         const int bb = cloud_of(t, p0);
@@ -342,7 +395,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             const int ci = dx_ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
             const float v = acc[r] * dx_scale;
             orow[(long long)ci * a.P] = v;
-            if (RED) DX[ci * XRS + pos] = v;
+            if (RED) DX[((RED && DB) ? (t & 1) * CIN * XRS : 0) + ci * XRS + pos] = v;
         }
     };
     if (DB) {
@@ -354,6 +407,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if (RED && t > 0) red_pass(t - 1);                 // (the dX buffer and the register copy of X of the previous tile)
             multiply(cur, acc);
             if (t + 1 < ntile) write_tile(cur ^ 1, min(t + 2, ntile - 1), t + 1);   // the next tile, while the MFMAs drain
             store_dx(t, acc);
@@ -363,7 +417,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         }
     } else {
         for (int t = 0; t < ntile; ++t) {
-            if (RED) red_pass();                               // the previous tile (the first time: the zeros written above)
+            if (RED) red_pass(t - 1);                          // the previous tile (the first time: the zeros written above)
             write_tile(0, min(t + 1, ntile - 1), t);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                      // (raw: the loads stay in flight across it)
@@ -379,17 +433,26 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     {
         float* out = a.part + (long long)blockIdx.x * COUT * CIN;
 #pragma unroll
-        for (int u = 0; u < NDW; ++u) {
-            const int ci_t = (wave * NDW + u) % NCI;
+        for (int u = 0; u < NDWR; ++u) {
+            const int T = dw_first + u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = dw_co * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                out[row * CIN + ci_t * 32 + c] = acc_dw[u][r] * dw_scale;
+                const int row = (T / NCI) * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                out[row * CIN + (T % NCI) * 32 + c] = acc_dw[u][r] * dw_scale;
             }
         }
     }
+    };   // run
+    if constexpr (SPLIT) {
+        constexpr int HALF = NW / 2, NDWS = NCO * NCI / HALF;
+        static_assert(NDX == HALF, "SPLIT: one dX tile per wave of the first half");
+        if (wave < HALF) run(std::true_type{}, std::integral_constant<int, 0>{}, 0);
+        else run(std::false_type{}, std::integral_constant<int, NDWS>{}, (wave - HALF) * NDWS);
+    } else {
+        run(std::true_type{}, std::integral_constant<int, NDW>{}, wave * NDW);
+    }
     if (RED) {
-        if (ntile > 0) red_pass();                             // the last tile (behind the loop's closing barrier)
+        if (ntile > 0) red_pass(ntile - 1);                    // the last tile (behind the loop's closing barrier)
         // the XPC threads of a channel are neighbouring lanes; one partial per channel and workgroup
 #pragma unroll
         for (int off = 1; off < XPC; off <<= 1) {
@@ -454,7 +517,9 @@ extern "C" long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, in
 // usip_bn_backward_reduce_f32 / usip_bn_backward_finalize_f32 write with want_bound -- or, when pool_dp / pool_arg are
 // given (dZ = NULL), from dZ[b][co][p] = (p % pool_group == pool_arg[b][co][p / pool_group]) ? pool_dp[b][co][p /
 // pool_group] : 0; act(X) = relu(X xcoef[0] + xcoef[1]), xcoef = the PRODUCING layer's [4][Cin] (scale, shift, mean,
-// invstd) of a training-mode BatchNorm over exactly these nb * P samples.  planes: usip_mlp_split2h_f32 image of W as
+// invstd) of a training-mode BatchNorm over exactly these nb * P samples.  group_sums (pooled form with red_partial, may be
+// NULL; pool_group a multiple of 32): [2][nb * Cin][P / pool_group], per neighbourhood of the PRODUCING layer sum_k dX [relu
+// on] and sum_k X -- what usip_bn_backward_reduce_f32 leaves in `gsum` for a pooled-concat layer.  planes: usip_mlp_split2h_f32 image of W as
 // the data-gradient operand (At = W [Cout][ldw] K-major, M = Cin, K = Cout).  X / dX point at the first of the Cin rows
 // inside [nb][x_rows][P] / [nb][dx_rows][P]; all pointers 16-B aligned.  workspace:
 // usip_mlp_layer_backward_x2h_workspace floats.  red_partial (may be NULL): receives [2][blocks][Cin] partial sums of the
@@ -463,21 +528,22 @@ extern "C" long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, in
 extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
                                                const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
                                                const float* xcoef, const void* planes, float* dX, int dx_rows,
-                                               float* workspace, float* dW, int lddw, float* red_partial, int Cin,
-                                               int Cout, int P, int nb, void* stream)
+                                               float* workspace, float* dW, int lddw, float* red_partial,
+                                               float* group_sums, int Cin, int Cout, int P, int nb, void* stream)
 {
     const bool pooled = pool_dp != nullptr;
     if (!usip_mlp_layer_backward_x2h_supported(Cin, Cout, P, pooled ? 1 : 0) || nb < 1 || x_rows < Cin || dx_rows < Cin ||
         lddw < Cin)
         return USIP_EINVAL;
     if ((!pooled && !dZ) || !Y || !coef4 || !X || !xcoef || !planes || !dX || !workspace || !dW) return USIP_EINVAL;
+    if (group_sums && (!pooled || !red_partial || pool_group % 32 != 0)) return USIP_EINVAL;
     if (pooled && (!pool_arg || pool_group < 1 || P % pool_group != 0)) return USIP_EINVAL;
     if ((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(X) |
          reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(planes)) & 15u)
         return USIP_EINVAL;
     const int blocks = layer_bwd_blocks(Cin, Cout, P, nb);
     LayerBwdArgs a{dZ, Y, coef4, pool_dp, pool_arg, pool_group, X, x_rows, xcoef, reinterpret_cast<const uint4*>(planes),
-                   dX, dx_rows, workspace, red_partial, P, nb};
+                   dX, dx_rows, workspace, red_partial, group_sums, P, nb};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks);
     const bool red = red_partial != nullptr;
@@ -485,11 +551,13 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
         if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
         else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4, 32, false>), grid, dim3(256), 0, st, a);
     } else {
-        if (red) return USIP_EINVAL;
         // (the single-buffer form with 64-position tiles measured the same, 224-230 us at 16 x 32768 positions, and
         // sits on the edge of spilling: 252-256 VGPRs)
-        if (pool_group % 32 == 0)
-            USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true, true>), grid, dim3(512), 0, st, a);
+        if (red && pool_group % 32 != 0) return USIP_EINVAL;
+        if (red)
+            USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, true, 8, 32, false, true, true>), grid, dim3(512), 0, st, a);
+        else if (pool_group % 32 == 0)
+            USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true, true, true>), grid, dim3(512), 0, st, a);
         else
             USIP_LAUNCH((layer_bwd_x2_kernel<128, 128, true, false, 8, 32, true, false>), grid, dim3(512), 0, st, a);
     }

@@ -412,6 +412,8 @@ def as_tensor(x):
 # that a gradient autograd accumulated into in place (a second consumer) is recognised as changed, and the step
 # clears the table when it starts and when it ends -- a stale entry can never meet a recycled address.
 PRE_BN_SUMS = {}
+# the fused backward of a max-pooled layer also takes the sums of the (pooled-concat) layer in front of it
+POOLED_LAYER_RED = _os.environ.get("USIP_POOLED_LAYER_RED", "1") != "0"
 
 
 def _register_pre_bn_sums(dx, partials):
@@ -437,6 +439,12 @@ def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
     pre = _take_pre_bn_sums(dz)                  # removed even when this layer cannot use them
     if pre is not None and group == 0 and relu:
         return ops.bn_backward_from_partials(pre[1], dz.shape[0] * dz.shape[2], coef, mean, invstd, go, bo)
+    if pre is not None and group and relu and len(pre[1]) == 1:
+        # a pooled-concat layer: the producer (the fused backward of a max-pooled layer) also took the
+        # per-neighbourhood sums
+        gsum = getattr(pre[1][0], "gsum", None)
+        if gsum is not None and gsum.shape[3] * group == dz.shape[2]:
+            return ops.bn_backward_from_partials(pre[1], dz.shape[0] * dz.shape[2], coef, mean, invstd, go, bo) + (gsum,)
     dgamma, dbeta, coef4, gsum = ops.bn_backward_reduce(dz, y, coef, mean, invstd, gamma, relu, group=group,
                                                         dgamma_out=go, dbeta_out=bo)
     return (dgamma, dbeta, coef4, gsum) if group else (dgamma, dbeta, coef4)
@@ -603,8 +611,14 @@ class _SharedMLPLayerMax(torch.autograd.Function):
         if (FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[3]
                 and ops.layer_backward_x2_supported(Cin, Cout, M * K, (y, x3), coef4, xcoef, pooled=True)):
             # f32x2: data and weight gradient from ONE pass over (Y, X) -- csrc/layer_bwd_x2.hip
-            dx, dw = ops.mlp_layer_backward_x2(None, y, coef4, x3, xcoef, w2.contiguous(), Cin=Cin, pool=pool,
-                                               dw_out=sink[0].view(w2.shape) if sink else None)
+            # ... which also leaves the producing layer's BatchNorm-backward sums (per channel and per neighbourhood)
+            red = (POOLED_LAYER_RED and FUSED_NARROW_RED and xcoef is not None and xcoef.shape[0] >= 4 and K % 32 == 0
+                   and bool(GRAD_SINK))
+            res = ops.mlp_layer_backward_x2(None, y, coef4, x3, xcoef, w2.contiguous(), Cin=Cin, pool=pool,
+                                            dw_out=sink[0].view(w2.shape) if sink else None, want_red=red, want_gsum=red)
+            dx, dw = res[0], res[1]
+            if red:
+                _register_pre_bn_sums(dx, [res[2]])
             db = torch.zeros_like(gamma) if (ctx.needs_input_grad[4] and not sink) else None
             if sink:
                 dw = db = dgamma = dbeta = None

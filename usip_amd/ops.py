@@ -726,6 +726,7 @@ class RedSums:
         self.flat = flat
         self.sums = flat[:2 * blocks * C].view(2, blocks, C)
         self.maxima = flat[2 * blocks * C:]
+        self.gsum = None                     # per-neighbourhood sums [2,nb,C,G], when the producer took them too
 
 
 def narrow_backward_supported(Cin: int, Cout: int, P: int, tensors=()) -> bool:
@@ -799,11 +800,12 @@ LAYER_BWD_X2 = _os.environ.get("USIP_LAYER_BWD_X2", "1") not in ("0", "off")
 
 
 def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64, want_red: bool = False,
-                          pool=None):
+                          pool=None, want_gsum: bool = False):
     """Fused backward of a <= 128-wide layer with f32x2 products (csrc/layer_bwd_x2.hip): -> (dx [nb,Cin,P], dW[, red]).
     Arguments as mlp_narrow_backward; coef4 [5,Cout] (with bounds), xcoef [4,Cin]; pool = (dpooled [nb,Cout,G],
     arg i32 [nb,Cout,G], group) with dz None for the pooled form.  red: a RedSums (partial sums [2, blocks, Cin] and the
-    workgroups' maxima of |dx [relu on]|)."""
+    workgroups' maxima of |dx [relu on]|); want_gsum (pooled form with red, group % 32 == 0): red.gsum [2,nb,Cin,G] =
+    the per-neighbourhood sums of dx [relu on] and of x that bn_backward_reduce(group=...) would return."""
     nb, Cout, P = y.shape
     dev = y.device
     for t, n in ((y, "y"), (x, "x"), (w2, "w2"), (coef4, "coef4"), (xcoef, "xcoef")):
@@ -816,27 +818,36 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     ws = torch.empty(int(lib.usip_mlp_layer_backward_x2h_workspace(Cin, Cout, P, nb)), dtype=torch.float32, device=dev)
     red = torch.empty(2 * blocks * Cin + blocks, dtype=torch.float32, device=dev) if want_red else None
     planes = weight_planes(w2, wcol, Cin, Cout, 2, P, nb)      # W as the data-gradient operand: K-major [Cout][ldw]
-    pdp = parg = None
+    pdp = parg = gsum = None
     group = 0
     if pool is not None:
         pdp, parg, group = pool
         _need(pdp, "dpooled", torch.float32)
         _need(parg, "arg", torch.int32)
+        if want_gsum:
+            if not want_red or group % 32:
+                raise ValueError("mlp_layer_backward_x2: group sums need want_red and a group that is a multiple of 32")
+            gsum = torch.empty((2, nb, Cin, P // group), dtype=torch.float32, device=dev)
     else:
         _need(dz, "dz", torch.float32)
+    pg = pool is not None and group % 32 == 0
     with torch.cuda.device(dev), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin),
                                              4.0 * Cout * Cin * nb * P,
-                                             rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s, %s> |wg=%d" % (
+                                             rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s, %s, %s> |wg=%d" % (
                                                  Cin, Cout, "true" if pool is not None else "false",
                                                  "true" if want_red else "false", 8 if Cin == 128 else 4,
-                                                 "true" if Cin == 128 else "false",
-                                                 "true" if (pool is not None and group % 32 == 0) else "false", blocks)):
+                                                 "true" if (Cin == 128 and not (want_red and pg)) else "false",
+                                                 "true" if pg else "false", "true" if pg else "false", blocks)):
         _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
             _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
             ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
-            int(dW.shape[1]), _opt(red), Cin, Cout, P, nb, _stream(y)), "usip_mlp_layer_backward_x2h_f32")
-    return (dx, dW, RedSums(red, Cin)) if want_red else (dx, dW)
+            int(dW.shape[1]), _opt(red), _opt(gsum), Cin, Cout, P, nb, _stream(y)), "usip_mlp_layer_backward_x2h_f32")
+    if not want_red:
+        return dx, dW
+    r = RedSums(red, Cin)
+    r.gsum = gsum
+    return dx, dW, r
 
 
 def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bool, yarg=None):
