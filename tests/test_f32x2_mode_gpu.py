@@ -279,7 +279,8 @@ def _bn_layer_inputs(g, nb, C, P, scale=1.0):
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 4096, 64, 0, 1.0), (3, 64, 64, 1024, 128, 64, 1.0), (1, 64, 64, 640, 64, 0, 1e-4),
-                                 (2, 64, 64, 2048, 64, 0, 1e3)])
+                                 (2, 64, 64, 2048, 64, 0, 1e3), (2, 64, 128, 2048, 128, 64, 1.0), (1, 64, 128, 640, 128, 0, 1e-3),
+                                 (3, 64, 128, 1088, 64, 0, 50.0)])
 def test_fused_layer_backward_x2_equals_fp64_truth_and_the_separate_products(cfg):
     """csrc/layer_bwd_x2.hip: data gradient, weight gradient and the producing layer's BatchNorm-backward sums of a
     64-input layer from ONE pass over (dZ, Y, X) with f32x2 products against fp64 truth, against the generic kernels,

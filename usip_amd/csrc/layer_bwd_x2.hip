@@ -499,7 +499,7 @@ extern "C" int usip_mlp_layer_backward_x2h_supported(int Cin, int Cout, int P, i
 {
     if (P <= 0 || P % 64 != 0 || (long long)Cout * P >= (1LL << 30) || (long long)Cin * P >= (1LL << 30)) return 0;
     if (pooled) return (Cin == 128 && Cout == 128) ? 1 : 0;
-    return (Cin == 64 && Cout == 64) ? 1 : 0;
+    return (Cin == 64 && (Cout == 64 || Cout == 128)) ? 1 : 0;
 }
 
 extern "C" int usip_mlp_layer_backward_x2h_blocks(int Cin, int Cout, int P, int nb)
@@ -547,7 +547,12 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks);
     const bool red = red_partial != nullptr;
-    if (Cin == 64) {
+    if (Cin == 64 && Cout == 128) {
+        // the feature half of conv4: two waves for dX (with the 64 registers of weight fragments), two for dW (with its 64)
+        if (pooled) return USIP_EINVAL;
+        if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 128, false, true, 4, 32, false, false, true>), grid, dim3(256), 0, st, a);
+        else USIP_LAUNCH((layer_bwd_x2_kernel<64, 128, false, false, 4, 32, false, false, true>), grid, dim3(256), 0, st, a);
+    } else if (Cin == 64) {
         if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
         else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4, 32, false>), grid, dim3(256), 0, st, a);
     } else {

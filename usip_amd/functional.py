@@ -719,12 +719,14 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         dpooled = dh = dw = None
         if ctx.needs_input_grad[3]:
             dpooled = ops.mlp_gemm(w2c, sdy, tag="dgrad_pooled", M=Cp, a_offset=poff)[0]
-        fused = (FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[4] and ctx.relu
-                 and ops.narrow_backward_supported(Ch, Cout, M * K, (dz, y, h3)))
+        want = FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[4] and ctx.relu
+        x2 = want and ops.layer_backward_x2_supported(Ch, Cout, M * K, (dz, y, h3), coef4, hcoef)
+        fused = x2 or (want and ops.narrow_backward_supported(Ch, Cout, M * K, (dz, y, h3)))
         if fused:                                           # data and weight gradient of the feature half in one pass
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
             red = FUSED_NARROW_RED and hcoef is not None and hcoef.shape[0] >= 4
-            res = ops.mlp_narrow_backward(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch, want_red=red)
+            back = ops.mlp_layer_backward_x2 if x2 else ops.mlp_narrow_backward      # f32x2 (csrc/layer_bwd_x2.hip) / fp32 MFMA
+            res = back(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch, want_red=red)
             if red:
                 _register_pre_bn_sums(res[0], [res[2]])
             dh = res[0].view(ctx.h_shape)
