@@ -787,8 +787,6 @@ def layer_backward_x2_supported(Cin: int, Cout: int, P: int, tensors=(), coef4=N
         return False
     if not _lib.lib().usip_mlp_layer_backward_x2h_supported(int(Cin), int(Cout), int(P), 1 if pooled else 0):
         return False
-    if Cin == 64 and Cout == 128 and not LAYER_BWD_X2_WIDE:
-        return False
     for t in tensors:
         if t is None:
             continue
@@ -799,7 +797,6 @@ def layer_backward_x2_supported(Cin: int, Cout: int, P: int, tensors=(), coef4=N
 
 # f32x2 mode: the fused layer backward on the 16-bit matrix cores; USIP_LAYER_BWD_X2=0 for A/B runs
 LAYER_BWD_X2 = _os.environ.get("USIP_LAYER_BWD_X2", "1") not in ("0", "off")
-LAYER_BWD_X2_WIDE = _os.environ.get("USIP_LAYER_BWD_X2_WIDE", "1") not in ("0", "off")     # ... its 64 -> 128 form
 
 
 def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64, want_red: bool = False,
@@ -841,8 +838,7 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
                                                  Cin, Cout, "true" if pool is not None else "false",
                                                  "true" if want_red else "false", 8 if Cin == 128 else 4,
                                                  "true" if (Cin == 128 and not (want_red and pg)) else "false",
-                                                 "true" if pg else "false",
-                                                 "true" if (pg or (Cin == 64 and Cout == 128)) else "false", blocks)):
+                                                 "true" if pg else "false", "true" if pg else "false", blocks)):
         _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
             _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
             ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
