@@ -1,5 +1,6 @@
 """Repeat three training steps from the same seed N times and report every run that differs from the first in any bit
-(which parameters): hunts rare races.   python tools/repro_stress.py <model> <N>   (USIP_MATMUL_MODE, A/B switches)"""
+(which parameters): hunts rare races.   python tools/repro_stress.py <model> <N> [pairs points nodes]   (USIP_MATMUL_MODE,
+A/B switches; default size: the reproducibility test's 2 pairs x 2048 points, 64 nodes; "8 16384 512" = the bench's)"""
 import os
 import sys
 
@@ -13,8 +14,9 @@ from usip_amd.step import DetectorStep, batch_to_device  # noqa: E402
 DEV = torch.device("cuda", 0)
 ops.set_matmul_mode(os.environ.get("USIP_MATMUL_MODE", "f32x2"))
 model, N = sys.argv[1], int(sys.argv[2])
-opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8)
-batch = batch_to_device(synth.make_pair_batch(21, 2, 2048, 64, 4, "sphere"), DEV)
+pairs, points, nodes = (int(v) for v in sys.argv[3:6]) if len(sys.argv) >= 6 else (2, 2048, 64)
+opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8 if nodes < 512 else 16)
+batch = batch_to_device(synth.make_pair_batch(21, pairs, points, nodes, 4, "sphere" if nodes < 512 else "slab"), DEV)
 
 
 def run():
