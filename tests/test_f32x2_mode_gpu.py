@@ -457,3 +457,47 @@ def test_fused_layer_backward_is_bit_stable_over_repeated_launches():
                 assert all(torch.equal(a, b) for a, b in zip(ref, cur))
     finally:
         ops.set_matmul_mode(prev)
+
+
+def test_streaming_and_split_kernels_are_bit_stable_over_repeated_launches():
+    """The same guard for the other kernels of the Ball front end and the second stage at sizes that fill the chip
+    (two workgroups per CU, several tiles each): 30 launches of each on the same inputs agree in every bit."""
+    from usip_amd import ops
+    g = torch.Generator().manual_seed(9)
+    prev = ops.set_matmul_mode("f32x2")
+
+    def stable(fn, n=30):
+        ref = None
+        for _ in range(n):
+            cur = [t for t in fn() if isinstance(t, torch.Tensor)]
+            ref = ref or [t.clone() for t in cur]
+            assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+
+    try:
+        nb, P, G = 16, 4096, 64
+        for K, M in ((64, 64), (64, 128), (128, 128)):                      # narrow_fwd / gemm_x2r (row bias) / gemm_x2r
+            At = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+            X = (torch.randn(nb, K, P, generator=g) * 3.0 + 1.0).to(DEV)
+            coef = _bn_coef(X, (1 + 0.3 * torch.randn(K, generator=g)).to(DEV), (0.3 * torch.randn(K, generator=g)).to(DEV))
+            bias = (0.1 * torch.randn(M, generator=g)).to(DEV)
+            rb = torch.randn(nb, M, P // G, generator=g).to(DEV) if (K, M) == (64, 128) else None
+            stable(lambda: ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef, rowbias=rb, rb_group=G if rb is not None else 0))
+        # the 64 -> 128 backward that stays on the fp32-MFMA kernel, and a second-stage layer: forward, data and weight gradient
+        y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, 128, P)
+        x, _, _, _, xcoef = _bn_layer_inputs(g, nb, 64, P)
+        dz = torch.randn(nb, 128, P, generator=g).to(DEV)
+        w2 = (torch.randn(128, 64, generator=g) * 0.18).to(DEV)
+        coef4 = ops.bn_backward_reduce(dz, y, coef_y, mean_y, invstd_y, gamma_y, True)[2]
+        stable(lambda: (lambda r: (r[0], r[1], r[2].flat))(ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, want_red=True)))
+        nb2, P2, C = 4, 8192, 256
+        y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb2, C, P2)
+        x, _, _, _, xcoef = _bn_layer_inputs(g, nb2, C, P2)
+        dz = torch.randn(nb2, C, P2, generator=g).to(DEV)
+        w2 = (torch.randn(C, C, generator=g) * 0.09).to(DEV)
+        coef4 = ops.bn_backward_reduce(dz, y, coef_y, mean_y, invstd_y, gamma_y, True)[2]
+        wt = w2.t().contiguous()
+        stable(lambda: ops.mlp_gemm(wt, x, want_stats=True, pro=1, coef=xcoef), 15)
+        stable(lambda: ops.mlp_gemm(w2, dz, pro=2, X2=y, coef=coef4, tag="dgrad"), 15)
+        stable(lambda: (ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef),), 15)
+    finally:
+        ops.set_matmul_mode(prev)
