@@ -279,7 +279,8 @@ def _bn_layer_inputs(g, nb, C, P, scale=1.0):
 
 
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 4096, 64, 0, 1.0), (3, 64, 64, 1024, 128, 64, 1.0), (1, 64, 64, 640, 64, 0, 1e-4),
-                                 (2, 64, 64, 2048, 64, 0, 1e3), (4, 64, 64, 8192, 64, 0, 1.0)])
+                                 (2, 64, 64, 2048, 64, 0, 1e3), (4, 64, 64, 8192, 64, 0, 1.0), (2, 64, 128, 2048, 128, 64, 1.0),
+                                 (1, 64, 128, 640, 128, 0, 1e-3), (3, 64, 128, 1088, 64, 0, 50.0), (4, 64, 128, 8192, 128, 64, 1.0)])
 def test_fused_layer_backward_x2_equals_fp64_truth_and_the_separate_products(cfg):
     """csrc/layer_bwd_x2.hip: data gradient, weight gradient and the producing layer's BatchNorm-backward sums of a
     64-input layer from ONE pass over (dZ, Y, X) with f32x2 products against fp64 truth, against the generic kernels,
@@ -421,25 +422,36 @@ def test_fused_pooled_layer_backward_x2_also_leaves_the_producing_layers_sums(cf
 
 def test_fused_layer_backward_is_bit_stable_over_repeated_launches():
     """40 launches of every fused-backward form on the same inputs, at sizes that put two workgroups on every CU and
-    several tiles on every workgroup, must agree in every bit (a 64 -> 128 form of the kernel passed the fp64-truth tests
-    on one launch and still produced 1-4 slightly wrong tiles of 1024 on most launches: csrc/layer_bwd_x2.hip)."""
+    several tiles on every workgroup, must agree in every bit and with the fp64 truth.  (Built with hipcc's SLP vectoriser
+    the 64 -> 128 form passed the small fp64-truth tests and still produced 1-4 slightly wrong tiles of 1024 on most
+    launches at these sizes -- a packed fp32 FMA with swapped halves going wrong with two waves on a SIMD; the library
+    is compiled with -fno-slp-vectorize since: usip_amd/build.py.)"""
     from usip_amd import ops
     g = torch.Generator().manual_seed(5)
     prev = ops.set_matmul_mode("f32x2")
     try:
         nb, P = 8, 8192
-        y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, 64, P)
-        x, _, _, _, xcoef = _bn_layer_inputs(g, nb, 64, P)
-        dz = torch.randn(nb, 64, P, generator=g).to(DEV)
-        w2 = (torch.randn(64, 128, generator=g) * 0.18).to(DEV)
-        coef4 = ops.bn_backward_reduce(dz, y, coef_y, mean_y, invstd_y, gamma_y, True)[2]
-        ref = None
-        for _ in range(40):
-            dx, dw, red = ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol=64, Cin=64, want_red=True,
-                                                    dw_out=torch.zeros(64, 128, device=DEV))
-            cur = (dx, dw, red.flat)
-            ref = ref or tuple(t.clone() for t in cur)
-            assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+        for Cout in (64, 128):
+            y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, Cout, P)
+            x, _, _, _, xcoef = _bn_layer_inputs(g, nb, 64, P)
+            dz = torch.randn(nb, Cout, P, generator=g).to(DEV)
+            w2 = (torch.randn(Cout, 128, generator=g) * 0.18).to(DEV)
+            coef4 = ops.bn_backward_reduce(dz, y, coef_y, mean_y, invstd_y, gamma_y, True)[2]
+            c = [coef4[i].double().view(1, Cout, 1) for i in range(4)]
+            fma = lambda a_, b_, c_: (a_.double() * b_.double() + c_.double()).float()
+            dyh = torch.where(fma(y, c[0], c[1]) > 0, dz, torch.zeros_like(dz))
+            dy = fma(c[0], dyh, fma(c[2], y, c[3])).double()
+            want_dx = torch.einsum("oc,bop->bcp", w2[:, 64:].double(), dy)
+            for want_red in (True, False):
+                ref = None
+                for _ in range(40):
+                    res = ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol=64, Cin=64, want_red=want_red,
+                                                    dw_out=torch.zeros(Cout, 128, device=DEV))
+                    cur = (res[0], res[1]) + ((res[2].flat,) if want_red else ())
+                    ref = ref or tuple(t.clone() for t in cur)
+                    assert all(torch.equal(a, b) for a, b in zip(ref, cur))
+                assert _rel(ref[0], want_dx) < 2e-6
+                assert float((ref[0].double() - want_dx).abs().max()) < 1e-5 * float(want_dx.abs().max())   # no tile off
         M, K = 128, 64
         y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, 128, M * K)
         x, _, _, _, xcoef = _bn_layer_inputs(g, nb, 128, M * K)

@@ -22,7 +22,8 @@ def bn_inputs(nb, C, P):
 
 ops.set_matmul_mode("f32x2")
 torch.manual_seed(3)
-for Cin, Cout, nb, P, Ctot, wcol in ((64, 64, 4, 4096, 64, 0), (64, 64, 16, 32768, 128, 64), (64, 64, 8, 16384, 64, 0)):
+for Cin, Cout, nb, P, Ctot, wcol in ((64, 64, 4, 4096, 64, 0), (64, 64, 16, 32768, 128, 64), (64, 128, 4, 4096, 128, 64), (64, 128, 16, 32768, 128, 64),
+                                     (64, 128, 8, 16384, 128, 0)):
     y, gy, my, iy, cy = bn_inputs(nb, Cout, P)
     x, gx, mx, ix, xcoef = bn_inputs(nb, Cin, P)
     dz = torch.randn(nb, Cout, P, device=dev)

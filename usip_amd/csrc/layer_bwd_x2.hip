@@ -492,17 +492,17 @@ int layer_bwd_blocks(int Cin, int Cout, int P, int nb)
 }  // namespace
 
 // 1 when usip_mlp_layer_backward_x2h_f32 takes the shape: (Cin, Cout) = (64, 64), or (128, 128) in the pooled form (dZ
-// synthesised from dpooled / arg); positions a multiple of 64.  (The plain (128, 128) form has no caller.  The (64, 128)
-// form -- four waves, 16 output channels per loader thread, with or without the role split -- is NOT offered: with two
-// of its workgroups on a CU 1-4 of 1024 tiles per launch came out with errors of 1e-3 (16 positions of all input rows),
-// different ones on every launch; bit-stable with one workgroup per CU.  Ruled out: stale LDS (poisoned), barrier
-// placement (full __syncthreads), the accumulator / operand register overlap of the first MFMA, the role split, the
-// next-tile loads.  Not understood, so not shipped; narrow_bwd.hip takes that layer.  tools/layer_bwd_race.py.)
+// synthesised from dpooled / arg), or (64, 128) (the feature half of conv4); positions a multiple of 64.  (The plain
+// (128, 128) form has no caller.)  The (64, 128) form was withdrawn for a day: built WITH hipcc's SLP vectoriser it
+// produced 1-4 slightly wrong tiles of 1024 per launch whenever two of its workgroups shared a CU -- a packed
+// `v_pk_fma_f32` with swapped halves (op_sel) evaluating c2 * y + c3 returned c3 in its low half for lanes 48-63.  The
+// library is now compiled with -fno-slp-vectorize (usip_amd/build.py); tools/layer_bwd_race.py and
+// test_fused_layer_backward_is_bit_stable_over_repeated_launches keep watch.
 extern "C" int usip_mlp_layer_backward_x2h_supported(int Cin, int Cout, int P, int pooled)
 {
     if (P <= 0 || P % 64 != 0 || (long long)Cout * P >= (1LL << 30) || (long long)Cin * P >= (1LL << 30)) return 0;
     if (pooled) return (Cin == 128 && Cout == 128) ? 1 : 0;
-    return (Cin == 64 && Cout == 64) ? 1 : 0;
+    return (Cin == 64 && (Cout == 64 || Cout == 128)) ? 1 : 0;
 }
 
 extern "C" int usip_mlp_layer_backward_x2h_blocks(int Cin, int Cout, int P, int nb)
@@ -550,7 +550,12 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks);
     const bool red = red_partial != nullptr;
-    if (Cin == 64) {
+    if (Cin == 64 && Cout == 128) {
+        // the feature half of conv4: two waves for dX (with the 64 registers of weight fragments), two for dW (with its 64)
+        if (pooled) return USIP_EINVAL;
+        if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 128, false, true, 4, 32, false, false, true>), grid, dim3(256), 0, st, a);
+        else USIP_LAUNCH((layer_bwd_x2_kernel<64, 128, false, false, 4, 32, false, false, true>), grid, dim3(256), 0, st, a);
+    } else if (Cin == 64) {
         if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
         else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4, 32, false>), grid, dim3(256), 0, st, a);
     } else {

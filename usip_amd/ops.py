@@ -838,7 +838,8 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
                                                  Cin, Cout, "true" if pool is not None else "false",
                                                  "true" if want_red else "false", 8 if Cin == 128 else 4,
                                                  "true" if (Cin == 128 and not (want_red and pg)) else "false",
-                                                 "true" if pg else "false", "true" if pg else "false", blocks)):
+                                                 "true" if pg else "false",
+                                                 "true" if (pg or (Cin == 64 and Cout == 128)) else "false", blocks)):
         _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
             _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
             ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
