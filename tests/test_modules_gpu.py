@@ -274,7 +274,7 @@ def test_detector_step_gradients_match_reference_with_pinned_decisions(fix, matm
     within the distance two independent fp32 evaluations can have: ref32's own fp32 distance from the truth is one
     evaluation's noise e, `hip` is a second evaluation, so |hip - ref32| <= ~2e.  Bars: per tensor 3x ITS reference
     noise (measured <= 2.9x), and over the whole fixture 2.5x the fixture's worst reference noise (measured <= 2.0x;
-    profiles/r03zg_pinned_grad_errors_*.json; round 2 allowed 4x per tensor).  Three of the five fixtures pass at 1e-5
+    profiles/r03zh_pinned_grad_errors_*.json; round 2 allowed 4x per tensor).  Three of the five fixtures pass at 1e-5
     outright.  The fixture's digests of the reference gradient (first 48 entries, norm, four whole-tensor
     projections) must hold too.  Runs in BOTH fp32-accurate arithmetic modes: fp32 MFMA, and the split-product mode bench.py times
     (forced onto every launch its tile supports, see conftest.matmul_mode)."""
@@ -741,7 +741,7 @@ def test_full_size_f32_and_f32x3_steps_agree():
     every index tensor equal, loss / keypoints / sigmas within 1e-5, BatchNorm buffers within 1e-5, and -- with the
     f32 run's discrete decisions (pool arg-max, near-zero ReLU on/off) handed to the f32x3 run -- every
     parameter gradient entry by entry.  Gradient bars: every tensor within 4e-5 of its scale (measured worst 1.3e-5,
-    profiles/r03zg_full_size_mode_agreement.json: the per-kernel fp64-truth bound of either mode is ~1e-6 per product
+    profiles/r03zh_full_size_mode_agreement.json: the per-kernel fp64-truth bound of either mode is ~1e-6 per product
     and a whole backward chains ~25 of them through BatchNorm's cancelling sums) and the whole gradient bucket
     within 1e-6 in relative norm (measured 1.3e-7)."""
     from usip_amd import functional as Fh
