@@ -386,7 +386,7 @@ int usip_mlp_narrow_backward_f32(const float* dZ, const float* Y, const float* c
                                  int P, int nb, void* stream);
 
 /* The same fused layer backward on the 16-bit matrix cores with f32x2 arithmetic (csrc/layer_bwd_x2.hip; no reference
- * counterpart: the layers' backward is autograd's, models/layers.py:208-216, :293-303), for (Cin, Cout) = (64, 64), or
+ * counterpart: the layers' backward is autograd's, models/layers.py:208-216, :293-303), for (Cin, Cout) = (64, 64), (64, 128), or
  * (128, 128) in the pooled form, and P % 64 == 0 (usip_mlp_layer_backward_x2h_supported).  coef4 = the [5][Cout] array usip_bn_backward_reduce_f32 /
  * usip_bn_backward_finalize_max_f32 write (row 4: bounds of |dY|); pool_dp / pool_arg (i32) [nb][Cout][P / pool_group]
  * given and dZ NULL: the pooled form, dZ = (p % pool_group == arg) ? pool_dp : 0, (128, 128) only; xcoef = the producing

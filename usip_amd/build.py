@@ -34,7 +34,7 @@ def _stale() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
-        glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
+        glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")) + [os.path.abspath(__file__)]   # (the flags)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         deps = [src] + glob.glob(os.path.join(CSRC, "*.h")) + \
-            glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
+            glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h")) + [os.path.abspath(__file__)]
         if not force and os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in deps):
             continue
         cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", obj]
