@@ -10,6 +10,7 @@ GPU, so the ISA is checked here, on CPU, every time the suite runs:
                                 operand, there are NPL * NA DMAs and NXL loads, and the wait in front of the barrier is
                                 vmcnt(NXL) -- "all but the register loads", i.e. the DMA has landed
 """
+import glob
 import os
 import re
 import shutil
@@ -117,14 +118,20 @@ def test_fused_layer_backward_has_no_scratch(tmp_path):
     assert seen == 7
 
 
-@pytest.mark.parametrize("src", ["layer_bwd_x2.hip", "narrow_fwd.hip", "shared_mlp_x3.hip", "group.hip"])
+@pytest.mark.parametrize("src", sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "usip_amd", "csrc", "*.hip"))))
 def test_no_packed_fp32_instruction_selects_halves(src, tmp_path):
     """Packed fp32 arithmetic whose operands pick their halves with op_sel is what hipcc's SLP vectoriser emits when it
     pairs the operations of neighbouring channels and finds the registers in the other order.  One such `v_pk_fma_f32`
     (op_sel:[0,1,0] op_sel_hi:[1,0,1]) in the 64 -> 128 fused layer backward returned c3 for c2 * y + c3 in its low half
     on lanes 48-63, rarely and only with two waves on a SIMD (gfx950, ROCm 7.2).  The library is built with
-    -fno-slp-vectorize; the packed operations written out by hand carry no op_sel.  This keeps it that way."""
+    -fno-slp-vectorize; the packed operations written out by hand never read a high register into a low half.  This
+    keeps it that way, for every translation unit of the library."""
     assert "-fno-slp-vectorize" in FLAGS
     asm = _asm(src, tmp_path)
-    bad = [ln.strip() for ln in asm.split("\n") if re.search(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel", ln)]
+    # op_sel:[..1..] = the LOW half of the result reads the HIGH register of that operand (the failing pattern; a swap
+    # or a broadcast of the high half).  op_sel_hi:[..0..] alone -- the low register broadcast to both halves, what
+    # `q - (f32x2){p, p}` in the hand-written distance loops compiles to -- is left alone: nearest_kernel's distances
+    # are compared bit for bit with the oracle in every run of the suite and have never differed.
+    bad = [ln.strip() for ln in asm.split("\n")
+           if re.search(r"\bv_pk_(fma|mul|add)_f32\b.*\bop_sel:\[[0-9,]*1", ln)]
     assert not bad, bad[:4]

@@ -19,8 +19,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # with op_sel.  On gfx950 (ROCm 7.2) such an instruction -- `v_pk_fma_f32 v[78:79], v[192:193], v[168:169], v[200:201]
 # op_sel:[0,1,0] op_sel_hi:[1,0,1]` in the 64 -> 128 fused layer backward -- returned c3 instead of c2 * y + c3 in its
 # LOW half for lanes 48-63, in 1-4 of 512 workgroups per launch, only with two waves on a SIMD (found by
-# dumping the LDS image of the wrong tiles).  Packed fp32 written out by hand (split_common.h, the distance loops)
-# carries no op_sel and stays; everything else is left scalar.  Measured cost: none (the kernels are not VALU-bound).
+# dumping the LDS image of the wrong tiles).  Packed fp32 written out by hand (split_common.h, the distance loops, the
+# BatchNorm-backward prologue of the split GEMMs) never reads a high register into a low half and stays; everything
+# else is left scalar (tests/test_kernel_isa.py checks every translation unit).  Measured cost: none (the kernels are not VALU-bound).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
