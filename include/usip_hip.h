@@ -35,7 +35,7 @@ const char* usip_version(void);
  * workgroup, prefetch depth, tile order), never the result.  0 restores the library's heuristic.  No reference
  * counterpart.  Returns USIP_EINVAL for an unknown name. */
 enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_X3_WGRAD_TILE, USIP_TUNE_X3_GEMM_TILE,
-       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_COUNT };
+       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_X2_DIRECT, USIP_TUNE_COUNT };
 int usip_set_tuning(const char* name, int value);
 int usip_tuning_value(int knob);
 

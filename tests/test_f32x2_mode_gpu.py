@@ -513,3 +513,99 @@ def test_streaming_and_split_kernels_are_bit_stable_over_repeated_launches():
         stable(lambda: (ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef),), 15)
     finally:
         ops.set_matmul_mode(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: csrc/gemm_x2d.hip -- the same products with the streamed operand going global -> registers -> MFMA.  It takes
+# the launches with 256-row tiles (>= 256 tiles of 256 x 128), which the shapes above are too small for: these shapes
+# fill the chip.  Cases: K with an even / odd number of 16-k stages (two / one stage of loads in flight), a K tail
+# (K % 16 != 0), a partial row tile (M = 300), positions that are not a multiple of the tile (P = 8200) or of 4.
+DIRECT_SHAPES = [(4, 256, 256, 8192), (2, 512, 512, 8192), (4, 272, 256, 8192), (4, 136, 256, 8192), (2, 640, 512, 8192),
+                 (3, 256, 300, 8200), (4, 256, 256, 8191)]
+
+
+def _direct(shape):
+    from usip_amd import _lib
+    nb, K, M, P = shape
+    return _lib.lib().usip_mlp_x3p_tile_rows(M, P, nb) == 256
+
+
+@pytest.mark.parametrize("shape", DIRECT_SHAPES)
+@pytest.mark.parametrize("heavy", [False, True])
+def test_direct_gemm_forward_is_fp32_accurate(shape, heavy, x2_forced):
+    from usip_amd import _lib, ops
+    assert _direct(shape)
+    nb, K, M, P = shape
+    g = torch.Generator().manual_seed(K * 7 + M + P)
+    At = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+    X = torch.randn(nb, K, P, generator=g)
+    if heavy:
+        X = X * torch.exp(1.5 * torch.randn(nb, K, P, generator=g))
+    X = (X * 7.0 + 3.0).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    bias = (0.1 * torch.randn(M, generator=g)).to(DEV)
+    coef = _bn_coef(X, gamma, beta)
+    xin = torch.relu(_fma(X, coef[0].view(1, K, 1), coef[1].view(1, K, 1)))
+    Y, stats = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)
+    want = torch.matmul(At.double().t().unsqueeze(0), xin.double()) + bias.double().view(1, M, 1)
+    _lib.lib().usip_set_tuning(b"x2_direct", 1)            # the LDS-staged kernel of round 3 on the same operands
+    try:
+        Yold, _ = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)
+    finally:
+        _lib.lib().usip_set_tuning(b"x2_direct", 0)
+    prev = ops.set_matmul_mode("f32")
+    Y32, _ = ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)
+    ops.set_matmul_mode(prev)
+    e2, e32 = _rel(Y, want), _rel(Y32, want)
+    assert torch.isfinite(Y).all()
+    assert e2 <= max(5e-7, 2 * e32), (e2, e32)
+    assert e2 < 2e-6
+    assert _rel(Y, Yold) < 1e-6
+    s = stats.double().sum(-1)
+    assert _rel(s[0], Y.double().sum((0, 2))) < 1e-5 and _rel(s[1], (Y.double() ** 2).sum((0, 2))) < 1e-5
+    for _ in range(3):                                     # bit-stable over repeated launches (counted waits, no races)
+        assert torch.equal(ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)[0], Y)
+
+
+@pytest.mark.parametrize("shape", [s for s in DIRECT_SHAPES if s[1] <= 512])
+@pytest.mark.parametrize("gscale", [1.0, 1e-6])
+def test_direct_gemm_backward_is_fp32_accurate(shape, gscale, x2_forced):
+    """pro = 2 and pro = 3 (the gradient synthesised from a max-pool's (dpooled, arg) pair) through the direct kernel."""
+    from usip_amd import _lib, ops
+    assert _direct(shape)
+    nb, K, M, P = shape
+    g = torch.Generator().manual_seed(K * 11 + M + P)
+    W = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+    Yp = (torch.randn(nb, K, P, generator=g) * 2.0 + 0.5).to(DEV)
+    dZ = torch.randn(nb, K, P, generator=g)
+    dZ[torch.rand(nb, K, P, generator=g) < 1e-4] *= 1e3
+    dZ = (dZ * gscale).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    cf = _bn_coef(Yp, gamma, beta)
+    _, _, coef4, _ = ops.bn_backward_reduce(dZ, Yp, cf, cf[2].contiguous(), cf[3].contiguous(), gamma, True)
+    c = [coef4[i].view(1, K, 1) for i in range(4)]
+    dyh = torch.where(_fma(Yp, c[0], c[1]) > 0, dZ, torch.zeros_like(dZ))
+    dy = _fma(c[0], dyh, _fma(c[2], Yp, c[3]))
+    dX, _ = ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4, tag="dgrad")
+    want = torch.matmul(W.double().t().unsqueeze(0), dy.double())
+    prev = ops.set_matmul_mode("f32")
+    dX32, _ = ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4[:4].contiguous(), tag="dgrad")
+    ops.set_matmul_mode(prev)
+    e2, e32 = _rel(dX, want), _rel(dX32, want)
+    assert torch.isfinite(dX).all()
+    assert e2 <= max(5e-7, 2 * e32), (e2, e32)
+    assert e2 < 2e-6
+    for _ in range(3):
+        assert torch.equal(ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4, tag="dgrad")[0], dX)
+    if P % 16 == 0:
+        # pro = 3: dZ[c][m][k] = (k == arg[c][m]) ? dpooled[c][m] : 0 over groups of 16 positions; the same coefficients
+        # applied to that dense tensor give the same arithmetic, so the two launches must agree bit for bit
+        G = 16
+        dp = (torch.randn(nb, K, P // G, generator=g) * gscale).to(DEV)
+        arg = torch.randint(0, G, (nb, K, P // G), generator=g, dtype=torch.int32).to(DEV)
+        dense = torch.zeros(nb, K, P // G, G, device=DEV).scatter_(3, arg.long().unsqueeze(3), dp.unsqueeze(3)).view(nb, K, P)
+        a = ops.mlp_gemm(W, None, pro=3, X2=Yp, coef=coef4, tag="dgrad", pool=(dp, arg, G))[0]
+        b = ops.mlp_gemm(W, dense, pro=2, X2=Yp, coef=coef4, tag="dgrad")[0]
+        assert torch.equal(a, b)

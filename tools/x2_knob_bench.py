@@ -53,7 +53,8 @@ for (M, K, P, nb) in [(512, 512, 8192, 16), (512, 256, 8192, 16), (256, 256, 819
             d = ops.mlp_gemm(Wd, G, pro=2, X2=Yg, coef=c4, tag="dgrad")[0]
             if ref is None:
                 ref, refd = y.clone(), d.clone()
-            print("M=%d K=%d %s=%d: fwd+bnrelu %7.1f us  dgrad %7.1f us  bit-equal to first: %s %s" % (
-                M, K, sys.argv[1], v, t1, t2, bool(torch.equal(y, ref)), bool(torch.equal(d, refd))), flush=True)
+            print("M=%d K=%d %s=%d: fwd+bnrelu %7.1f us  dgrad %7.1f us  bit-equal to first: %s %s  max diff / max: %.2e %.2e" % (
+                M, K, sys.argv[1], v, t1, t2, bool(torch.equal(y, ref)), bool(torch.equal(d, refd)),
+                float((y - ref).abs().max() / ref.abs().max()), float((d - refd).abs().max() / refd.abs().max())), flush=True)
     ops.PLANES_CACHE = None
 _lib.lib().usip_set_tuning(knob, 0)

@@ -1,0 +1,402 @@
+// usip_amd/csrc/gemm_x2d.hip -- the f32x2 forward / data-gradient GEMM of the 256..640-wide shared-MLP layers
+// (models/layers.py:208-216, :293-303, :401-440) with the STREAMED operand going global memory -> registers -> MFMA,
+// never through LDS ("direct").  Round 4; replaces gemm_x3p_kernel<.., 4, 2, 2> of shared_mlp_x3.hip on that path.
+//
+// Why.  The round-3 kernel staged the streamed operand through LDS: load -> BN/ReLU prologue -> fp16 hi/lo split ->
+// ds_write -> barrier -> ds_read -> MFMA.  Its counters (profiles/r03_pmc_x2_gemm.txt) showed a wave parked 41 % of its
+// cycles (s_waitcnt / s_barrier) with the matrix pipe 38 % busy: every 16-k stage put an LDS write -> barrier -> read
+// round trip and a drain of the global loads in front of the next 24 MFMAs, and spent 2.3 VALU + 3 SALU instructions
+// per MFMA on addresses, clamps, conversions back from fp16 and LDS coefficient lookups.
+//
+// What.  Tile 256 channels x 128 positions, four waves, two workgroups per CU -- but each wave owns 32 POSITIONS of
+// ALL 256 channels (8 accumulator tiles of 32 x 32).  The MFMA operand layout of the streamed side (lane = position
+// l & 31, eight consecutive k at 8 (l >> 5)) is then exactly what a lane can load for itself: 8 dword loads per
+// stage, rows (k) at a scalar offset, positions across lanes (two 128-B segments per instruction).  Prologue and split
+// run on those registers and the result IS the MFMA operand.  Consequences:
+//   * no LDS write / barrier / read for the streamed operand; the only shared data is the weight image, which arrives
+//     by LDS-DMA two stages ahead into a four-slot ring, so the per-stage barrier never has a memory wait behind it;
+//   * the prologue of stage kt+1 runs while stage kt's MFMAs issue (the planes of the NEXT stage are prepared one
+//     stage ahead into a second register set; the loop is unrolled by two so that no copies are needed);
+//   * instruction diet: split = v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16 (3 instructions per PAIR instead of 6; the mix
+//     form subtracts the fp16 high part from the fp32 value and rounds the difference to fp16 in one instruction),
+//     coefficients as 16-B broadcast LDS reads ([k][c0, c1(, c2, c3)] interleaved), row offsets as scalar adds,
+//     weight DMA through a buffer descriptor with scalar offsets (no 64-bit vector adds), no clamps unless K % 16 != 0.
+// Arithmetic, scales, plane products and their order are those of shared_mlp_x3.hip (two fp16 planes per operand,
+// three products, smallest first); results differ from it only by fp32 summation order in the statistics.
+#include "mlp_common.h"
+#include "split_common.h"
+
+using namespace usip_mlp;
+
+namespace {
+
+constexpr int DBM = 256, DBN = 128, DNT = 256, DSLOTS = 4;
+constexpr int DPL = DBM * 32;                                  // bytes of one plane of one 16-k stage of the weights
+constexpr int DSTAGE = 2 * DPL;                                // hi + lo
+
+// byte offset of (row, 16-B half) inside a [rows][16 fp16] plane (the image usip_mlp_split2h_f32 writes)
+__device__ __forceinline__ int d_lds_off(int row, int half) { return row * 32 + ((half ^ (row >> 3)) & 1) * 16; }
+
+// two fp32 -> packed fp16 high parts and packed fp16 low parts (x = hi + lo up to 2^-22 |x|), 3 VALU instructions
+__device__ __forceinline__ void split_pair_mix(float x, float y, unsigned& hi, unsigned& lo)
+{
+    const f32x2 v = {x, y};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));          // v_cvt_pk_f16_f32, RNE
+    // lo.lo16 = f16(x - f32(hi.lo16)), lo.hi16 = f16(y - f32(hi.hi16)): the differences are exact in fp32
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(y), "v"(hi));
+}
+
+template <int PRO, int EPI, bool KTAIL, int DEPTH>
+__global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x2d_kernel(
+    const GemmArgs a, const uint4* __restrict__ planes)
+{
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
+    constexpr int NC = TWO ? 4 : 2;                            // prologue coefficients per input channel
+    constexpr int KMAX = TWO ? 512 : 640;
+    constexpr int KPAD = KMAX + 16;
+    constexpr int RING = DSLOTS * DSTAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING + NC * KPAD * 4];
+    float* cf = reinterpret_cast<float*>(smem + RING);         // [k][NC], zero beyond K
+
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // same logical tile order and XCD remap as the other GEMMs of the library
+    const int tpc = (a.P + DBN - 1) / DBN, nmt = (a.M + DBM - 1) / DBM;
+    const int total = a.nb * tpc * nmt;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+    const int mt = L % nmt, tn = L / nmt;
+    const int b = tn / tpc, pt = tn % tpc;
+    const int m0 = mt * DBM, p0 = pt * DBN;
+    const int nk = (a.K + XBK - 1) / XBK;
+    // measurement aid (tools/x2_knob_bench.py, knob x2_direct = 16 / 32 / 48): bit 0 = run only two stages of the main
+    // loop, bit 1 = no epilogue -- wrong results, used to split a launch's time into prologue / loop / epilogue
+    const int dbg = a.a_trans;
+    const int nk_run = (dbg & 1) ? min(nk, 2) : nk;
+
+    // operand scales (see gemm_x3p_kernel): weights carry theirs behind the image, the streamed operand's comes from a
+    // rigorous bound of what the prologue can produce
+    float xs, out_scale;
+    {
+        float* redm = reinterpret_cast<float*>(smem);
+        float bnd = 0.f;
+        if (PRO == PRO_AFFINE_RELU) {
+            const float rn = sqrtf((float)a.nb * (float)a.P);
+            for (int k = tid; k < a.K; k += DNT) {
+                const float c0 = a.coef[k], c1 = a.coef[a.K + k], mu = a.coef[2 * a.K + k], is = a.coef[3 * a.K + k];
+                bnd = fmaxf(bnd, fabsf(c0) / is * rn + fabsf(__builtin_fmaf(mu, c0, c1)));
+            }
+        } else {
+            for (int i = tid; i < (a.K + 63) / 64; i += DNT) bnd = fmaxf(bnd, a.coef[4 * a.K + i]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, off));
+        if (lane == 0) redm[wave] = bnd;
+        __syncthreads();
+        bnd = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        xs = pow2_scale(bnd, X2H_TOP);
+        const float ws = __uint_as_float(planes[(long long)nmt * nk * (DSTAGE / 16)].x);
+        out_scale = 1.0f / (xs * ws);
+        for (int i = tid; i < nk * XBK * NC; i += DNT) {
+            const int k = i / NC, j = i % NC;
+            cf[i] = (k < a.K) ? a.coef[j * a.K + k] * xs : 0.0f;
+        }
+        __syncthreads();                                       // redm is read; the ring may be written from here on
+    }
+
+    // Buffer descriptors as plain SGPR quads (base, stride 0, bytes, raw-buffer flags): every memory instruction of the
+    // main loop is inline asm (see dma_half / load_x1), which takes them as "s" operands.
+    typedef int v4i32 __attribute__((ext_vector_type(4)));
+    auto make_rsrc = [](const void* base, unsigned bytes) {
+        const unsigned long long p = (unsigned long long)reinterpret_cast<uintptr_t>(base);
+        return v4i32{(int)__builtin_amdgcn_readfirstlane((unsigned)p),
+                     (int)__builtin_amdgcn_readfirstlane((unsigned)(p >> 32) & 0xffffu),
+                     (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000};
+    };
+    // weight image of this row tile through a buffer descriptor: a stage is 16 KiB = 4 x (256 lanes x 16 B), wave w
+    // copies chunk rows [w*64, w*64+64) of each quarter: voffset = tid * 16, scalar offset = stage and quarter
+    const v4i32 rAv = make_rsrc(planes + (long long)mt * nk * (DSTAGE / 16), (unsigned)nk * DSTAGE);
+    const int a_voff = tid * 16;
+
+    // streamed operand: lane = (position c of the wave's 32, k-half h)
+    const unsigned pc = (unsigned)min(p0 + wave * 32 + c, a.P - 1);
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const unsigned cloud_bytes = (unsigned)a.K * (unsigned)a.P * 4u, pool_bytes = (unsigned)a.K * (unsigned)pgrp * 4u;
+    const v4i32 rX = make_rsrc((POOL ? a.X2 : a.X) + (long long)b * a.K * a.P, cloud_bytes);
+    const v4i32 rX2 = make_rsrc((TWO ? a.X2 : a.X) + (long long)b * a.K * a.P, cloud_bytes);
+    const v4i32 rPd = make_rsrc(POOL ? a.pool_dp + (long long)b * a.K * pgrp : a.X, POOL ? pool_bytes : 4u);
+    const v4i32 rPa = make_rsrc(POOL ? (const float*)(a.pool_arg + (long long)b * a.K * pgrp) : a.X, POOL ? pool_bytes : 4u);
+    const int rs = a.P * 4, rsg = pgrp * 4;                    // row strides in bytes
+    const int xoff = (int)(pc * 4u), goff = POOL ? (int)((pc / (unsigned)a.pool_group) * 4u) : 0;
+    const int xvoff = xoff + h * 8 * rs, gvoff = goff + h * 8 * rsg;
+    const int xkin = POOL ? (int)(pc % (unsigned)a.pool_group) : 0;
+
+    // DEPTH register sets of raw operand values: the loads run DEPTH stages ahead of their conversion.  One stage of one
+    // wave is 8 x 256 B; a CU (8 waves) keeps DEPTH x 16 KiB in flight, and tools/l2_cu_bw.hip shows that HBM needs
+    // ~32 KiB per CU in flight before it delivers its 24 GB/s per CU (16 KiB: 18).
+    struct XSet { float rx[8]; float ry[TWO ? 8 : 1]; int rarg[POOL ? 8 : 1]; };
+    XSet xs0, xs1;
+    auto load_x1 = [&](int kt, XSet& S, int i) {               // element i (row kt*16 + 8h + i) of stage kt
+        const int kb = kt * XBK;
+        int vo = xvoff, so = (kb + i) * rs, vg = gvoff, sg = (kb + i) * rsg;
+        if (KTAIL) {                                           // rows beyond K: clamp per lane (finite data for zero weights)
+            const int k = min(kb + h * 8 + i, a.K - 1);
+            vo = xoff + k * rs; so = 0; vg = goff + k * rsg; sg = 0;
+        }
+        // inline asm: the compiler neither counts these loads nor waits for them -- x_wait() does, with exact counts
+        if (POOL) {
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.rx[i]) : "v"(vg), "s"(rPd), "s"(sg) : "memory");
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.rarg[POOL ? i : 0]) : "v"(vg), "s"(rPa), "s"(sg) : "memory");
+        } else {
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.rx[i]) : "v"(vo), "s"(rX), "s"(so) : "memory");
+        }
+        if (TWO) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.ry[TWO ? i : 0]) : "v"(vo), "s"(rX2), "s"(so) : "memory");
+    };
+    // Memory instructions of one stage, in issue order: 4 DMA (slots 0, 1), then the NX register loads, element by
+    // element, each right after the element's old value was consumed.  When element e of stage kt+1 is needed, what was
+    // issued after its loads is: the rest of that stage's elements, DEPTH-1 whole stages, and this stage's DMA and
+    // earlier elements -- (NX - q) + 4 + (DEPTH - 1)(NX + 4) instructions, whichever element (q = loads per element).
+    constexpr int NXQ = POOL ? 3 : (TWO ? 2 : 1);
+    constexpr int XWAIT = (8 * NXQ - (TWO ? NXQ : 2 * NXQ)) + 4 + (DEPTH - 1) * (8 * NXQ + 4);
+    auto x_wait = [&](XSet& S, int i) {                        // element i (TWO) / elements i, i+1 (pairs) have landed
+        if (POOL) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(S.rx[i]), "+v"(S.ry[TWO ? i : 0]), "+v"(S.rarg[POOL ? i : 0]) : "n"(XWAIT) : "memory");
+        else if (TWO) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.rx[i]), "+v"(S.ry[TWO ? i : 0]) : "n"(XWAIT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.rx[i]), "+v"(S.rx[i + 1]) : "n"(XWAIT) : "memory");
+    };
+    auto load_x = [&](int kt, XSet& S) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) load_x1(kt, S, i);
+    };
+    // Every load in flight has landed.  The register operands matter: an asm load's destination is, for the compiler, an
+    // ordinary value that is dead after its last use -- without them it re-used the registers of the last (redundant)
+    // loads for copies of the accumulators while those loads were still in flight (r04d: two registers of one
+    // accumulator tile wrong in a fifth of the workgroups, only with two workgroups per CU), and it may move reads of
+    // the registers in front of a wait they do not depend on.
+    auto x_drain = [&](XSet& S) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.rx[0]), "+v"(S.rx[1]), "+v"(S.rx[2]), "+v"(S.rx[3]), "+v"(S.rx[4]),
+                     "+v"(S.rx[5]), "+v"(S.rx[6]), "+v"(S.rx[7]) :: "memory");
+        if (TWO) asm volatile("" : "+v"(S.ry[0]), "+v"(S.ry[TWO ? 1 : 0]), "+v"(S.ry[TWO ? 2 : 0]), "+v"(S.ry[TWO ? 3 : 0]),
+                              "+v"(S.ry[TWO ? 4 : 0]), "+v"(S.ry[TWO ? 5 : 0]), "+v"(S.ry[TWO ? 6 : 0]), "+v"(S.ry[TWO ? 7 : 0]));
+        if (POOL) asm volatile("" : "+v"(S.rarg[0]), "+v"(S.rarg[POOL ? 1 : 0]), "+v"(S.rarg[POOL ? 2 : 0]),
+                               "+v"(S.rarg[POOL ? 3 : 0]), "+v"(S.rarg[POOL ? 4 : 0]), "+v"(S.rarg[POOL ? 5 : 0]),
+                               "+v"(S.rarg[POOL ? 6 : 0]), "+v"(S.rarg[POOL ? 7 : 0]));
+    };
+    // prologue of element i / split of pair j of the stage in S -> packed fp16 planes (the MFMA operand of the lane);
+    // cq: the coefficients of the stage for this half-wave, TWO: one float4 (c0..c3) per k, else one per PAIR of k
+    const float4* cfl = reinterpret_cast<const float4*>(cf) + h * (8 * NC / 4);
+    float4 cq[TWO ? 8 : 4];
+    float cv[8];
+    auto cf_read = [&](int kt, int i) { cq[i] = cfl[kt * (XBK * NC / 4) + i]; };
+    auto conv_elem = [&](const XSet& S, int i) {
+        if (TWO) {
+            float x = S.rx[i];
+            if (POOL) x = (S.rarg[POOL ? i : 0] == xkin) ? x : 0.f;
+            const float4 c4 = cq[TWO ? i : 0];
+            cv[i] = pro_apply<PRO_BN_BWD>(x, S.ry[TWO ? i : 0], c4.x, c4.y, c4.z, c4.w);
+        } else {
+            const float4 c4 = cq[TWO ? 0 : i / 2];
+            cv[i] = (i & 1) ? pro_apply<PRO_AFFINE_RELU>(S.rx[i], 0.f, c4.z, c4.w, 0.f, 0.f)
+                            : pro_apply<PRO_AFFINE_RELU>(S.rx[i], 0.f, c4.x, c4.y, 0.f, 0.f);
+        }
+    };
+    auto convert_all = [&](int kt, const XSet& S, unsigned (&ph)[4], unsigned (&pl)[4]) {
+#pragma unroll
+        for (int i = 0; i < (TWO ? 8 : 4); ++i) cf_read(kt, i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) conv_elem(S, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair_mix(cv[2 * j], cv[2 * j + 1], ph[j], pl[j]);
+    };
+
+    f32x16 acc[8][1];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] = 0.0f;
+
+    // weight fragment of channel tile t: row t*32 + c, half h; (row >> 3) & 1 does not depend on t
+    const int fa0 = d_lds_off(c, h);
+    // fragments of one PAIR of channel tiles (2u, 2u+1): 16 registers; two sets, used alternately
+    struct Frag { f16x8 lo[2], hi[2]; };
+    Frag FA, FB;
+    auto read_pair = [&](int kt, int u, int half, Frag& F) {
+        const unsigned char* As = smem + (kt & (DSLOTS - 1)) * DSTAGE + fa0 + u * 2048;
+        if (half == 0) {
+            F.lo[0] = *reinterpret_cast<const f16x8*>(As + DPL);
+            F.lo[1] = *reinterpret_cast<const f16x8*>(As + DPL + 1024);
+        } else {
+            F.hi[0] = *reinterpret_cast<const f16x8*>(As);
+            F.hi[1] = *reinterpret_cast<const f16x8*>(As + 1024);
+        }
+    };
+    // The weight DMA is inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint
+    // from a pending LDS-DMA it knows about (here: the coefficient reads) -- a drain of every load in flight, once per
+    // stage.  What has landed when is this kernel's own business (the counted wait in front of the barrier).
+    const unsigned ring_lds = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
+    auto dma_half = [&](int kt, int hf) {
+        const unsigned dst = ring_lds + (unsigned)((kt & (DSLOTS - 1)) * DSTAGE) + (unsigned)(wave * 1024);
+#pragma unroll
+        for (int j = 2 * hf; j < 2 * hf + 2; ++j)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                         :: "s"(dst + j * 4096), "v"(a_voff), "s"(rAv), "s"(kt * DSTAGE + j * 4096) : "memory");
+    };
+    constexpr int NX = POOL ? 24 : (TWO ? 16 : 8);             // register loads of one stage of the streamed operand
+
+    // One 16-k stage = 24 MFMAs in program order, each followed by the few other instructions that issue while it runs
+    // (an in-order wave hides ~5 issue slots behind a 32-cycle MFMA; the matrix instructions are inline asm, which the
+    // compiler would otherwise bunch: eight back to back, the conversion after them -- nothing overlapped, measured equal
+    // to the LDS-staged kernel).  The 8 channel tiles are taken in PAIRS (2u, 2u+1), six MFMAs per pair: X_hi.A_lo,
+    // X_lo.A_hi, X_hi.A_hi for both tiles (smallest terms first; dependent MFMAs are two apart), so that only 16
+    // fragment registers are in use and 16 more hold the next pair, read from LDS a pair ahead.  sched_barrier(0)
+    // after every slot pins the order.
+    //   slots  0..17  pairs 0-2; fillers: weight DMA of stage kt+2, fragment reads of the next pair, coefficients,
+    //                 prologue + split of stage kt+1 into the other plane set, operand loads of stage kt+1+DEPTH (each
+    //                 register is reloaded right after its value is used)
+    //   barrier       every wave's DMA of stage kt+1 has landed (counted wait: only what was issued after it may be
+    //                 outstanding: the loads of two stages and one DMA)
+    //   slots 18..23  pair 3; fillers: fragment reads of pair 0 of stage kt+1
+    auto stage = [&](int kt, XSet& S, const unsigned (&ch)[4], const unsigned (&cl)[4], unsigned (&nh)[4], unsigned (&nl)[4]) {
+        const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(ch[0], ch[1], ch[2], ch[3]));
+        const f16x8 xl = __builtin_bit_cast(f16x8, make_uint4(cl[0], cl[1], cl[2], cl[3]));
+        const int k1 = min(kt + 1, nk - 1), k2 = min(kt + 2, nk - 1), kx = min(kt + 1 + DEPTH, nk - 1);
+        auto mfma = [&](int sl) {
+            const int u = sl / 6, i = sl % 6, t = 2 * u + (i & 1);
+            Frag& F = (u & 1) ? FB : FA;
+            const f16x8& x = (i / 2 == 1) ? xl : xh;
+            const f16x8& f = (i / 2 == 0) ? F.lo[i & 1] : F.hi[i & 1];
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t][0]) : "v"(x), "v"(f));
+        };
+        auto filler = [&](int sl) {
+            const int u = sl / 6, i = sl % 6;
+            // fragments of the next pair: (u+1) of this stage into the other set, or pair 0 of stage kt+1 into FA
+            if (i < 2) {
+                if (u < 3) read_pair(kt, u + 1, i, (u & 1) ? FA : FB);
+                else read_pair(kt + 1, 0, i, FA);
+            }
+            if (sl < 2) dma_half(k2, sl);
+            if (!TWO) {
+                if (sl == 2) { cf_read(k1, 0); cf_read(k1, 1); cf_read(k1, 2); cf_read(k1, 3); }
+                constexpr int CA[4] = {3, 5, 9, 11}, CB[4] = {4, 8, 10, 14};      // slots of pair j: prologue / split + reload
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (sl == CA[j]) { x_wait(S, 2 * j); conv_elem(S, 2 * j); conv_elem(S, 2 * j + 1); }
+                    if (sl == CB[j]) {
+                        split_pair_mix(cv[2 * j], cv[2 * j + 1], nh[j], nl[j]);
+                        load_x1(kx, S, 2 * j); load_x1(kx, S, 2 * j + 1);
+                    }
+                }
+            } else {
+                // 8 prologues of 5 instructions, 4 splits of 3; a coefficient quad is read two slots before its use
+                constexpr int CR[8] = {0, 0, 1, 3, 4, 6, 8, 9}, CE[8] = {2, 3, 5, 7, 8, 10, 12, 13}, CS[4] = {4, 9, 11, 14};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (sl == CR[e]) cf_read(k1, e);
+                    if (sl == CE[e]) { x_wait(S, e); conv_elem(S, e); }
+                    if (sl == CE[e] + 1) load_x1(kx, S, e);       // its registers are free again
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (sl == CS[j]) split_pair_mix(cv[2 * j], cv[2 * j + 1], nh[j], nl[j]);
+            }
+        };
+#define USIP_X2D_SLOT(N_)                                              \
+        mfma(N_);                                                      \
+        filler(N_);                                                    \
+        __builtin_amdgcn_sched_barrier(0);
+        USIP_X2D_SLOT(0) USIP_X2D_SLOT(1) USIP_X2D_SLOT(2) USIP_X2D_SLOT(3) USIP_X2D_SLOT(4) USIP_X2D_SLOT(5)
+        USIP_X2D_SLOT(6) USIP_X2D_SLOT(7) USIP_X2D_SLOT(8) USIP_X2D_SLOT(9) USIP_X2D_SLOT(10) USIP_X2D_SLOT(11)
+        USIP_X2D_SLOT(12) USIP_X2D_SLOT(13) USIP_X2D_SLOT(14) USIP_X2D_SLOT(15) USIP_X2D_SLOT(16) USIP_X2D_SLOT(17)
+        // this wave's DMA of stage kt+1 has landed: everything issued after it (two stages of loads, one DMA) may stay
+        // in flight across the barrier (__syncthreads() would drain it); lgkmcnt(0): its reads of the slot are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * NX) : "memory");
+        __builtin_amdgcn_s_barrier();
+        USIP_X2D_SLOT(18) USIP_X2D_SLOT(19) USIP_X2D_SLOT(20) USIP_X2D_SLOT(21) USIP_X2D_SLOT(22) USIP_X2D_SLOT(23)
+#undef USIP_X2D_SLOT
+    };
+
+    unsigned ah[4], al[4], bh[4], bl[4];
+    dma_half(0, 0); dma_half(0, 1);
+    dma_half(min(1, nk - 1), 0); dma_half(min(1, nk - 1), 1);
+    load_x(0, xs0);
+    x_drain(xs0);                                              // (asm loads and DMA: invisible to the compiler's own waits)
+    convert_all(0, xs0, ah, al);
+    __syncthreads();                                           // stages 0 and 1 of the weights have landed (all waves)
+    load_x(min(1, nk - 1), xs1);                               // stage s lives in set s & 1 (DEPTH 2) / always xs1 (DEPTH 1)
+    if (DEPTH == 2) {
+        // x_wait() counts instructions, so the issue order before the loop must be the loop's: loads, DMA, loads, ...
+        // (a repeat of the DMA of stage 1: the same bytes into the same slot, landed before anyone reads it)
+        dma_half(min(1, nk - 1), 0); dma_half(min(1, nk - 1), 1);
+        load_x(min(2, nk - 1), xs0);
+    }
+    read_pair(0, 0, 0, FA); read_pair(0, 0, 1, FA);
+    if constexpr (DEPTH == 2) {
+        // two stages per trip (nk is even: the launcher sends odd nk to DEPTH 1): register sets and plane sets swap roles
+        for (int kt = 0; kt < nk_run; kt += 2) {
+            stage(kt, xs1, ah, al, bh, bl);
+            stage(kt + 1, xs0, bh, bl, ah, al);
+        }
+    } else {
+        for (int kt = 0; kt < nk_run; ++kt) {
+            stage(kt, xs1, ah, al, bh, bl);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ah[j] = bh[j]; al[j] = bl[j]; }
+        }
+    }
+    // the clamped repeats of the last DMA / loads (both register sets stay reserved until everything has landed: the
+    // second drain's operands keep the other set alive across the first one's wait)
+    x_drain(xs1);
+    if (DEPTH == 2) x_drain(xs0);
+    __syncthreads();                                           // the ring is scratch from here on
+    // The MFMAs are inline asm (accumulators pinned to AGPRs: with them in the unified file hipcc shuffled and spilled
+    // accumulator tuples in the data-gradient forms), so the compiler does not know that the instructions before this
+    // point are matrix instructions whose results need up to 18 wait states before a v_accvgpr_read: wait by hand.
+#pragma unroll
+    for (int t = 0; t < 8; ++t) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(acc[t][0]));
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][0][r] *= out_scale;
+    if (dbg & 2) {
+        if (a.P == -12345) a.Y[tid] = acc[0][0][0] + acc[1][0][1] + acc[2][0][2] + acc[3][0][3] + acc[4][0][4] + acc[5][0][5] +
+                                      acc[6][0][6] + acc[7][0][7];
+        return;
+    }
+    gemm_epilogue<1, 4, EPI, 8, 1>(a, acc, reinterpret_cast<float*>(smem), (RING + NC * KPAD * 4) / 4, b, m0, p0, tn, tpc);
+}
+
+}  // namespace
+
+namespace usip_mlp {
+
+int launch_gemm_x2d(const GemmArgs& a_in, const uint4* pl, int pro, hipStream_t st)
+{
+    GemmArgs a = a_in;
+    a.a_trans = usip_tuning_value(USIP_TUNE_X2_DIRECT) >> 4;   // measurement aid, see the kernel (0 in the product)
+    const int tpc = (a.P + DBN - 1) / DBN, nmt = (a.M + DBM - 1) / DBM;
+    const long long total = (long long)a.nb * tpc * nmt;
+    if (total > 0x7fffffffLL || (long long)a.K * a.P * 4 >= (1LL << 31)) return USIP_EINVAL;
+    const int epi = a.stats ? EPI_STATS : EPI_NONE;
+    const bool tail = (a.K % XBK) != 0;
+    // two stages of operand loads in flight (DEPTH 2) needs an even number of stages; knob x2_direct = 2: DEPTH 1
+    const bool deep = !tail && ((a.K / XBK) % 2 == 0) && usip_tuning_value(USIP_TUNE_X2_DIRECT) != 2;
+    dim3 grid((unsigned)total), block(DNT);
+#define USIP_X2D_CASE(P_, E_)                                                                  \
+    if (pro == P_ && epi == E_) {                                                              \
+        if (tail) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, true, 1>), grid, block, 0, st, a, pl);  \
+        else if (deep) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, false, 2>), grid, block, 0, st, a, pl); \
+        else USIP_LAUNCH((gemm_x2d_kernel<P_, E_, false, 1>), grid, block, 0, st, a, pl);      \
+        USIP_LAUNCH_CHECK();                                                                   \
+        return USIP_OK;                                                                        \
+    }
+    USIP_X2D_CASE(PRO_AFFINE_RELU, EPI_STATS)
+    USIP_X2D_CASE(PRO_AFFINE_RELU, EPI_NONE)
+    USIP_X2D_CASE(PRO_BN_BWD, EPI_NONE)
+    USIP_X2D_CASE(PRO_BN_BWD_POOL, EPI_NONE)
+#undef USIP_X2D_CASE
+    return USIP_EINVAL;
+}
+
+}  // namespace usip_mlp

@@ -55,11 +55,13 @@ enum { EPI_NONE = 0, EPI_STATS = 1 };
 //     instead of a 32-lane reduction per accumulator register.
 // `scratch` is LDS the main loop no longer needs (>= 2*WN*BM floats; what is left holds the tile's row bias when
 // it fits).
-template <int WM, int WN, int EPI, int TM = 2>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][2], float* scratch,
+// NJ = 32-position tiles per wave (2: a wave covers 64 positions; 1: gemm_x2d.hip, a wave covers 32 positions of
+// every channel of the tile).
+template <int WM, int WN, int EPI, int TM = 2, int NJ = 2>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[TM][NJ], float* scratch,
                                               int scratch_floats, int b, int m0, int p0, int tn, int tpc)
 {
-    constexpr int BM = WM * 32 * TM, BN = WN * 64;
+    constexpr int BM = WM * 32 * TM, BN = WN * 32 * NJ;
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -90,10 +92,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
         float* yrow = Yb + (long long)rowc * a.P;
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int pb = p0 + wn * 64 + j * 32 + 8 * g + 4 * half;   // first position of the run
+                const int pb = p0 + wn * (32 * NJ) + j * 32 + 8 * g + 4 * half;   // first position of the run
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv;
@@ -224,6 +226,9 @@ int launch_wgrad_x3(const WgradArgs& a, int pro, bool xpro, bool vec, unsigned b
 // 256 x 256 tiles, own slicing (shared_mlp_x3.hip); needs the vector path (P % 4 == 0, 16-B aligned operands)
 void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* tiles);
 int launch_wgrad_x3_256(const WgradArgs& a, int pro, bool xpro, unsigned blocks, hipStream_t st);
+// f32x2 forward / data gradient with the streamed operand global -> registers -> MFMA (gemm_x2d.hip); `pl` = the
+// usip_mlp_split2h_f32 image with 256-row tiles; tiles of 256 channels x 128 positions
+int launch_gemm_x2d(const GemmArgs& a, const uint4* pl, int pro, hipStream_t st);
 // the same from two fp16 planes per operand (pro 2 / 3 with the [5][M] coef4, xcoef = [4][N] batch statistics)
 int launch_wgrad_x2h_256(const WgradArgs& a, int pro, unsigned blocks, hipStream_t st);
 
