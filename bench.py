@@ -37,8 +37,6 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3         # f32-in MFMA / f32 vector peak
 PEAK_BF16_TFLOPS = 2500.0
-CU_PATH_GBPS = 6400.0           # what 256 CUs' vector memory paths carry together (~25 GB/s each, L2 hits included):
-#                                 the rate every streaming kernel of this library tops out at
 
 
 def parse():
@@ -78,6 +76,8 @@ def parse():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true",
+                    help="skip the 10-step run of the same step with fp32 MFMA everywhere (`fp32_mfma_only` in the line)")
     ap.add_argument("--no-kernel-leg", action="store_true",
                     help="skip the stand-alone roofline leg of the two HBM-bound integer kernels the north star names "
                          "(dist-in ball_query, index_max), which runs after the timed region at N=1")
@@ -188,45 +188,70 @@ def kernel_leg(dev, traffic_db, iters=12):
     return rows
 
 
-def cpu_baseline(args, model):
+def cpu_baseline(args, model, dev=None):
     """the oracle (PyTorch-CPU restatement of the same step, proven equal to the reference by the golden
     fixtures) on a bounded sample -- 1 pair = 2 clouds of the same workload -- for BOTH detectors: (A)
     RPN_Detector_Ball, the K=64 headline model, and (B) RPN_Detector, the reference's default.  3 warm-up + 5 timed
-    steps each, median.  `value` is the model this run benchmarks; the other is under `models`."""
+    steps each, median.  `value` is the model this run benchmarks; the other is under `models`.
+
+    The oracle's result for the benchmarked model is not thrown away: the HIP step (eager, the arithmetic mode this run
+    times) runs on the SAME pair with the SAME parameters and `parity_check` reports what the parity tests assert --
+    every index tensor equal, floats relative to the tensor's scale -- at the size the bench times (N=16384, M=512)."""
     import numpy as np
     from oracle import detector as od
     from usip_amd import synth
-    from usip_amd.networks import detector_param_shapes
+    from usip_amd.networks import DetectorOptions, detector_param_shapes
     # ATen's strided reductions oversubscribe badly on a many-core host (62 s/step with 256
     # threads vs ~5 s with 8-16): use at most 16 threads and report that count next to the host's.
     host_cores = os.cpu_count() or 1
     cores = min(host_cores, 16)
     torch.set_num_threads(cores)
-    batch = {k: torch.from_numpy(v) for k, v in
-             synth.make_pair_batch(99, 1, args.n, args.m, 4, args.cloud).items()}
-    res = {}
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=16)
+    batch_np = synth.make_pair_batch(99, 1, args.n, args.m, 4, args.cloud)
+    batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    me = model if model in ("ball", "som") else "ball"
+    res, parity = {}, None
     for mdl in ("ball", "som"):
         filled = synth.fill_parameters(detector_param_shapes(mdl, 4))
         P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
              if not ("running_" in k or "num_batches" in k)}
         bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
-        times = []
+        times, last = [], None
         for i in range(3 + 5):
             for p in P.values():
                 p.grad = None
             t0 = time.perf_counter()
-            od.detector_step(P, bufs, batch, mdl, 16, 1e-3, 0.01)
+            last = od.detector_step(P, bufs, batch, mdl, opt.node_knn_k_1, opt.loss_sigma_lower_bound,
+                                    opt.keypoint_on_pc_alpha)
             times.append(time.perf_counter() - t0)
         t = sorted(times[3:])
         res[mdl] = dict(value=2.0 / t[len(t) // 2], s_per_step=round(t[len(t) // 2], 3), p10=round(t[0], 3),
                         p90=round(t[-1], 3))
-    me = model if model in res else "ball"
+        if mdl == me and dev is not None:
+            from usip_amd.step import DetectorStep, batch_to_device
+            st = DetectorStep(mdl, opt, dev)
+            st.load_numpy_state(filled)
+            st.step(batch_to_device(batch_np, dev))
+            torch.cuda.synchronize()
+            idx_equal, worst, names = {}, {}, ("node", "keypoints", "sigmas", "loss", "loss_chamfer", "chamfer_pure",
+                                                 "chamfer_weighted")
+            for k, v in st.detector.last_indices.items():
+                idx_equal[k] = bool(np.array_equal(v.cpu().numpy(), last[k].numpy()))
+            for k in names:
+                a_, b_ = st.last[k].detach().double().cpu().numpy(), last[k].detach().double().numpy()
+                worst[k] = float(np.abs(a_ - b_).max() / max(float(np.abs(b_).max()), 1e-30))
+            parity = dict(model={"ball": "RPN_Detector_Ball", "som": "RPN_Detector"}[mdl], pairs=1, n=args.n, m=args.m,
+                          indices_equal=all(idx_equal.values()), index_tensors=idx_equal,
+                          max_rel=max(worst.values()), rel_by_tensor={k: float("%.3e" % v) for k, v in worst.items()},
+                          bar="indices bit-exact, floats <= 1e-5 of the tensor's scale (tests/conftest.py::assert_close)",
+                          ok=bool(all(idx_equal.values()) and max(worst.values()) <= 1e-5))
+            del st
     return dict(value=res[me]["value"], unit="point-clouds/s", cores=cores, host_cores=host_cores, kind="port",
                 thread_cap="16 (ATen's strided reductions slow down beyond that: 62 s/step at 256 threads vs ~6 s)",
                 models={"RPN_Detector_Ball": res["ball"], "RPN_Detector": res["som"]},
                 sample="1 pair (2 clouds) N=%d M=%d, oracle/detector.py fwd+losses+bwd, median of 5 after 3 warm-up; "
                        "value = %s (%.2f s/step)" % (args.n, args.m, {"ball": "RPN_Detector_Ball", "som": "RPN_Detector"}[me],
-                                                     res[me]["s_per_step"]))
+                                                     res[me]["s_per_step"])), parity
 
 
 def spawn_ranks(n):
@@ -428,9 +453,10 @@ def main():
             "vs_baseline": None,
             "dtype": {"f32": "f32", "f32x3": "f32 (matrix-bound products as six bf16-plane MFMAs of an exact three-way "
                                              "split, fp32 accumulate: fp32-accurate)",
-                      "f32x2": "f32 (matrix-bound products as three fp16-plane MFMAs of a two-way split with exact "
-                               "power-of-two operand scaling, fp32 accumulate: fp32-accurate; launches without an operand "
-                               "bound as six bf16-plane MFMAs)",
+                      "f32x2": "f32 results; matrix-bound products emulated from 2 fp16 planes per operand (22-bit "
+                               "operands, 3 plane products, exact power-of-two operand scaling, fp32 accumulate; launches "
+                               "without an operand bound: 3 bf16 planes / 6 products); fp32_mfma_only = the same step with "
+                               "fp32 MFMA everywhere",
                       "bf16": "bf16 multiply, f32 accumulate and storage (perf mode)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("KITTI descriptor head N=%d, 256 keypoints, K=64, batch=%d pairs/GPU (BASELINE "
@@ -478,13 +504,16 @@ def main():
             pick = lambda q: per_step[min(len(per_step) - 1, int(q * len(per_step)))]
             out["step_ms_rank0"] = {"p10": round(pick(0.1), 4), "median": round(pick(0.5), 4), "p90": round(pick(0.9), 4),
                                     "max": round(per_step[-1], 4), "first": round(raw_steps[0], 4)}
+            # the same inside `config` (the contract's own keys): with the driver's --steps 20 the timed region is 0.1 s
+            out["config"]["step_ms_rank0"] = out["step_ms_rank0"]
         if not args.no_kernel_timing:
             traffic_db, traffic_src = load_traffic_db(args.precision)
             def products(r):
                 """Matrix products per fp32 product of a split-product launch: 6 (three bf16 planes), 3 (two fp16
                 planes, template argument NPL = 2 / kernel name x2h), 0 for every other kernel."""
                 key = (r.get("rocprof_key") or "").split(" |wg=")[0]
-                if "x2h" in key or (("x3p_kernel" in key or "wgrad_x3_kernel" in key) and key.rstrip(">").endswith(", 2")):
+                if "x2h" in key or "x2d_kernel" in key or \
+                        (("x3p_kernel" in key or "wgrad_x3_kernel" in key) and key.rstrip(">").endswith(", 2")):
                     return 3
                 if "x3" in key or ("bf16_kernel" in key and key.rstrip(">").endswith(", 3")):
                     return 6
@@ -495,23 +524,40 @@ def main():
 
             kernels = []
             for name, r in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"]):
-                mfma = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
-                # a split-product launch does six bf16 matrix products per fp32 product: its ceiling in fp32-equivalent
-                # flops is the dense bf16 peak / 6
+                gemm = r["flops_per_call"] > 0 and name.startswith("shared_mlp")
+                # a split-product launch issues `products` 16-bit matrix products per fp32 product: its ceiling in
+                # fp32-equivalent flops is the dense 16-bit peak / products
                 mm_peak = PEAK_BF16_TFLOPS / products(r) if is_x3(r) else mfma_peak
-                # the roofline that binds a shared-MLP launch is the one whose floor is higher: the narrow layers
-                # (64 inputs, 16 flop/B) are HBM-bound, the wide ones matrix-bound
-                if mfma and r["bytes_per_call"] / (PEAK_HBM_GBPS * 1e9) > r["flops_per_call"] / (mm_peak * 1e12):
-                    mfma = False
-                ach = r["TFLOPs"] if mfma else r["GBps"]
-                peak = mm_peak if mfma else PEAK_HBM_GBPS
-                kernels.append({"kernel": name, "calls_per_step": r["calls"] / timed_steps_sampled,
-                                "avg_us": round(r["avg_us"], 2),
-                                "share_of_step": round(r["total_ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4),
-                                "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 3), "peak": peak,
-                                "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4),
-                                "traffic": (traffic_db.get(r.get("rocprof_key") or "", {}).get("hbm_bytes_per_launch")),
-                                "rocprof_key": r.get("rocprof_key")})
+                row = {"kernel": name, "calls_per_step": r["calls"] / timed_steps_sampled, "avg_us": round(r["avg_us"], 2),
+                       "share_of_step": round(r["total_ms"] / timed_steps_sampled / (elapsed / args.steps * 1e3), 4)}
+                if gemm:
+                    # both rooflines of a GEMM launch; `bound` = the one whose floor is higher (the narrow layers, 16
+                    # flop/B, are HBM-bound; 512 x 256 sits at the ridge: 50 us of HBM against 41 us of matrix pipe)
+                    f_mm, f_hbm = r["TFLOPs"] / mm_peak, r["GBps"] / PEAK_HBM_GBPS
+                    mfma = r["bytes_per_call"] / (PEAK_HBM_GBPS * 1e9) <= r["flops_per_call"] / (mm_peak * 1e12)
+                    row.update({"bound": "mfma" if mfma else "hbm", "achieved": round(r["TFLOPs"] if mfma else r["GBps"], 3),
+                                "peak": mm_peak if mfma else PEAK_HBM_GBPS, "unit": "TFLOP/s" if mfma else "GB/s",
+                                "frac": round(f_mm if mfma else f_hbm, 4), "frac_mfma": round(f_mm, 4),
+                                "frac_hbm": round(f_hbm, 4)})
+                elif r["flops_per_call"] > 0:
+                    # brute-force distance kernels (ball_query_coords, nearest, knn, som_assign): SURVEY 8d prices them in
+                    # pair evaluations against the fp32 vector peak (8 flop per pair: 3 sub, 3 mul/fma, compare, select);
+                    # their HBM traffic is tiny by design
+                    pairs = r["flops_per_call"] / 8.0
+                    row.update({"bound": "valu", "achieved": round(r["TFLOPs"], 3), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(r["TFLOPs"] / PEAK_F32_TFLOPS, 4),
+                                "pair_evals_per_s": round(pairs / (r["avg_us"] * 1e-6), 1) if r["avg_us"] > 0 else None,
+                                "hbm_GBps": round(r["GBps"], 1)})
+                elif r["bytes_per_call"] < 4.0e6 and r["avg_us"] < 30.0:
+                    # a few hundred KB and microseconds: neither roofline applies, the launch's own latency does
+                    row.update({"bound": "latency", "achieved": round(r["avg_us"], 2), "peak": None, "unit": "us",
+                                "frac": None, "hbm_GBps": round(r["GBps"], 1)})
+                else:
+                    row.update({"bound": "hbm", "achieved": round(r["GBps"], 3), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                "frac": round(r["GBps"] / PEAK_HBM_GBPS, 4)})
+                row.update({"traffic": (traffic_db.get(r.get("rocprof_key") or "", {}).get("hbm_bytes_per_launch")),
+                            "rocprof_key": r.get("rocprof_key")})
+                kernels.append(row)
             if kernels:
                 # The dominant KERNEL (device function = template instantiation, as rocprofv3 lists it), all its
                 # launches in the timed region together.
@@ -545,7 +591,8 @@ def main():
                 out["roofline"] = {
                     "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                     "traffic": (top["traffic"] / top["traffic_calls"]) if top["traffic_calls"] else None,
-                    "kernel": top_name + (" (csrc/shared_mlp_x3.hip)" if "x3" in top_name else
+                    "kernel": top_name + (" (csrc/gemm_x2d.hip)" if "x2d" in top_name else
+                                          " (csrc/shared_mlp_x3.hip)" if "x3" in top_name else
                                           " (csrc/shared_mlp_bf16.hip)" if "bf16" in top_name else " (csrc/shared_mlp.hip)")
                     if top["mfma"] else top_name, "launches_per_step": top["calls"] / timed_steps_sampled,
                     "avg_us": round(avg_s * 1e6, 2),
@@ -554,16 +601,6 @@ def main():
                                if light else "HIP events on the launch stream, every %d-th step of the timed region "
                                "(%d steps)" % (sample_every, timed_steps_sampled)),
                     "algorithmic_per_launch": (top["flops"] if top["mfma"] else top["nbytes"]) / top["calls"],
-                    # the second roofline of a split GEMM: bytes it moves into its CUs by construction (weight planes
-                    # re-read from L2 per position tile + streamed operand + output) against the CUs' memory paths
-                    "cu_memory_path": ({"moved_bytes_per_launch": top["moved"] / top["calls"],
-                                        "achieved_GBps": round(top["moved"] / top["calls"] / avg_s / 1e9, 1),
-                                        "ceiling_GBps": CU_PATH_GBPS,
-                                        "frac": round(top["moved"] / top["calls"] / avg_s / 1e9 / CU_PATH_GBPS, 4),
-                                        "note": "~25 GB/s per CU x 256, L2-served bytes included (measured: every "
-                                                "streaming kernel here tops out at it; DESIGN.md 5): this, not the "
-                                                "matrix pipe (38 % busy), bounds the kernel"}
-                                       if top["moved"] > 0 else None),
                     "fp32_mfma_peak_ratio": (round(ach / PEAK_F32_TFLOPS, 3) if (top["mfma"] and peak != mfma_peak) else None),
                     "traffic_source": traffic_src,
                     "peak_note": ("fp32-equivalent: a split-product launch issues %d 16-bit matrix products per fp32 "
@@ -579,6 +616,30 @@ def main():
                 if light:
                     out["kernels_note"] = ("shared_mlp_* rows: HIP events inside the timed region (one eager step); the "
                                            "other rows: one instrumented eager step run after the timed region")
+        if world == 1 and args.precision != "f32" and not args.no_fp32_leg and args.model != "descriptor":
+            # the same step with plain fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), timed the same way on a short
+            # region: what the headline would be without the 16-bit-plane emulation of the matrix-bound products
+            prev_mode = ops.set_matmul_mode("f32")
+            torch.manual_seed(0)
+            st32 = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer, graph=not args.no_graph)
+            b32 = batch_to_device(synth.make_pair_batch(1234 + rank, args.pairs, args.n, args.m, 4, args.cloud), dev)
+            for _ in range(3):
+                st32.step(b32)
+            if not args.no_graph:
+                b32 = st32.static_batch(b32) or b32
+            for _ in range(3):
+                st32.step(b32)
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            n32 = 10
+            for _ in range(n32):
+                st32.step(b32)
+            torch.cuda.synchronize()
+            t32 = (time.perf_counter() - t32) / n32
+            out["fp32_mfma_only"] = {"ms_per_step": t32 * 1e3, "value": 2 * args.pairs / t32, "unit": "point-clouds/s",
+                                     "steps": n32, "dtype": "f32 (fp32 MFMA for every product)"}
+            del st32, b32
+            ops.set_matmul_mode(prev_mode)
         if world == 1 and not args.no_kernel_leg and not args.no_kernel_timing and args.model != "descriptor":
             del st, batch
             torch.cuda.empty_cache()
@@ -586,7 +647,7 @@ def main():
             out["kernels_note"] = (out.get("kernels_note", "") + "; rows with calls_per_step 0: stand-alone roofline leg "
                                    "after the timed region (see their note)").lstrip("; ")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.model)
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(args, args.model, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

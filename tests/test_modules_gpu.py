@@ -393,6 +393,135 @@ def test_config2_shape_parity_vs_oracle():
         assert_close(st.last[k].detach().cpu().numpy(), ref[k].detach().numpy(), name=k)
 
 
+_CFG3 = {}
+
+
+def _config3_case():
+    """BASELINE.json configs[2] shapes at a batch the CPU oracle handles in seconds: 2 pairs = 4 clouds, N=16384, M=512,
+    Kb=64, Kn=16, Cs=4, "slab" clouds -- the same per-cloud sizes bench.py times, and enough clouds that the dispatcher
+    picks the kernels it picks there (256-row tiles, the direct f32x2 GEMM, the persistent narrow / fused layer
+    kernels).  One free-running oracle step (fwd + losses + bwd), cached for the three arithmetic modes."""
+    import os
+    torch.set_num_threads(min(16, os.cpu_count() or 1))    # ATen's strided reductions crawl with 256 threads (bench.py)
+    if not _CFG3:
+        from usip_amd import synth
+        from usip_amd.networks import DetectorOptions, detector_param_shapes
+        opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=16)
+        batch_np = synth.make_pair_batch(4321, 2, 16384, 512, 4, "slab")
+        filled = synth.fill_parameters(detector_param_shapes("ball", 4))
+        from oracle import detector as od
+        P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
+             if not ("running_" in k or "num_batches" in k)}
+        bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}      # updated in place
+        res = od.detector_step(P, bufs, {k: torch.from_numpy(v) for k, v in batch_np.items()}, "ball",
+                               opt.node_knn_k_1, opt.loss_sigma_lower_bound, opt.keypoint_on_pc_alpha)
+        _CFG3.update(opt=opt, batch_np=batch_np, filled=filled, P=P, res=res, bufs=bufs)
+    return _CFG3
+
+
+def test_config3_shape_parity_vs_oracle(matmul_mode_natural):
+    """oracle parity AT THE SIZE THE BENCH TIMES, natural dispatch, all three fp32-accurate modes.
+    Every index tensor bit-exact; node / keypoints / sigmas / the three losses / BatchNorm buffers within 1e-5 of the
+    oracle (oracle/detector.py = the reference's ATen calls); gradients free-running with the flip-tolerant bound of
+    test_detector_step_matches_reference (a handful of max-pool / ReLU decisions within rounding distance of a tie move
+    gradient entries by O(1e-2): DESIGN.md 3)."""
+    from usip_amd.step import DetectorStep, batch_to_device
+    c = _config3_case()
+    st = DetectorStep("ball", c["opt"], DEV)
+    st.load_numpy_state(c["filled"])
+    st.step(batch_to_device(c["batch_np"], DEV))
+    torch.cuda.synchronize()
+    ref = c["res"]
+    for k, v in st.detector.last_indices.items():
+        assert np.array_equal(v.cpu().numpy(), ref[k].numpy()), k
+    for k in ("node", "keypoints", "sigmas", "loss", "loss_chamfer", "chamfer_pure", "chamfer_weighted"):
+        assert_close(st.last[k].detach().cpu().numpy(), ref[k].detach().numpy(), name=k)
+    # BatchNorm buffers: the oracle updated its copies in place from the same starting values
+    for k, v in st.detector.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(v.cpu().numpy(), c["bufs"][k].numpy(), name=k)
+    gmax = max(float(p.grad.abs().max()) for p in c["P"].values() if p.grad is not None)
+    num = den = 0.0
+    for k, p in st.detector.named_parameters():
+        r = c["P"][k].grad.numpy().ravel().astype(np.float64)
+        if np.abs(r).max() < 1e-5 * gmax:
+            continue                                   # analytically zero (a bias in front of a BatchNorm)
+        g = p.grad.detach().cpu().numpy().ravel().astype(np.float64)
+        assert abs(np.linalg.norm(g) - np.linalg.norm(r)) <= 2e-2 * np.linalg.norm(r), k
+        num += ((g - r) ** 2).sum()
+        den += (r ** 2).sum()
+    assert np.sqrt(num / den) <= 2e-2
+
+
+def test_config3_shape_gradients_at_recorded_decisions():
+    """The gradient half of the same case in the mode bench.py times (f32x2), entry by entry: the HIP step records its
+    own discrete decisions (arg-max of the four max-pools, on/off of every pre-activation within 1e-4 of zero), the
+    oracle replays them in fp32 and -- replaying every decision of that run -- in fp64.  Bar per tensor: 1e-5 of its
+    scale or 3x the oracle's own fp32 distance from its fp64 truth (the bar of
+    test_detector_step_gradients_match_reference_with_pinned_decisions, here at N=16384 / M=512)."""
+    from oracle import detector as od
+    from usip_amd import functional as Fh
+    from usip_amd import ops
+    from usip_amd.step import DetectorStep, batch_to_device
+    c = _config3_case()
+    prev = ops.set_matmul_mode("f32x2")
+    try:
+        st = DetectorStep("ball", c["opt"], DEV)
+        st.allow_pinned_decisions = True
+        st.load_numpy_state(c["filled"])
+        rec = Fh.pinned_decisions(record=True)
+        with rec:
+            st.step(batch_to_device(c["batch_np"], DEV))
+            torch.cuda.synchronize()
+    finally:
+        ops.set_matmul_mode(prev)
+    pools = [p.long().cpu() for p in rec.pools]
+    relu_fix = [(i.long().cpu(), o.cpu()) for i, o in rec.relu]
+
+    def oracle(dtype, tape):
+        P = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in c["filled"].items()
+             if not ("running_" in k or "num_batches" in k)}
+        bufs = {k: torch.from_numpy(v.copy()).to(dtype) for k, v in c["filled"].items() if "running_" in k}
+        od.TAPE = tape
+        try:
+            res = od.detector_step(P, bufs, {k: torch.from_numpy(v).to(dtype) for k, v in c["batch_np"].items()}, "ball",
+                                   c["opt"].node_knn_k_1, c["opt"].loss_sigma_lower_bound, c["opt"].keypoint_on_pc_alpha)
+        finally:
+            od.TAPE = None
+        return P, res
+
+    tape = od.DecisionTape(pools=pools, relu_fix=relu_fix)
+    ref32, res32 = oracle(torch.float32, tape)
+    assert tape.pools == [] and tape.relu_fix == []
+    truth, _ = oracle(torch.float64, od.DecisionTape(replay=tape.rec))
+    for k, v in st.detector.last_indices.items():
+        assert np.array_equal(v.cpu().numpy(), res32[k].numpy()), k
+    for k in ("keypoints", "sigmas", "loss"):
+        assert_close(st.last[k].detach().cpu().numpy(), res32[k].detach().numpy(), name=k)
+    gmax = max(float(p.grad.abs().max()) for p in truth.values())
+    report, bad = {}, {}
+    for k, p in st.detector.named_parameters():
+        tru = truth[k].grad.numpy().ravel()
+        scale = float(np.abs(tru).max())
+        if scale < 1e-5 * gmax:
+            continue
+        hip = p.grad.detach().cpu().numpy().ravel().astype(np.float64)
+        r32 = ref32[k].grad.numpy().ravel().astype(np.float64)
+        noise = np.abs(r32 - tru).max() / scale
+        e = dict(hip_vs_ref32=np.abs(hip - r32).max() / scale, hip_vs_truth=np.abs(hip - tru).max() / scale, ref32_vs_truth=noise)
+        report[k] = e
+        if max(e["hip_vs_ref32"], e["hip_vs_truth"]) > max(1e-5, 3 * noise):
+            bad[k] = e
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "config3_recorded_decision_grad_errors_f32x2.json"), "w") as f:
+            json.dump(dict(worst={q: max(v[q] for v in report.values()) for q in ("hip_vs_ref32", "hip_vs_truth", "ref32_vs_truth")},
+                           relu_decisions_listed=int(sum(i.numel() for i, _ in relu_fix)), errors=report), f, indent=1)
+    assert not bad, "gradients off at the recorded decisions: %s" % bad
+
+
 def test_full_size_step_properties(matmul_mode_natural):
     """(both arithmetic modes, each with the dispatcher's own kernel choice: f32x3 here IS what bench.py times)
     BASELINE.json configs[2] at FULL size (8 pairs = 16 clouds, N=16384, M=512, K=64, Kn=16): the oracle

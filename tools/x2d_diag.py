@@ -40,6 +40,8 @@ for rep in range(3):
         one = t[bi, mi, :, pi, :]                              # [256 ch, 128 pos]
         print("   in that tile: bad per wave (32 positions):", [int((one[:, w * 32:(w + 1) * 32] > 1e-5).sum()) for w in range(4)],
               " bad per channel tile (32 rows):", [int((one[r * 32:(r + 1) * 32] > 1e-5).sum()) for r in range(8)])
+        bl = (one > 1e-5).nonzero().tolist()
+        print("   bad (row, pos) in tile:", bl[:40])
         sub = one[160:192]                                     # [32 ch, 128 pos]
         rows = (sub > 1e-5).any(dim=1).nonzero().flatten().tolist()
         cols = (sub > 1e-5).any(dim=0).nonzero().flatten().tolist()

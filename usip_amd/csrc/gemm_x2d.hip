@@ -25,6 +25,7 @@
 // three products, smallest first); results differ from it only by fp32 summation order in the statistics.
 #include "mlp_common.h"
 #include "split_common.h"
+#include <type_traits>
 
 using namespace usip_mlp;
 
@@ -47,6 +48,207 @@ __device__ __forceinline__ void split_pair_mix(float x, float y, unsigned& hi, u
     asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(y), "v"(hi));
 }
 
+// Output epilogue of the direct kernel.  A wave holds 32 positions x 256 channels: lane = channel (l & 31) of each of the
+// eight 32-channel tiles, positions 8g + 4 (l >> 5) + e.  Stored straight from that layout (mlp_common.h's epilogue) a
+// store instruction writes 32 rows x 32 B -- measured: the epilogue of the 512 x 512 layer cost 70 of the launch's 240
+// us (profiles/r04h_gemm_x2d_time_split.txt).  Here every channel tile goes through a 32 x 32 transposition in LDS (wave
+// private, no barrier: a wave's DS instructions execute in order), after which a store instruction writes 8 rows x 128
+// B: whole cache lines.  Bias, row bias, statistics and their summation order are those of gemm_epilogue<.., 8, 1>.
+constexpr int TRS = 36;                                        // floats per transposition row (32 + 4: conflict-free b128 writes)
+constexpr int EPI_SCRATCH_FLOATS = 4 * 32 * TRS + 2 * 4 * DBM; // transposition areas + statistics exchange
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_x2d(const GemmArgs& a, f32x16 (&acc)[8][1], float out_scale, float* scratch,
+                                             int scratch_floats, int b, int m0, int p0, int tn, int tpc)
+{
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* tr = scratch + wave * (32 * TRS);
+    float* red = scratch + 4 * 32 * TRS;                       // [2][4 waves][256 channels]
+    float* rbs = red + 2 * 4 * DBM;
+    const int pw = p0 + wave * 32;
+    const int ngrp = a.rowbias ? a.P / a.rb_group : 0;
+    const int g0 = a.rowbias ? p0 / a.rb_group : 0;
+    const int G = a.rowbias ? (min(p0 + DBN, a.P) - 1) / a.rb_group - g0 + 1 : 0;
+    const bool rb_lds = a.rowbias && DBM * G <= scratch_floats - EPI_SCRATCH_FLOATS;
+    if (rb_lds) {
+        for (int e = tid; e < DBM * G; e += DNT) {
+            const int rl = e / G, g = e % G;
+            rbs[e] = (m0 + rl < a.M) ? a.rowbias[((long long)b * a.M + m0 + rl) * ngrp + g0 + g] : 0.f;
+        }
+        __syncthreads();
+    }
+    // compute role: channel c of tile i, positions pw + 8g + 4 half + e; store role: row rr + 8k of tile i, positions pst..+3
+    const int rr = lane >> 3, cc = lane & 7;
+    const int pst = pw + 4 * cc;
+    const bool st_full = pst + 3 < a.P;
+    float* const ydst = a.Y + (long long)b * a.y_rows * a.P + (long long)(m0 + rr) * a.P + pst;
+    float* const trw = tr + c * TRS + 4 * half;
+    const float* const trr = tr + rr * TRS + 4 * cc;
+    bool pv[4][4];                                             // position of (g, e) inside the cloud
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[g][e] = pw + 8 * g + 4 * half + e < a.P;
+
+    auto tiles = [&](auto rb_tag) {
+        constexpr bool RB = decltype(rb_tag)::value;
+        const bool run_one_group = RB && (a.rb_group % 4 == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row_l = i * 32 + c, row = m0 + row_l, rowc = min(row, a.M - 1);
+            const bool rok = row < a.M;
+            const float bv = a.bias ? a.bias[rowc] : 0.0f;
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pb = pw + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(acc[i][0][4 * g + e], out_scale, bv);   // out_scale = 2^n: exact
+                if (RB) {
+                    if (run_one_group) {
+                        const int grp = min(pb, a.P - 1) / a.rb_group;
+                        const float rb = rb_lds ? rbs[row_l * G + grp - g0] : a.rowbias[((long long)b * a.M + rowc) * ngrp + grp];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rb;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int grp = min(pb + e, a.P - 1) / a.rb_group;
+                            v[e] += rb_lds ? rbs[row_l * G + grp - g0] : a.rowbias[((long long)b * a.M + rowc) * ngrp + grp];
+                        }
+                    }
+                }
+                if (EPI == EPI_STATS) {
+                    // (adding 0 for rows / positions outside the tensor leaves the sums of the old epilogue bit for bit)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float u = (rok && pv[g][e]) ? v[e] : 0.0f;
+                        s += u;
+                        q = __builtin_fmaf(u, u, q);
+                    }
+                }
+                *reinterpret_cast<float4*>(trw + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (EPI != EPI_NONE) {
+                s += __shfl_xor(s, 32);
+                q += __shfl_xor(q, 32);
+                if (half == 0) { red[wave * DBM + row_l] = s; red[4 * DBM + wave * DBM + row_l] = q; }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // see epilogue_x2d_fast
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 w = *reinterpret_cast<const float4*>(trr + 8 * k * TRS);
+                float* dst = ydst + (long long)(i * 32 + 8 * k) * a.P;
+                if (m0 + i * 32 + rr + 8 * k < a.M) {
+                    if (a.y_vec && st_full) {
+                        *reinterpret_cast<float4*>(dst) = w;
+                    } else {
+                        if (pst + 0 < a.P) dst[0] = w.x;
+                        if (pst + 1 < a.P) dst[1] = w.y;
+                        if (pst + 2 < a.P) dst[2] = w.z;
+                        if (pst + 3 < a.P) dst[3] = w.w;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);                 // one channel tile at a time (register pressure: 128 VGPRs)
+        }
+    };
+    if (a.rowbias) tiles(std::true_type{}); else tiles(std::false_type{});
+    if (EPI != EPI_NONE) {
+        __syncthreads();
+        if (m0 + tid < a.M) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[w * DBM + tid]; q += red[4 * DBM + w * DBM + tid]; }
+            const long long ntn = (long long)a.nb * tpc;
+            a.stats[(long long)(m0 + tid) * ntn + tn] = s;
+            a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn] = q;
+        }
+    }
+}
+
+// The same for a tile that lies entirely inside the tensor (every tile of the step's layers): no row or position
+// predicates, 32-bit buffer addressing with the row as a scalar offset, the row bias (one value per run of four
+// positions: rb_group % 4 == 0) straight from L2.  ~100 instructions per channel tile instead of the ~500 the general
+// form compiles to -- its instruction stream alone took ~10 us per tile.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int EPI, bool RB>
+__device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&acc)[8][1], float out_scale, float* scratch,
+                                                  int b, int m0, int p0, int tn, int tpc)
+{
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* tr = scratch + wave * (32 * TRS);
+    float* red = scratch + 4 * 32 * TRS;
+    const int pw = p0 + wave * 32;
+    const int rr = lane >> 3, cc = lane & 7;
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Y + (long long)b * a.y_rows * a.P), 0, (unsigned)a.y_rows * (unsigned)a.P * 4u, 0x00020000);
+    const int st_voff = ((m0 + rr) * a.P + pw + 4 * cc) * 4;
+    float* const trw = tr + c * TRS + 4 * half;
+    const float* const trr = tr + rr * TRS + 4 * cc;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bv[i] = a.bias ? a.bias[m0 + i * 32 + c] : 0.0f;
+    const int ngrp = RB ? a.P / a.rb_group : 0;
+    int grp[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) grp[g] = RB ? (pw + 8 * g + 4 * half) / a.rb_group : 0;
+    const float* rbp = RB ? a.rowbias + ((long long)b * a.M + m0 + c) * ngrp : nullptr;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float rb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (RB) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rb[g] = rbp[(long long)i * 32 * ngrp + grp[g]];
+        }
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = __builtin_fmaf(acc[i][0][4 * g + e], out_scale, bv[i]);   // out_scale = 2^n: exact
+                if (RB) v[e] += rb[g];
+                if (EPI == EPI_STATS) { s += v[e]; q = __builtin_fmaf(v[e], v[e], q); }
+            }
+            *reinterpret_cast<float4*>(trw + 8 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (EPI != EPI_NONE) {
+            s += __shfl_xor(s, 32);
+            q += __shfl_xor(q, 32);
+            if (half == 0) { red[wave * DBM + i * 32 + c] = s; red[4 * DBM + wave * DBM + i * 32 + c] = q; }
+        }
+        // The transposition reads what OTHER lanes of this wave just wrote.  With the reads issued right behind the
+        // writes (this lean form) a few lanes read the previous tile's values -- 16 wrong elements in 15 % of the
+        // workgroups, r04p; the general form with hundreds of instructions in between never did.  Wait for the writes.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 w = *reinterpret_cast<const float4*>(trr + 8 * k * TRS);
+            const u32x4 d = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 8 * k) * a.P * 4, 0);
+        }
+        // gfx950 / ROCm 7.2: a buffer_store_dwordx4 with an SGPR soffset whose data registers the NEXT instruction
+        // overwrites (here: the v_fma of the next channel tile re-using the tuple) stored the new value in the first
+        // dword of lanes 12-15 of every 16 -- 16 wrong elements in 15 % of the workgroups, timing dependent (r04p-r04s;
+        // hipcc inserts wait states only for the immediate-soffset form).  Eight wait states behind the last store.
+        asm volatile("s_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (EPI != EPI_NONE) {
+        __syncthreads();
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += red[w * DBM + tid]; q += red[4 * DBM + w * DBM + tid]; }
+        const long long ntn = (long long)a.nb * tpc;
+        a.stats[(long long)(m0 + tid) * ntn + tn] = s;
+        a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn] = q;
+    }
+}
+
 template <int PRO, int EPI, bool KTAIL, int DEPTH>
 __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x2d_kernel(
     const GemmArgs a, const uint4* __restrict__ planes)
@@ -66,11 +268,6 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // same logical tile order and XCD remap as the other GEMMs of the library
     const int tpc = (a.P + DBN - 1) / DBN, nmt = (a.M + DBM - 1) / DBM;
     const int total = a.nb * tpc * nmt;
-    int L = blockIdx.x;
-    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
-    const int mt = L % nmt, tn = L / nmt;
-    const int b = tn / tpc, pt = tn % tpc;
-    const int m0 = mt * DBM, p0 = pt * DBN;
     const int nk = (a.K + XBK - 1) / XBK;
     // measurement aid (tools/x2_knob_bench.py, knob x2_direct = 16 / 32 / 48): bit 0 = run only two stages of the main
     // loop, bit 1 = no epilogue -- wrong results, used to split a launch's time into prologue / loop / epilogue
@@ -107,6 +304,17 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __syncthreads();                                       // redm is read; the ring may be written from here on
     }
 
+    // Persistent workgroups (two per CU): the scale and the coefficient table above are per launch, not per tile -- with
+    // one tile per workgroup they and the first loads' latency were 30 of the 240 us of the 512 x 512 layer.  Virtual
+    // block v -> logical tile as before (blocks of one XCD, v & 7, take consecutive tiles, so the two row tiles of a
+    // position tile meet in one L2); gridDim.x is a multiple of 8 whenever it is smaller than `total`.
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+    int L = v;
+    if ((total & 7) == 0) L = (v & 7) * (total >> 3) + (v >> 3);
+    const int mt = L % nmt, tn = L / nmt;
+    const int b = tn / tpc, pt = tn % tpc;
+    const int m0 = mt * DBM, p0 = pt * DBN;
+
     // Buffer descriptors as plain SGPR quads (base, stride 0, bytes, raw-buffer flags): every memory instruction of the
     // main loop is inline asm (see dma_half / load_x1), which takes them as "s" operands.
     typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -125,10 +333,14 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned pc = (unsigned)min(p0 + wave * 32 + c, a.P - 1);
     const int pgrp = POOL ? a.P / a.pool_group : 0;
     const unsigned cloud_bytes = (unsigned)a.K * (unsigned)a.P * 4u, pool_bytes = (unsigned)a.K * (unsigned)pgrp * 4u;
-    const v4i32 rX = make_rsrc((POOL ? a.X2 : a.X) + (long long)b * a.K * a.P, cloud_bytes);
-    const v4i32 rX2 = make_rsrc((TWO ? a.X2 : a.X) + (long long)b * a.K * a.P, cloud_bytes);
-    const v4i32 rPd = make_rsrc(POOL ? a.pool_dp + (long long)b * a.K * pgrp : a.X, POOL ? pool_bytes : 4u);
-    const v4i32 rPa = make_rsrc(POOL ? (const float*)(a.pool_arg + (long long)b * a.K * pgrp) : a.X, POOL ? pool_bytes : 4u);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((POOL ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((TWO ? a.X2 : a.X) + (long long)b * a.K * a.P), 0, cloud_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPd = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? a.pool_dp + (long long)b * a.K * pgrp : a.X), 0, POOL ? pool_bytes : 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rPa = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? (const float*)(a.pool_arg + (long long)b * a.K * pgrp) : a.X), 0, POOL ? pool_bytes : 4u, 0x00020000);
     const int rs = a.P * 4, rsg = pgrp * 4;                    // row strides in bytes
     const int xoff = (int)(pc * 4u), goff = POOL ? (int)((pc / (unsigned)a.pool_group) * 4u) : 0;
     const int xvoff = xoff + h * 8 * rs, gvoff = goff + h * 8 * rsg;
@@ -146,43 +358,22 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int k = min(kb + h * 8 + i, a.K - 1);
             vo = xoff + k * rs; so = 0; vg = goff + k * rsg; sg = 0;
         }
-        // inline asm: the compiler neither counts these loads nor waits for them -- x_wait() does, with exact counts
+        // Plain (compiler-visible) loads: hipcc places the counted waits in front of their uses.  Round 4 tried them as
+        // inline asm with hand-counted waits -- faster by nothing, and unsafe: an asm load's destination is an ordinary
+        // value for the register allocator, which may copy it (to satisfy a tied asm operand, a loop phi) BEFORE the
+        // hand-written wait: one stage of garbage per tile in one of twelve instantiations (r04k).  The weight DMA stays
+        // asm (it writes no register); the waits hipcc computes without knowing about it are only ever too strict.
         if (POOL) {
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.rx[i]) : "v"(vg), "s"(rPd), "s"(sg) : "memory");
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.rarg[POOL ? i : 0]) : "v"(vg), "s"(rPa), "s"(sg) : "memory");
+            S.rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, vg, sg, 0));
+            S.rarg[POOL ? i : 0] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, vg, sg, 0);
         } else {
-            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.rx[i]) : "v"(vo), "s"(rX), "s"(so) : "memory");
+            S.rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, vo, so, 0));
         }
-        if (TWO) asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(S.ry[TWO ? i : 0]) : "v"(vo), "s"(rX2), "s"(so) : "memory");
-    };
-    // Memory instructions of one stage, in issue order: 4 DMA (slots 0, 1), then the NX register loads, element by
-    // element, each right after the element's old value was consumed.  When element e of stage kt+1 is needed, what was
-    // issued after its loads is: the rest of that stage's elements, DEPTH-1 whole stages, and this stage's DMA and
-    // earlier elements -- (NX - q) + 4 + (DEPTH - 1)(NX + 4) instructions, whichever element (q = loads per element).
-    constexpr int NXQ = POOL ? 3 : (TWO ? 2 : 1);
-    constexpr int XWAIT = (8 * NXQ - (TWO ? NXQ : 2 * NXQ)) + 4 + (DEPTH - 1) * (8 * NXQ + 4);
-    auto x_wait = [&](XSet& S, int i) {                        // element i (TWO) / elements i, i+1 (pairs) have landed
-        if (POOL) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(S.rx[i]), "+v"(S.ry[TWO ? i : 0]), "+v"(S.rarg[POOL ? i : 0]) : "n"(XWAIT) : "memory");
-        else if (TWO) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.rx[i]), "+v"(S.ry[TWO ? i : 0]) : "n"(XWAIT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(S.rx[i]), "+v"(S.rx[i + 1]) : "n"(XWAIT) : "memory");
+        if (TWO) S.ry[TWO ? i : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX2, vo, so, 0));
     };
     auto load_x = [&](int kt, XSet& S) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) load_x1(kt, S, i);
-    };
-    // Every load in flight has landed.  The register operands matter: an asm load's destination is, for the compiler, an
-    // ordinary value that is dead after its last use -- without them it re-used the registers of the last (redundant)
-    // loads for copies of the accumulators while those loads were still in flight (r04d: two registers of one
-    // accumulator tile wrong in a fifth of the workgroups, only with two workgroups per CU), and it may move reads of
-    // the registers in front of a wait they do not depend on.
-    auto x_drain = [&](XSet& S) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(S.rx[0]), "+v"(S.rx[1]), "+v"(S.rx[2]), "+v"(S.rx[3]), "+v"(S.rx[4]),
-                     "+v"(S.rx[5]), "+v"(S.rx[6]), "+v"(S.rx[7]) :: "memory");
-        if (TWO) asm volatile("" : "+v"(S.ry[0]), "+v"(S.ry[TWO ? 1 : 0]), "+v"(S.ry[TWO ? 2 : 0]), "+v"(S.ry[TWO ? 3 : 0]),
-                              "+v"(S.ry[TWO ? 4 : 0]), "+v"(S.ry[TWO ? 5 : 0]), "+v"(S.ry[TWO ? 6 : 0]), "+v"(S.ry[TWO ? 7 : 0]));
-        if (POOL) asm volatile("" : "+v"(S.rarg[0]), "+v"(S.rarg[POOL ? 1 : 0]), "+v"(S.rarg[POOL ? 2 : 0]),
-                               "+v"(S.rarg[POOL ? 3 : 0]), "+v"(S.rarg[POOL ? 4 : 0]), "+v"(S.rarg[POOL ? 5 : 0]),
-                               "+v"(S.rarg[POOL ? 6 : 0]), "+v"(S.rarg[POOL ? 7 : 0]));
     };
     // prologue of element i / split of pair j of the stage in S -> packed fp16 planes (the MFMA operand of the lane);
     // cq: the coefficients of the stage for this half-wave, TWO: one float4 (c0..c3) per k, else one per PAIR of k
@@ -244,6 +435,10 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                          :: "s"(dst + j * 4096), "v"(a_voff), "s"(rAv), "s"(kt * DSTAGE + j * 4096) : "memory");
     };
     constexpr int NX = POOL ? 24 : (TWO ? 16 : 8);             // register loads of one stage of the streamed operand
+    // Memory instructions issued AFTER the last DMA instruction of the previous stage (slot 5) when this stage's barrier
+    // is reached: the previous stage's loads from slot 6 on (3/4 of them, see the slot tables in stage()), this stage's
+    // 4 DMA and NX loads.  Waiting until at most that many are outstanding means that DMA has landed.
+    constexpr int BARRIER_VMCNT = NX * 3 / 4 + 4 + NX;
 
     // One 16-k stage = 24 MFMAs in program order, each followed by the few other instructions that issue while it runs
     // (an in-order wave hides ~5 issue slots behind a 32-cycle MFMA; the matrix instructions are inline asm, which the
@@ -252,11 +447,11 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // X_lo.A_hi, X_hi.A_hi for both tiles (smallest terms first; dependent MFMAs are two apart), so that only 16
     // fragment registers are in use and 16 more hold the next pair, read from LDS a pair ahead.  sched_barrier(0)
     // after every slot pins the order.
-    //   slots  0..17  pairs 0-2; fillers: weight DMA of stage kt+2, fragment reads of the next pair, coefficients,
+    //   slots  0..17  pairs 0-2; fillers: fragment reads of the next pair, coefficients, weight DMA of stage kt+2 (slots 4, 5),
     //                 prologue + split of stage kt+1 into the other plane set, operand loads of stage kt+1+DEPTH (each
     //                 register is reloaded right after its value is used)
     //   barrier       every wave's DMA of stage kt+1 has landed (counted wait: only what was issued after it may be
-    //                 outstanding: the loads of two stages and one DMA)
+    //                 outstanding, BARRIER_VMCNT instructions)
     //   slots 18..23  pair 3; fillers: fragment reads of pair 0 of stage kt+1
     auto stage = [&](int kt, XSet& S, const unsigned (&ch)[4], const unsigned (&cl)[4], unsigned (&nh)[4], unsigned (&nl)[4]) {
         const f16x8 xh = __builtin_bit_cast(f16x8, make_uint4(ch[0], ch[1], ch[2], ch[3]));
@@ -276,13 +471,14 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (u < 3) read_pair(kt, u + 1, i, (u & 1) ? FA : FB);
                 else read_pair(kt + 1, 0, i, FA);
             }
-            if (sl < 2) dma_half(k2, sl);
+            // (not earlier: hipcc's wait in front of the first conversion of a stage is vmcnt(0) -- it would drain them)
+            if (sl == 4 || sl == 5) dma_half(k2, sl - 4);
             if (!TWO) {
                 if (sl == 2) { cf_read(k1, 0); cf_read(k1, 1); cf_read(k1, 2); cf_read(k1, 3); }
                 constexpr int CA[4] = {3, 5, 9, 11}, CB[4] = {4, 8, 10, 14};      // slots of pair j: prologue / split + reload
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (sl == CA[j]) { x_wait(S, 2 * j); conv_elem(S, 2 * j); conv_elem(S, 2 * j + 1); }
+                    if (sl == CA[j]) { conv_elem(S, 2 * j); conv_elem(S, 2 * j + 1); }
                     if (sl == CB[j]) {
                         split_pair_mix(cv[2 * j], cv[2 * j + 1], nh[j], nl[j]);
                         load_x1(kx, S, 2 * j); load_x1(kx, S, 2 * j + 1);
@@ -294,7 +490,7 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (sl == CR[e]) cf_read(k1, e);
-                    if (sl == CE[e]) { x_wait(S, e); conv_elem(S, e); }
+                    if (sl == CE[e]) conv_elem(S, e);
                     if (sl == CE[e] + 1) load_x1(kx, S, e);       // its registers are free again
                 }
 #pragma unroll
@@ -309,9 +505,9 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         USIP_X2D_SLOT(0) USIP_X2D_SLOT(1) USIP_X2D_SLOT(2) USIP_X2D_SLOT(3) USIP_X2D_SLOT(4) USIP_X2D_SLOT(5)
         USIP_X2D_SLOT(6) USIP_X2D_SLOT(7) USIP_X2D_SLOT(8) USIP_X2D_SLOT(9) USIP_X2D_SLOT(10) USIP_X2D_SLOT(11)
         USIP_X2D_SLOT(12) USIP_X2D_SLOT(13) USIP_X2D_SLOT(14) USIP_X2D_SLOT(15) USIP_X2D_SLOT(16) USIP_X2D_SLOT(17)
-        // this wave's DMA of stage kt+1 has landed: everything issued after it (two stages of loads, one DMA) may stay
-        // in flight across the barrier (__syncthreads() would drain it); lgkmcnt(0): its reads of the slot are done
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + 2 * NX) : "memory");
+        // this wave's DMA of stage kt+1 has landed: what was issued after it may stay in flight across the barrier
+        // (__syncthreads() would drain it); lgkmcnt(0): its reads of the slot are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BARRIER_VMCNT) : "memory");
         __builtin_amdgcn_s_barrier();
         USIP_X2D_SLOT(18) USIP_X2D_SLOT(19) USIP_X2D_SLOT(20) USIP_X2D_SLOT(21) USIP_X2D_SLOT(22) USIP_X2D_SLOT(23)
 #undef USIP_X2D_SLOT
@@ -321,16 +517,11 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     dma_half(0, 0); dma_half(0, 1);
     dma_half(min(1, nk - 1), 0); dma_half(min(1, nk - 1), 1);
     load_x(0, xs0);
-    x_drain(xs0);                                              // (asm loads and DMA: invisible to the compiler's own waits)
-    convert_all(0, xs0, ah, al);
-    __syncthreads();                                           // stages 0 and 1 of the weights have landed (all waves)
-    load_x(min(1, nk - 1), xs1);                               // stage s lives in set s & 1 (DEPTH 2) / always xs1 (DEPTH 1)
-    if (DEPTH == 2) {
-        // x_wait() counts instructions, so the issue order before the loop must be the loop's: loads, DMA, loads, ...
-        // (a repeat of the DMA of stage 1: the same bytes into the same slot, landed before anyone reads it)
-        dma_half(min(1, nk - 1), 0); dma_half(min(1, nk - 1), 1);
-        load_x(min(2, nk - 1), xs0);
-    }
+    load_x(min(1, nk - 1), xs1);                               // stage s lives in set s & 1 (DEPTH 2) / always xs1 (DEPTH 1);
+    convert_all(0, xs0, ah, al);                               // both requested at once: one memory latency per tile, not two
+    if (DEPTH == 2) load_x(min(2, nk - 1), xs0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX) : "memory");  // the DMA (older than every load; asm: hipcc's barrier does not
+    __syncthreads();                                           // wait for it): stages 0 and 1 of the weights have landed
     read_pair(0, 0, 0, FA); read_pair(0, 0, 1, FA);
     if constexpr (DEPTH == 2) {
         // two stages per trip (nk is even: the launcher sends odd nk to DEPTH 1): register sets and plane sets swap roles
@@ -345,26 +536,27 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < 4; ++j) { ah[j] = bh[j]; al[j] = bl[j]; }
         }
     }
-    // the clamped repeats of the last DMA / loads (both register sets stay reserved until everything has landed: the
-    // second drain's operands keep the other set alive across the first one's wait)
-    x_drain(xs1);
-    if (DEPTH == 2) x_drain(xs0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the clamped repeat of the last DMA (asm: hipcc does not know)
     __syncthreads();                                           // the ring is scratch from here on
     // The MFMAs are inline asm (accumulators pinned to AGPRs: with them in the unified file hipcc shuffled and spilled
     // accumulator tuples in the data-gradient forms), so the compiler does not know that the instructions before this
     // point are matrix instructions whose results need up to 18 wait states before a v_accvgpr_read: wait by hand.
 #pragma unroll
     for (int t = 0; t < 8; ++t) asm volatile("s_nop 7\n\ts_nop 7" : "+a"(acc[t][0]));
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][0][r] *= out_scale;
+    // epilogue scratch: ring slots 2 and 3 (every DMA has landed and every fragment read is done: drains + barrier above)
     if (dbg & 2) {
         if (a.P == -12345) a.Y[tid] = acc[0][0][0] + acc[1][0][1] + acc[2][0][2] + acc[3][0][3] + acc[4][0][4] + acc[5][0][5] +
                                       acc[6][0][6] + acc[7][0][7];
-        return;
+    } else {
+        float* scr = reinterpret_cast<float*>(smem + 2 * DSTAGE);
+        const bool inside = a.y_vec && m0 + DBM <= a.M && p0 + DBN <= a.P && (!a.rowbias || a.rb_group % 4 == 0) &&
+                            (long long)a.y_rows * a.P * 4 < (1LL << 31);
+        if (inside && a.rowbias) epilogue_x2d_fast<EPI, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
+        else if (inside) epilogue_x2d_fast<EPI, false>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
+        else epilogue_x2d<EPI>(a, acc, out_scale, scr, 2 * DSTAGE / 4, b, m0, p0, tn, tpc);
     }
-    gemm_epilogue<1, 4, EPI, 8, 1>(a, acc, reinterpret_cast<float*>(smem), (RING + NC * KPAD * 4) / 4, b, m0, p0, tn, tpc);
+    __syncthreads();                                           // the scratch becomes ring again
+    }                                                          // tiles
 }
 
 }  // namespace
@@ -381,8 +573,17 @@ int launch_gemm_x2d(const GemmArgs& a_in, const uint4* pl, int pro, hipStream_t 
     const int epi = a.stats ? EPI_STATS : EPI_NONE;
     const bool tail = (a.K % XBK) != 0;
     // two stages of operand loads in flight (DEPTH 2) needs an even number of stages; knob x2_direct = 2: DEPTH 1
-    const bool deep = !tail && ((a.K / XBK) % 2 == 0) && usip_tuning_value(USIP_TUNE_X2_DIRECT) != 2;
-    dim3 grid((unsigned)total), block(DNT);
+    const bool deep = !tail && ((a.K / XBK) % 2 == 0) && (usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) != 2;
+    // persistent: two workgroups per CU (LDS: 70 KiB each); 8-aligned so that v & 7 is the same XCD for every tile of a block
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+            n = 256;
+        return n;
+    }();
+    const long long slots = (long long)(2 * cus) / 8 * 8;
+    const bool one_tile_each = (usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) == 4;     // measurement: knob x2_direct = 4
+    dim3 grid((unsigned)((total <= slots || (total & 7) || one_tile_each) ? total : slots)), block(DNT);
 #define USIP_X2D_CASE(P_, E_)                                                                  \
     if (pro == P_ && epi == E_) {                                                              \
         if (tail) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, true, 1>), grid, block, 0, st, a, pl);  \

@@ -1092,7 +1092,7 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
     if (usip_mlp_x3p_tile_cols(M, P, nb, pro, stats != nullptr) == 256) return launch_x3p<4, 4, 2>(a, pl, pro, st);
     // round 4: the streamed operand goes global -> registers -> MFMA (gemm_x2d.hip); knob x2_direct = 1 restores the
     // LDS-staged kernel for A/B runs
-    if (usip_tuning_value(USIP_TUNE_X2_DIRECT) != 1 && (long long)K * P * 4 < (1LL << 31))
+    if ((usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) != 1 && (long long)K * P * 4 < (1LL << 31))
         return launch_gemm_x2d(a, pl, pro, st);
     return launch_x3p<4, 2, 2>(a, pl, pro, st);
 }

@@ -553,6 +553,14 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                                min(512, nb * ((P + 63) // 64)))
             if x2h:
                 bn = 128
+                if bm == 256 and (_lib.lib().usip_tuning_value(6) & 15) != 1 and K * P * 4 < 2 ** 31:
+                    # csrc/gemm_x2d.hip: <pro, stats, K % 16 != 0, stages of operand loads in flight>; persistent, two
+                    # workgroups per CU once there are more tiles than that
+                    tail = K % 16 != 0
+                    depth = 2 if (not tail and (K // 16) % 2 == 0 and (_lib.lib().usip_tuning_value(6) & 15) != 2) else 1
+                    tiles_ = nb * ((P + 127) // 128) * ((M + 255) // 256)
+                    wg = tiles_ if (tiles_ <= 512 or tiles_ % 8) else 512
+                    return "gemm_x2d_kernel<%d, %d, %s, %d> |wg=%d" % (pro, e, "true" if tail else "false", depth, wg)
             return "gemm_x3p_kernel<%d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3,
                                                                    nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
         if x3:
