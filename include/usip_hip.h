@@ -63,12 +63,17 @@ int usip_index_max_f32_cpu(const float* data, const int32_t* index, int32_t* max
 int usip_ball_query_f32(const float* dist, int32_t* out_idx, float radius, int K,
                         int B, int M, int N, void* stream);
 
+/* Host twin (HOST pointers, no stream): the same rows for BASELINE configs[0], the reference's CPU plumbing case.  The
+ * reference itself has no CPU ball_query (models/ball_query_ext/ball_query.cpp:23-31 is a stub). */
+int usip_ball_query_f32_cpu(const float* dist, int32_t* out_idx, float radius, int K, int B, int M, int N);
+
 /* ------------------------------------------------------------------ pairwise distances
  * Replaces the materialised torch.norm(a.unsqueeze(3) - b.unsqueeze(2), dim=1) in front of
  * ball_query (models/networks.py:694-696, :355-357):
  *   dist[b,m,n] = sqrt(fma(dz,dz, fma(dy,dy, dx*dx))), d* = a[b,*,m] - x[b,*,n]
  * (the arithmetic order of the pinned oracle platform, bit-exact with it).
  * a f32 [B,3,M], x f32 [B,3,N] -> dist f32 [B,M,N]. */
+int usip_pairwise_dist_f32_cpu(const float* a, const float* x, float* dist, int B, int M, int N);   /* host twin */
 int usip_pairwise_dist_f32(const float* a, const float* x, float* dist,
                            int B, int M, int N, void* stream);
 
@@ -169,6 +174,11 @@ int usip_fill_scaled_f32(const float* g, float factor, float* out, long long n, 
  * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) -- the arithmetic of torch's single-tensor update. */
 int usip_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step_count,
                        float lr, float beta1, float beta2, float eps, long long n, void* stream);
+/* The same with (lr, beta1, beta2, eps) read from the device array hyper[4]: a launch captured into a HIP graph then
+ * follows ModelDetector.update_learning_rate (models/keypoint_detector.py:356-366 sets param_groups[..]['lr']) without
+ * a new capture -- the host refreshes the four floats before the replay. */
+int usip_adam_step_hyper_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* step_count,
+                             const float* hyper, long long n, void* stream);
 
 /* Pooled-concat layers (a-6 / a-7 row-bias rewrite): the sum over each neighbourhood's K positions of the layer's
  * dY, from the per-neighbourhood sums of the BatchNorm-backward reduction: out[b][c][g] = K * coef4[3][c]

@@ -325,9 +325,22 @@ def chamfer_single_side(kp, pc):
     return d
 
 
+def point_on_surface(kp, pc, sn):
+    """PointOnSurfaceLoss.forward (losses.py:146-187) -> [B,M,1,1]: nearest cloud point p and its normal n (the first
+    three channels of sn), (n . (kp - p) / (|kp - p| + 1e-7))^2 through the same ATen calls."""
+    B, M = kp.shape[0], kp.shape[2]
+    _, I = _min_over(pairwise_norm(kp, pc), 2)
+    idx = I.unsqueeze(1).expand(B, 3, M)
+    p_sel = torch.gather(pc, 2, idx)
+    n_sel = torch.gather(sn, 2, idx)
+    diff = kp - p_sel
+    unit = diff / (torch.norm(diff, dim=1, keepdim=True) + 1e-7)
+    return torch.matmul(n_sel.permute(0, 2, 1).unsqueeze(2), unit.permute(0, 2, 1).unsqueeze(3)) ** 2
+
+
 # --------------------------------------------------------------------------- the training step
 def detector_step(P: Params, bufs, batch: Dict[str, torch.Tensor], model: str, node_knn_k: int,
-                  sigma_lower_bound: float, on_pc_alpha: float):
+                  sigma_lower_bound: float, on_pc_alpha: float, on_pc_type: str = "point_to_point"):
     """ModelDetector.optimize minus the optimizer update (keypoint_detector.py:158-205):
     siamese forward on cat(src, dst), rigid transform of the src keypoints, probabilistic
     chamfer + 2x keypoint-on-pc, backward.  P tensors must have requires_grad=True;
@@ -336,6 +349,11 @@ def detector_step(P: Params, bufs, batch: Dict[str, torch.Tensor], model: str, n
     # widths come with the parameter shapes
     fwd = {"ball": rpn_detector_ball_forward, "knn": rpn_detector_knn_forward,
            "som": rpn_detector_forward, "lite": rpn_detector_forward}[model]
+    if "keep_idx" in batch:              # random point dropout (keypoint_detector.py:160-168): ONE index set for all four
+        batch = dict(batch)
+        idx = batch.pop("keep_idx").long()
+        for k in ("src_pc", "src_sn", "dst_pc", "dst_sn"):
+            batch[k] = torch.index_select(batch[k], 2, idx)
     B = batch["src_pc"].shape[0]
     out = fwd(P, bufs,
               torch.cat((batch["src_pc"], batch["dst_pc"]), 0),
@@ -348,8 +366,12 @@ def detector_step(P: Params, bufs, batch: Dict[str, torch.Tensor], model: str, n
     kp_t = kp_t * batch["scale"].unsqueeze(1).unsqueeze(2)  # :183
     kp_t = kp_t + batch["shift"]                            # :184
     loss_chamfer, pure, weighted, _, _ = chamfer_prob(kp_t, kp_dst, sg_src, sg_dst)
-    on_src = chamfer_single_side(kp_src, batch["src_pc"]).mean() * on_pc_alpha
-    on_dst = chamfer_single_side(kp_dst, batch["dst_pc"]).mean() * on_pc_alpha
+    if on_pc_type == "point_to_plane":                      # :197-201
+        on_src = point_on_surface(kp_src, batch["src_pc"], batch["src_sn"]).mean() * on_pc_alpha
+        on_dst = point_on_surface(kp_dst, batch["dst_pc"], batch["dst_sn"]).mean() * on_pc_alpha
+    else:
+        on_src = chamfer_single_side(kp_src, batch["src_pc"]).mean() * on_pc_alpha
+        on_dst = chamfer_single_side(kp_dst, batch["dst_pc"]).mean() * on_pc_alpha
     loss = loss_chamfer + on_src + on_dst
     loss.backward()
     res = dict(out)

@@ -334,6 +334,28 @@ def gen_losses(losses):
     save("losses_cases.npz", **out)
 
 
+def gen_point_to_plane(losses):
+    """Round 4: the keypoint-on-surface form of KeypointOnPCLoss (models/losses.py:146-187, selected by
+    opt.keypoint_on_pc_type == 'point_to_plane' at keypoint_detector.py:197-201): (n . (kp - p) / (|kp - p| + 1e-7))^2 for
+    the nearest cloud point p with normal n.  sn carries 4 channels as in KITTI (normal + curvature); the reference
+    gathers the first three."""
+    rng = np.random.default_rng(606)
+    opt = Opt()
+    B, M, N = 3, 40, 300
+    kp = torch.from_numpy(rng.normal(0, 1, (B, 3, M)).astype(np.float32))
+    pc = torch.from_numpy(rng.normal(0, 1, (B, 3, N)).astype(np.float32))
+    nrm = rng.normal(0, 1, (B, 3, N))
+    nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    sn = torch.from_numpy(np.concatenate((nrm, rng.uniform(0, 1, (B, 1, N))), 1).astype(np.float32))
+    kp[0, :, 0] = pc[0, :, 5]                       # exact coincidence: 0 / (0 + 1e-7)
+    kp.requires_grad_(True)
+    loss = losses.KeypointOnPCLoss(opt)(kp, pc, sn)            # B x M x 1 x 1
+    g = torch.from_numpy(rng.normal(0, 1, tuple(loss.shape)).astype(np.float32))
+    loss.backward(g)
+    save("point_to_plane_cases.npz", kp=kp.detach().numpy(), pc=pc.numpy(), sn=sn.numpy(), loss=loss.detach().numpy(),
+         g=g.numpy(), gkp=kp.grad.numpy())
+
+
 def run_step(net, losses_mod, opt, batch, alpha):
     """ModelDetector.optimize without the Adam update, driven on the reference's modules
     directly (ModelDetector itself calls torch.cuda.synchronize(), keypoint_detector.py:134)."""
@@ -650,6 +672,9 @@ if __name__ == "__main__":
     if "--only-detectors-r3" in sys.argv:
         gen_detectors_r3(networks, losses, som)
         sys.exit(0)
+    if "--only-point-to-plane" in sys.argv:
+        gen_point_to_plane(losses)
+        sys.exit(0)
     if "--only-bn-decay" in sys.argv:
         gen_bn_decay(layers)
         sys.exit(0)
@@ -659,6 +684,7 @@ if __name__ == "__main__":
     gen_layers(layers)
     gen_bn_decay(layers)
     gen_losses(losses)
+    gen_point_to_plane(losses)
     gen_detectors(networks, losses, som)
     gen_detectors_r3(networks, losses, som)
     gen_descriptor(networks, losses)

@@ -69,6 +69,31 @@ def test_host_entry_points_match_reference_golden(tag, threads):
     assert np.array_equal(out.numpy(), g[tag + "_out"])
 
 
+def test_ball_front_end_host_twins_match_oracle_and_fixture():
+    """BASELINE configs[0] (ModelNet40 detector, N=1024, M=64, batch 2 on PyTorch CPU): the Ball front end's two operators
+    through the product's own host twins (usip_pairwise_dist_f32_cpu, usip_ball_query_f32_cpu) -- distances bit-identical
+    to torch.norm on the pinned platform, rows equal to the C oracle's and to the committed fixture."""
+    import usip_amd
+    from oracle import native
+    from usip_amd import ops, synth
+    _, bq = usip_amd.install()
+    g = load_golden("dist_ball_cases.npz")
+    x, node = torch.from_numpy(g["x"]), torch.from_numpy(g["node"])
+    dist = ops.pairwise_dist_cpu(node, x)
+    assert np.array_equal(dist.numpy(), g["dist"])
+    out = bq.forward_cpu(dist, float(g["radius"]), int(g["K"]))
+    assert out.dtype == torch.int32 and np.array_equal(out.numpy(), g["ball_idx_unpinned"])
+    b = synth.make_pair_batch(11, 2, 1024, 64, 3, "sphere")            # configs[0] shapes
+    x, node = torch.from_numpy(b["src_pc"]), torch.from_numpy(b["src_node"])
+    ref = torch.norm(node.unsqueeze(3) - x.unsqueeze(2), dim=1).contiguous()
+    dist = ops.pairwise_dist_cpu(node, x)
+    assert torch.equal(dist, ref)
+    for radius, K in ((0.2, 64), (0.05, 32), (5.0, 8)):                # partially filled, empty and full balls
+        assert np.array_equal(bq.forward_cpu(dist, radius, K).numpy(), native.ball_query(dist.numpy(), radius, K))
+    with pytest.raises(RuntimeError):
+        bq.forward_cpu(dist.double(), 0.2, 4)
+
+
 def test_bn_momentum_decay_rule_matches_reference():
     """a-13 host logic: the momentum _EpochDecayBatchNorm switches to equals what the reference's MyBatchNorm1d/2d
     end up with (models/layers.py:61-71, :112-121; fixture from the reference itself): no change for epoch None / 0,

@@ -101,6 +101,62 @@ def test_losses_match_reference():
     assert_close(kp.grad.cpu(), g["ss_gkp"], name="ss_gkp")
 
 
+def test_point_to_plane_loss_matches_reference():
+    """KeypointOnPCLoss(kp, pc, sn) -- the point-to-plane form (losses.py:146-187) on the fused nearest-neighbour kernel:
+    values and the keypoint gradient against the reference's fixture (incl. a keypoint ON a cloud point: 0 / (0 + 1e-7))."""
+    from usip_amd.losses import KeypointOnPCLoss
+    from usip_amd.networks import DetectorOptions
+    g = load_golden("point_to_plane_cases.npz")
+    kp = _t(g["kp"], grad=True)
+    crit = KeypointOnPCLoss(DetectorOptions())
+    loss = crit(kp, _t(g["pc"]), _t(g["sn"]))
+    assert tuple(loss.shape) == tuple(g["loss"].shape)
+    loss.backward(_t(g["g"]))
+    assert_close(loss.detach().cpu().numpy(), g["loss"], name="point-to-plane loss")
+    assert_close(kp.grad.cpu().numpy(), g["gkp"], name="point-to-plane d/dkp")
+
+
+def test_step_with_point_to_plane_and_point_dropout_matches_oracle():
+    """ModelDetector.optimize with its two non-default switches (keypoint_detector.py:160-168 random point dropout,
+    :197-201 point_to_plane): the chosen point indices travel with the batch (the reference draws them with numpy on the
+    host), so HIP step and oracle drop the same points; indices bit-exact, floats 1e-5, flip-tolerant gradient norms."""
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions, detector_param_shapes
+    from usip_amd.step import DetectorStep, batch_to_device
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8, keypoint_on_pc_type="point_to_plane",
+                          random_pc_dropout_lower_limit=0.7, input_pc_num=2048)
+    batch_np = synth.make_pair_batch(77, 2, 2048, 48, 4, "sphere")
+    keep = np.sort(np.random.default_rng(5).choice(2048, 1600, replace=False)).astype(np.int64)
+    filled = synth.fill_parameters(detector_param_shapes("ball", 4))
+    st = DetectorStep("ball", opt, DEV)
+    st.load_numpy_state(filled)
+    dev_batch = batch_to_device(batch_np, DEV)
+    dev_batch["keep_idx"] = torch.from_numpy(keep).to(DEV)
+    st.step(dev_batch)
+    torch.cuda.synchronize()
+    from oracle import detector as od
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items() if not ("running_" in k or "num_batches" in k)}
+    bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
+    ob = {k: torch.from_numpy(v) for k, v in batch_np.items()}
+    ob["keep_idx"] = torch.from_numpy(keep)
+    ref = od.detector_step(P, bufs, ob, "ball", opt.node_knn_k_1, opt.loss_sigma_lower_bound, opt.keypoint_on_pc_alpha,
+                           on_pc_type="point_to_plane")
+    for k, v in st.detector.last_indices.items():
+        assert np.array_equal(v.cpu().numpy(), ref[k].numpy()), k
+    for k in ("keypoints", "sigmas", "loss", "loss_chamfer"):
+        assert_close(st.last[k].detach().cpu().numpy(), ref[k].detach().numpy(), name=k)
+    # the plane term normalises kp - p, a difference ~100x smaller than the coordinates: keypoints equal to 1e-7 of their
+    # scale give unit vectors equal to ~1e-5 (the loss itself meets 1e-5 on equal inputs: the fixture test above)
+    for k in ("loss_on_pc_src", "loss_on_pc_dst"):
+        assert_close(st.last[k].detach().cpu().numpy(), ref[k].detach().numpy(), rel=2e-4, name=k)
+    # the unset switch draws its own indices: a different number of points every call, never more than the cloud has
+    st2 = DetectorStep("ball", opt, DEV)
+    st2.load_numpy_state(filled)
+    st2.step(batch_to_device(batch_np, DEV))
+    assert 0.7 * 2048 - 1 <= st2.last_keep <= 2048 and st.last_keep == 1600
+    assert torch.isfinite(st2.last["loss"])
+
+
 def test_som_front_end_matches_reference():
     from usip_amd import ops, som
     from oracle import detector as od
@@ -680,6 +736,40 @@ def test_adam_update_matches_reference_optimizer():
         ref_opt.step()
         for n, r, p in zip(names, ref, st.bucket.params):
             assert_close(p.detach().cpu().numpy(), r.detach().numpy(), rel=2e-6, name="%s after step %d" % (n, it + 1))
+
+
+def test_captured_adam_update_follows_a_changed_learning_rate():
+    """every train_detector.py calls ModelDetector.update_learning_rate every lr_decay_step epochs
+    (keypoint_detector.py:356-366: param_groups[..]['lr'] = ...).  The update replayed from a HIP graph must follow it:
+    lr is halved between replays and the parameters are compared with torch.optim.Adam driven by the same gradients
+    and the same schedule; the optimizer's checkpoint carries the decayed rate."""
+    from usip_amd import synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8)
+    torch.manual_seed(5)
+    st = DetectorStep("ball", opt, DEV, with_optimizer=True, graph=True)
+    batch = batch_to_device(synth.make_pair_batch(7, 2, 1024, 32, 4, "sphere"), DEV)
+    ref = [p.detach().cpu().clone().requires_grad_(True) for p in st.bucket.params]
+    ref_opt = torch.optim.Adam(ref, lr=opt.lr, betas=(0.9, 0.999), foreach=False, fused=False)
+    for it in range(7):
+        if it in (4, 6):                                   # steps 0, 1 run eagerly, 2 captures: 4 and 6 are replays
+            for g in st.optimizer.param_groups:
+                g["lr"] = g["lr"] * 0.5
+            for g in ref_opt.param_groups:
+                g["lr"] = g["lr"] * 0.5
+        st.step(batch)
+        for r, p in zip(ref, st.bucket.params):
+            r.grad = p.grad.detach().cpu().clone()
+        ref_opt.step()
+    assert st.use_graph and len(st._graphs) == 1           # one capture served every learning rate
+    for r, p in zip(ref, st.bucket.params):
+        assert_close(p.detach().cpu().numpy(), r.detach().numpy(), rel=2e-6, name="parameters after the lr schedule")
+    sd = st.optimizer.state_dict()
+    assert sd["param_groups"][0]["lr"] == opt.lr * 0.25 and sd["state"][0]["step"].dim() == 0
+    st2 = DetectorStep("ball", opt, DEV, with_optimizer=True)
+    st2.optimizer.load_state_dict(sd)
+    assert st2.optimizer.param_groups[0]["lr"] == opt.lr * 0.25 and float(st2.optimizer.state[st2.optimizer.param]["step"]) == 7.0
 
 
 def test_graph_replay_equals_eager_steps(matmul_mode):

@@ -89,6 +89,18 @@ def test_losses_oracle_matches_reference():
     assert_close(kp.grad, g["ss_gkp"], name="ss_gkp")
 
 
+def test_point_to_plane_oracle_matches_reference():
+    """PointOnSurfaceLoss (losses.py:146-187) -- selected by opt.keypoint_on_pc_type == 'point_to_plane'
+    (keypoint_detector.py:197-201): the oracle's restatement against values and gradient captured from the reference."""
+    g = load_golden("point_to_plane_cases.npz")
+    kp = torch.from_numpy(g["kp"]).requires_grad_(True)
+    loss = od.point_on_surface(kp, torch.from_numpy(g["pc"]), torch.from_numpy(g["sn"]))
+    assert tuple(loss.shape) == tuple(g["loss"].shape)
+    loss.backward(torch.from_numpy(g["g"]))
+    assert_close(loss.detach(), g["loss"], name="point-to-plane loss")
+    assert_close(kp.grad, g["gkp"], name="point-to-plane d/dkp")
+
+
 def _params_from_fixture(g):
     shapes = {k[len("grad_norm/"):]: None for k in g if k.startswith("grad_norm/")}
     return shapes

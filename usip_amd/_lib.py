@@ -8,6 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # USIP_LIB=<path>: load another BUILD of the same library (same-box A/B of two builds, tools/ab_build.sh); never a fallback
 LIB_PATH = os.environ.get("USIP_LIB") or os.path.join(_HERE, "libusip_hip.so")
+ABI = 4                      # = "abi=<n>" of usip_version(): bumped with every incompatible change of include/usip_hip.h
 _lib = None
 
 _f32p = ctypes.c_void_p
@@ -24,6 +25,8 @@ SIGNATURES = {
     "usip_index_max_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_index_max_f32_cpu": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _int], _int),
     "usip_ball_query_f32": ([_f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),
+    "usip_ball_query_f32_cpu": ([_f32p, _i32p, _flt, _int, _int, _int, _int], _int),
+    "usip_pairwise_dist_f32_cpu": ([_f32p, _f32p, _f32p, _int, _int, _int], _int),
     "usip_pairwise_dist_f32": ([_f32p, _f32p, _f32p, _int, _int, _int, _stream], _int),
     "usip_som_assign_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_som_cluster_f32": ([_f32p, _i32p, _f32p, _i32p, _f32p, _int, _int, _int, _stream], _int),
@@ -118,6 +121,7 @@ SIGNATURES = {
     "usip_group_max_backward_add_f32": ([_f32p, _i32p, _f32p, ctypes.c_longlong, _int, _stream], _int),
     "usip_multi_transpose_f32": ([_f32p, _f32p, _i32p, _int, _int, _stream], _int),
     "usip_adam_step_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _flt, _flt, _flt, _flt, ctypes.c_longlong, _stream], _int),
+    "usip_adam_step_hyper_f32": ([_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, ctypes.c_longlong, _stream], _int),
     "usip_knn_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_knn_points_f32": ([_f32p, _f32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_fps_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
@@ -153,6 +157,12 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = res
+        # ctypes cannot see a changed signature, and results depend on three compile flags (an SLP-vectorised build gave
+        # rare wrong values on gfx950): the library says what it is, anything else is refused
+        ver = l.usip_version().decode()
+        if ("abi=%d" % ABI) not in ver.split() or "flags=no-contract,no-fast-math,no-slp" not in ver.split():
+            raise RuntimeError("usip_amd: %s reports %r; this package needs abi=%d built by usip_amd/build.py "
+                               "(-ffp-contract=off -fno-fast-math -fno-slp-vectorize)" % (LIB_PATH, ver, ABI))
         # measurement knobs for same-box A/B runs: USIP_TUNE="x3_gemm_tile=3,index_max_ch=4" (include/usip_hip.h)
         for item in filter(None, os.environ.get("USIP_TUNE", "").split(",")):
             name, _, value = item.partition("=")

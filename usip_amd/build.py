@@ -23,7 +23,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # BatchNorm-backward prologue of the split GEMMs) never reads a high register into a low half and stays; everything
 # else is left scalar (tests/test_kernel_isa.py checks every translation unit).  Measured cost: none (the kernels are not VALU-bound).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
+         # what usip_version() reports and usip_amd/_lib.py insists on: the three flags results depend on
+         '-DUSIP_BUILD_FLAGS="no-contract,no-fast-math,no-slp"']
 
 
 def sources():

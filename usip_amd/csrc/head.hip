@@ -199,11 +199,15 @@ namespace {
 
 __global__ void adam_bump_kernel(float* step) { step[0] += 1.0f; }
 
+// hyper != null: (lr, beta1, beta2, eps) are read from that device array instead of the launch arguments, so that a
+// captured launch follows param_groups[...]['lr'] (models/keypoint_detector.py:356-366 changes it every lr_decay_step
+// epochs) without a new capture
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ step, float lr, float b1, float b2,
-                                                   float eps, long long n)
+                                                   float eps, long long n, const float* __restrict__ hyper)
 {
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; }
     __shared__ float cf[2];
     if (threadIdx.x == 0) {
         const double t = (double)step[0];
@@ -256,7 +260,26 @@ extern "C" int usip_adam_step_f32(float* param, const float* grad, float* exp_av
     USIP_LAUNCH(adam_bump_kernel, dim3(1), dim3(1), 0, st, step_count);
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(adam_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq,
-                step_count, lr, beta1, beta2, eps, n);
+                step_count, lr, beta1, beta2, eps, n, (const float*)nullptr);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
+}
+
+// The same with the hyper-parameters in device memory: hyper[4] = (lr, beta1, beta2, eps).
+extern "C" int usip_adam_step_hyper_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                        float* step_count, const float* hyper, long long n, void* stream)
+{
+    if (n < 0) return USIP_EINVAL;
+    if (n == 0) return USIP_OK;
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step_count || !hyper) return USIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+         reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15u)
+        return USIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    USIP_LAUNCH(adam_bump_kernel, dim3(1), dim3(1), 0, st, step_count);
+    USIP_LAUNCH_CHECK();
+    USIP_LAUNCH(adam_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq,
+                step_count, 0.f, 0.f, 0.f, 0.f, n, hyper);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

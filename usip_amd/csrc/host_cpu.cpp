@@ -48,7 +48,60 @@ extern "C" int usip_index_max_f32_cpu(const float* data, const int32_t* index, i
     return USIP_OK;
 }
 
-extern "C" const char* usip_version(void) { return "usip_hip 0.2 gfx950"; }
+// ------------------------------------------------------------------------------------------------
+// Host twins of the Ball front end's two operators, so that BASELINE configs[0] (N = 1024, M = 64, batch 2 on PyTorch CPU:
+// plumbing without a GPU) reaches the product's own code.  The reference has no CPU ball_query (ball_query.cpp:23-31 is
+// a stub); these follow the device kernels' contracts (ball_query_cuda.cu:22-46; torch.norm over the three coordinates as
+// the pinned platform evaluates it: sqrt(fma(dz,dz, fma(dy,dy, dx*dx)))).  HOST pointers; never reached from the device
+// entry points.
+#include <cmath>
+extern "C" int usip_ball_query_f32_cpu(const float* dist, int32_t* out_idx, float radius, int K, int B, int M, int N)
+{
+    if (B < 0 || M < 0 || N < 0 || K < 1) return USIP_EINVAL;
+    if ((long long)B * M == 0) return USIP_OK;
+    if (!out_idx || (N > 0 && !dist)) return USIP_EINVAL;
+    for (long long row = 0; row < (long long)B * M; ++row) {
+        const float* d = dist + row * N;
+        int32_t* o = out_idx + row * K;
+        int u = 0;
+        for (int n = 0; n < N && u < K; ++n)
+            if (d[n] <= radius) o[u++] = n;
+        if (u == 0) { std::fill(o, o + K, 0); continue; }
+        for (int i = 0; u + i < K; ++i) o[u + i] = o[i % u];    // cyclic padding with the genuine hits
+    }
+    return USIP_OK;
+}
+
+extern "C" int usip_pairwise_dist_f32_cpu(const float* a, const float* x, float* dist, int B, int M, int N)
+{
+    if (B < 0 || M < 0 || N < 0) return USIP_EINVAL;
+    if ((long long)B * M * N == 0) return USIP_OK;
+    if (!a || !x || !dist) return USIP_EINVAL;
+    for (int b = 0; b < B; ++b) {
+        const float* ab = a + (size_t)b * 3 * M;
+        const float* xb = x + (size_t)b * 3 * N;
+        for (int m = 0; m < M; ++m) {
+            float* row = dist + ((size_t)b * M + m) * N;
+            const float ax = ab[m], ay = ab[M + m], az = ab[2 * M + m];
+            for (int n = 0; n < N; ++n) {
+                const float dx = ax - xb[n], dy = ay - xb[N + n], dz = az - xb[2 * N + n];
+                float s2 = dx * dx;
+                s2 = std::fmaf(dy, dy, s2);
+                s2 = std::fmaf(dz, dz, s2);
+                row[n] = std::sqrt(s2);
+            }
+        }
+    }
+    return USIP_OK;
+}
+
+// "usip_hip <version> gfx950 abi=<n> flags=<...>": abi counts incompatible changes of include/usip_hip.h (a signature that
+// gained an argument is not detectable through ctypes); flags names what the build MUST have been compiled with --
+// USIP_BUILD_FLAGS comes from usip_amd/build.py; a foreign build without it reports "unknown" and is refused.
+#ifndef USIP_BUILD_FLAGS
+#define USIP_BUILD_FLAGS "unknown"
+#endif
+extern "C" const char* usip_version(void) { return "usip_hip 0.4 gfx950 abi=4 flags=" USIP_BUILD_FLAGS; }
 
 // Launch-geometry knobs (speed only, never results): 0 = the library's own heuristic.  tools/ sweeps set them to
 // measure alternatives on the GPU; the product never does.

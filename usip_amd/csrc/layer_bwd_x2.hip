@@ -1,8 +1,8 @@
 // usip_amd/csrc/layer_bwd_x2.hip -- backward of a shared-MLP layer with <= 128 inputs and <= 128 outputs as ONE kernel,
 // f32x2 arithmetic (two fp16 planes per operand, three plane products: shared_mlp_x3.hip): conv2, conv3 and the pooled
 // conv5 of RPN_Detector_Ball (models/networks.py:705-712; the layers' backward is autograd's in the reference:
-// models/layers.py:208-216, :293-303).  (The feature half of conv4, 64 -> 128, compiles from the same template but
-// needs scratch and stays on narrow_bwd.hip.)
+// models/layers.py:208-216, :293-303).  (The feature half of conv4, 64 -> 128, is the same template with one LDS buffer; the
+// dispatcher launches it since round 3.)
 //
 // These layers are HBM-bound and their (dZ, Y) pair used to be read two or three times per step (BatchNorm-backward
 // reduction, data-gradient GEMM, weight-gradient GEMM).  narrow_bwd.hip fused the two products for 64-input layers

@@ -18,3 +18,9 @@ def forward_cuda(node_to_point_dist, radius, K):
     """The reference's forward_cuda is an unimplemented stub that prints and returns garbage
     (ball_query.cpp:23-31); here it is an alias of the working entry point."""
     return _ops.ball_query(node_to_point_dist, radius, K)
+
+
+def forward_cpu(node_to_point_dist, radius, K):
+    """No reference counterpart (its CPU path is the stub above): the host twin of the device kernel, for BASELINE
+    configs[0] -- the reference's plumbing case on PyTorch CPU.  dist f32 [B,M,N] on the HOST -> i32 [B,M,K]."""
+    return _ops.ball_query_cpu(node_to_point_dist, radius, K)

@@ -37,18 +37,42 @@ class SingleSideChamferLoss_Brute(nn.Module):
         return Fh.nearest_distance_i32(pc_src_input, pc_dst_input)[0]
 
 
+class PointOnSurfaceLoss(nn.Module):
+    """Point-to-plane form (models/losses.py:146-187): with p = the cloud point nearest to the keypoint and n its
+    normal (the first three channels of sn), (n . (kp - p) / (|kp - p| + 1e-7))^2 -> B x M x 1 x 1.  The arg-min comes
+    from the fused nearest-neighbour kernel (no B x M x N matrix); the rest is M-sized ATen arithmetic in the
+    reference's order, which autograd differentiates exactly as it does there (the arg-min carries no gradient)."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+
+    def forward(self, keypoint, pc, sn):
+        B, M = keypoint.shape[0], keypoint.shape[2]
+        _, I = Fh.nearest_distance_i32(keypoint.detach(), pc)
+        self.last_indices = I
+        idx = I.long().unsqueeze(1).expand(B, 3, M)
+        pc_selected = torch.gather(pc, 2, idx)
+        sn_selected = torch.gather(sn, 2, idx)                          # channels 0..2 of sn
+        diff = keypoint - pc_selected
+        unit = diff / (torch.norm(diff, dim=1, keepdim=True) + 1e-7)
+        dot = torch.matmul(sn_selected.permute(0, 2, 1).unsqueeze(2), unit.permute(0, 2, 1).unsqueeze(3))
+        return dot ** 2                                                 # B x M x 1 x 1
+
+
 class KeypointOnPCLoss(nn.Module):
-    """Keypoint-to-cloud distance (models/losses.py:102-116).  The point-to-plane variant
-    (sn given) is not a default anywhere and is outside the path."""
+    """Keypoint-to-cloud distance (models/losses.py:102-116): point-to-point (sn None: the default of every options
+    file) or point-to-plane (sn given; selected by opt.keypoint_on_pc_type, keypoint_detector.py:193-201)."""
 
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
         self.single_side_chamfer = SingleSideChamferLoss_Brute(opt)
+        self.keypoint_on_surface = PointOnSurfaceLoss(opt)
 
     def forward(self, keypoint, pc, sn=None):
         if sn is not None:
-            raise NotImplementedError("usip_amd: point_to_plane keypoint-on-pc loss is outside the path")
+            return self.keypoint_on_surface(keypoint, pc, sn)
         return self.single_side_chamfer(keypoint, pc)
 
 

@@ -236,6 +236,8 @@ class DetectorOptions:
         self.loss_sigma_lower_bound = 0.001
         self.keypoint_on_pc_alpha = 0.01
         self.keypoint_on_pc_type = "point_to_point"
+        self.random_pc_dropout_lower_limit = 1.0          # kitti/options_detector.py: off by default
+        self.input_pc_num = 16384
         self.lr = 0.001
         # descriptor head (kitti/options_descriptor.py:53-59)
         self.descriptor_len = 128

@@ -533,7 +533,8 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     x2h = (x3p and _matmul_mode == "f32x2" and coef is not None and
            ((pro == 1 and coef.shape[0] >= 4) or (pro >= 2 and coef.shape[0] >= 5)))
     # 128-wide layers: weight fragments resident in registers, persistent workgroups (usip_mlp_gemm_x2r_f32)
-    x2r = x2h and M <= 128 and K <= 128 and X2R and (rowbias is None or (pro == 1 and rb_ok and rb_group >= 32))
+    x2r = (x2h and M <= 128 and K <= 128 and X2R and K * P < 2 ** 30          # (usip_mlp_gemm_x2r_f32's own limits)
+           and (rowbias is None or (pro == 1 and rb_ok and rb_group >= 32)))
     stats = None
     if want_stats:
         tiles = _lib.lib().usip_mlp_gemm_x2r_tiles(P, nb) if x2r else _lib.lib().usip_mlp_gemm_tiles(M, P, nb)
@@ -1038,11 +1039,20 @@ def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr: float, beta1: float, beta2: float, eps: float):
-    """One Adam step on flat fp32 buffers, in place (usip_adam_step_f32); `step` is a device float[1], incremented."""
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr: float, beta1: float, beta2: float, eps: float, hyper=None):
+    """One Adam step on flat fp32 buffers, in place (usip_adam_step_f32); `step` is a device float[1], incremented.
+    hyper: device float[4] = (lr, beta1, beta2, eps) read by the kernel instead of the scalar arguments (a captured launch
+    then follows a changed learning rate)."""
     for t, n in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq"), (step, "step")):
         _need(t, n, torch.float32)
     n = param.numel()
+    if hyper is not None:
+        _need(hyper, "hyper", torch.float32)
+        with torch.cuda.device(param.device), prof.kernel("adam", 4.0 * 7 * n):
+            _lib.check(_lib.lib().usip_adam_step_hyper_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                                           _ptr(step), _ptr(hyper), n, _stream(param)),
+                       "usip_adam_step_hyper_f32")
+        return
     with torch.cuda.device(param.device), prof.kernel("adam", 4.0 * 7 * n):
         _lib.check(_lib.lib().usip_adam_step_f32(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(step),
                                                  float(lr), float(beta1), float(beta2), float(eps), n, _stream(param)),
@@ -1086,6 +1096,29 @@ def nms(keypoints: torch.Tensor, sigmas: torch.Tensor, radius: float):
         _lib.check(_lib.lib().usip_nms_f32(_ptr(keypoints), _ptr(sigmas), float(radius), _ptr(order), _ptr(count),
                                            B, M, _stream(keypoints)), "usip_nms_f32")
     return order, count
+
+
+def ball_query_cpu(dist: torch.Tensor, radius: float, K: int) -> torch.Tensor:
+    """Host twin of ball_query (BASELINE configs[0], the CPU plumbing case): dist f32 [B,M,N] on the HOST -> i32 [B,M,K]."""
+    if dist.is_cuda or not dist.is_contiguous() or dist.dtype != torch.float32 or dist.dim() != 3:
+        raise RuntimeError("node_to_point_dist must be a contiguous CPU float32 tensor [B,M,N]")
+    B, M, N = dist.shape
+    out = torch.empty((B, M, int(K)), dtype=torch.int32)
+    _lib.check(_lib.lib().usip_ball_query_f32_cpu(_ptr(dist), _ptr(out), float(radius), int(K), B, M, N),
+               "usip_ball_query_f32_cpu")
+    return out
+
+
+def pairwise_dist_cpu(a: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Host twin of pairwise_dist: a [B,3,M], x [B,3,N] on the HOST -> [B,M,N]."""
+    for t, name in ((a, "a"), (x, "x")):
+        if t.is_cuda or not t.is_contiguous() or t.dtype != torch.float32 or t.dim() != 3 or t.shape[1] != 3:
+            raise RuntimeError("%s must be a contiguous CPU float32 tensor [B,3,*]" % name)
+    B, _, M = a.shape
+    N = x.shape[2]
+    out = torch.empty((B, M, N), dtype=torch.float32)
+    _lib.check(_lib.lib().usip_pairwise_dist_f32_cpu(_ptr(a), _ptr(x), _ptr(out), B, M, N), "usip_pairwise_dist_f32_cpu")
+    return out
 
 
 def index_max_cpu(data: torch.Tensor, index: torch.Tensor, K: int, num_threads: int = 1) -> torch.Tensor:

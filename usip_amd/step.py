@@ -76,26 +76,53 @@ class FlatAdam:
         self.state = {flat_param: dict(step=torch.zeros(1, dtype=torch.float32, device=dev),
                                        exp_avg=torch.zeros_like(flat_param.data),
                                        exp_avg_sq=torch.zeros_like(flat_param.data))}
+        # (lr, beta1, beta2, eps) on the device: the kernel reads them there, so that a launch captured into a HIP graph
+        # follows param_groups[0]['lr'] (ModelDetector.update_learning_rate, keypoint_detector.py:356-366)
+        self._hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = None
+        self.sync_hyper()
+
+    def sync_hyper(self):
+        """Refresh the device copy of (lr, betas, eps) from param_groups when they changed (a 16-byte copy; never
+        inside a stream capture: the step calls it before it replays the update)."""
+        g = self.param_groups[0]
+        now = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+        if now != self._hyper_host:
+            self._hyper.copy_(torch.tensor(now, dtype=torch.float32))
+            self._hyper_host = now
 
     def step(self):
         from . import ops
-        g = self.param_groups[0]
+        if self.param.grad is None:
+            return
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
         st = self.state[self.param]
+        g = self.param_groups[0]
         ops.adam_step(self.param.data, self.param.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], g["lr"],
-                      g["betas"][0], g["betas"][1], g["eps"])
+                      g["betas"][0], g["betas"][1], g["eps"], hyper=self._hyper)
 
     def zero_grad(self, set_to_none: bool = False):
-        self.param.grad.zero_()
+        if self.param.grad is not None:
+            self.param.grad.zero_()
 
     def state_dict(self):
+        """torch.optim.Adam's layout for ONE parameter (index 0): state[0] = {step (0-dim), exp_avg, exp_avg_sq} over
+        the FLAT parameter buffer -- the per-parameter tensors are views into it in nn.Module.parameters() order, which
+        is how a per-parameter Adam checkpoint (the CPU / gloo path builds torch.optim.Adam) maps onto it."""
         st = self.state[self.param]
-        return dict(state={0: {k: v.clone() for k, v in st.items()}},
+        return dict(state={0: dict(step=st["step"].reshape(()).clone(), exp_avg=st["exp_avg"].clone(),
+                                   exp_avg_sq=st["exp_avg_sq"].clone())},
                     param_groups=[{k: (v if k != "params" else [0]) for k, v in self.param_groups[0].items()}])
 
     def load_state_dict(self, sd):
         st = self.state[self.param]
         for k, v in sd["state"][0].items():
             st[k].copy_(torch.as_tensor(v).reshape(st[k].shape))
+        for k, v in (sd.get("param_groups") or [{}])[0].items():     # a decayed learning rate survives a resume
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if k == "betas" else v
+        self.sync_hyper()
 
 
 class _GraphedStep:
@@ -298,6 +325,8 @@ class _GraphedStep:
         ga.replay()
         self._all_reduce(group)
         if gb is not None:
+            if hasattr(self.optimizer, "sync_hyper"):
+                self.optimizer.sync_hyper()                   # a changed learning rate reaches the captured update
             gb.replay()
         self.last = last
         return loss
@@ -334,6 +363,36 @@ class DetectorStep(_GraphedStep):
             static[a], static[b], static[both] = cat[:n], cat[n:], cat
         return static
 
+    def _prepare(self, batch):
+        """Random point dropout of ModelDetector.optimize (keypoint_detector.py:160-168): when
+        opt.random_pc_dropout_lower_limit < 0.99, a keep ratio U(limit, 1) and that many point indices WITHOUT
+        replacement are drawn on the host every step (random.uniform + np.random.choice, as there) and ONE index set
+        selects the same points of src and dst clouds and normals.  The indices travel as batch["keep_idx"] (int64 [n]
+        device tensor; pass it yourself to fix the choice -- the parity fixture does).  The number of kept points
+        changes from step to step, so with graph=True every new count captures a new graph (bounded cache)."""
+        limit = getattr(self.opt, "random_pc_dropout_lower_limit", 1.0)
+        if "keep_idx" not in batch and limit < 0.99:
+            import random
+            import numpy as np
+            n_in = int(getattr(self.opt, "input_pc_num", batch["src_pc"].shape[2]))
+            keep = round(random.uniform(limit, 1.0) * n_in)
+            idx = np.random.choice(n_in, keep, replace=False)
+            batch = dict(batch, keep_idx=torch.from_numpy(idx).to(self.device))
+        if "keep_idx" in batch:
+            if self.use_graph:                                # a new point count almost every step: replay cannot pay off
+                import warnings
+                warnings.warn("usip_amd: random point dropout changes the cloud size every step; HIP-graph replay is "
+                              "switched off for this step object")
+                self.use_graph = False
+            batch = dict(batch)
+            idx = batch.pop("keep_idx").long()
+            self.last_keep = int(idx.numel())                 # points per cloud this step trains on
+            for k in ("src_pc", "src_sn", "dst_pc", "dst_sn"):
+                batch[k] = torch.index_select(batch[k], 2, idx).contiguous()
+            for k in [both for _, _, both in self._SIAMESE if both in batch]:
+                del batch[k]                                 # concatenated views of the undropped clouds
+        return batch
+
     def forward_losses(self, batch: Dict[str, torch.Tensor], epoch: Optional[int] = None):
         B = batch["src_pc"].shape[0]
         self.detector.train()                                 # keypoint_detector.py:171
@@ -348,8 +407,13 @@ class DetectorStep(_GraphedStep):
         alpha = self.opt.keypoint_on_pc_alpha
         # :196-203  keypoint-on-pc for src and dst: both clouds of every pair in ONE nearest-neighbour launch
         # (rows [0,B) = src, [B,2B) = dst; every cloud is independent, so the values are the reference's)
-        loss, on_src, on_dst = Fh.detector_loss_combine(self.keypoint_on_pc_criteria(kp, pc, None), loss_chamfer,
-                                                        alpha)   # :204
+        if getattr(self.opt, "keypoint_on_pc_type", "point_to_point") == "point_to_plane":     # :197-201
+            on = self.keypoint_on_pc_criteria(kp, pc, sn)                    # 2B x M x 1 x 1
+            on_src, on_dst = torch.mean(on[:B]) * alpha, torch.mean(on[B:]) * alpha
+            loss = loss_chamfer + on_src + on_dst
+        else:
+            loss, on_src, on_dst = Fh.detector_loss_combine(self.keypoint_on_pc_criteria(kp, pc, None), loss_chamfer,
+                                                            alpha)   # :204
         self.last = dict(node=nodes, keypoints=kp, sigmas=sg, loss=loss, loss_chamfer=loss_chamfer,
                          chamfer_pure=pure, chamfer_weighted=weighted, loss_on_pc_src=on_src,
                          loss_on_pc_dst=on_dst)
