@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-n1-probe", action="store_true",
+                    help="(N > 1) skip rank 0's 5-step single-GPU probe of the same workload (`distributed.n1_probe`)")
     ap.add_argument("--no-fp32-leg", action="store_true",
                     help="skip the 10-step run of the same step with fp32 MFMA everywhere (`fp32_mfma_only` in the line)")
     ap.add_argument("--no-kernel-leg", action="store_true",
@@ -357,11 +359,33 @@ def main():
         if world > 1:
             dist.barrier()
 
+    n1_probe = None
+    if world > 1 and args.model != "descriptor" and not args.no_n1_probe:
+        # Self-check of the scaling line: rank 0 alone times 5 steps of the SAME per-GPU workload without any exchange
+        # (its own step object, so the replicas stay identical) while the other ranks wait; the N-GPU step should cost
+        # that plus the all-reduce.  The driver computes scaling efficiency from separate runs; this is one run's view.
+        if rank == 0:
+            torch.manual_seed(0)
+            st1 = DetectorStep(args.model, opt, dev, with_optimizer=not args.no_optimizer, graph=not args.no_graph)
+            st1.solo = True                                # no all-reduce, no capture of one
+            b1 = batch_to_device(synth.make_pair_batch(1234, args.pairs, args.n, args.m, 4, args.cloud), dev)
+            for _ in range(6):
+                st1.step(b1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                st1.step(b1)
+            torch.cuda.synchronize()
+            n1_probe = {"n1_reference_ms": (time.perf_counter() - t1) / 5 * 1e3, "steps": 5,
+                        "how": "rank 0 alone, same per-GPU workload, no gradient exchange, before the timed region"}
+            del st1, b1
+            torch.cuda.empty_cache()
+        barrier()
     for _ in range(args.warmup):
         st.step(batch)
     torch.cuda.synchronize()
     barrier()
-    if world > 1:
+    if world > 1 and not getattr(st, "allreduce_in_graph", False):
         st.allreduce_events = []                           # two HIP events around every gradient all-reduce
     # Per-kernel HIP events cost ~3 us of stream bubble each (~0.7 ms per step for ~220 of them): they are
     # recorded on every 4th step (1-GPU eager runs) or on one middle step only (graph replay, multi-GPU), which keeps the headline
@@ -406,7 +430,7 @@ def main():
     if world > 1:
         # who took part: every rank reports its device; all-reduce durations (max over ranks per percentile) and the
         # per-rank step time, so that the line shows that RCCL saw N ranks on N devices and what the exchange cost
-        ar_events, st.allreduce_events = st.allreduce_events[:args.steps], None
+        ar_events, st.allreduce_events = (st.allreduce_events or [])[:args.steps], None
         ar = sorted(s.elapsed_time(e) * 1e3 for s, e in ar_events)
         props = torch.cuda.get_device_properties(dev)
         mine = dict(rank=rank, local_rank=local_rank, device_index=dev.index, pid=os.getpid(),
@@ -471,8 +495,9 @@ def main():
                        "ball_radius": 2, "ball_k": 64, "cloud": args.cloud, "matmul": args.precision,
                        "step": "fwd+losses+bwd" + ("+allreduce" if world > 1 else "") +
                                ("" if args.no_optimizer else "+adam"),
-                       "launch": "HIP graph replay (2 graphs per step, all-reduce between them)" if graphed
-                                 else "eager",
+                       "launch": ("HIP graph replay (ONE graph per step: forward, backward, RCCL all-reduce, Adam)"
+                                  if getattr(st, "allreduce_in_graph", False) else
+                                  "HIP graph replay (2 graphs per step, all-reduce between them)") if graphed else "eager",
                        "parallelism": "dp%d" % world, "tuning": args.tune or None},
             "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,
         }
@@ -496,8 +521,19 @@ def main():
                 "loss_per_rank": [c["loss"] for c in census],
                 "param_checksum_per_rank": [c["param_checksum"] for c in census],
                 "replicas_identical": len({str(c["param_checksum"]) for c in census}) == 1,
+                "allreduce_in_graph": bool(getattr(st, "allreduce_in_graph", False)),
+                "n1_probe": n1_probe,
                 "launcher": "self-spawned torch.distributed.run" if os.environ.get("USIP_BENCH_SPAWNED") else
                             "external launcher"}
+        if census is not None and backend == "nccl":
+            # a line that claims N GPUs must have run on N GPUs with identical replicas: anything else is an error, not
+            # a number (USIP_DIST_BACKEND=gloo + USIP_SHARE_DEVICE=1, the one-GPU debugging mode, is exempt by design)
+            d = out["distributed"]
+            if d["distinct_devices"] != world or not d["replicas_identical"]:
+                print(json.dumps({"error": "bench.py --gpus %d: %d distinct devices, replicas_identical=%s"
+                                           % (world, d["distinct_devices"], d["replicas_identical"]),
+                                  "distributed": d, "ranks_seen": out["ranks_seen"]}), flush=True)
+                sys.exit(3)
         raw_steps = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         per_step = sorted(raw_steps)
         if per_step:

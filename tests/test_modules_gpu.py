@@ -1084,3 +1084,9 @@ def test_bench_two_ranks_graph_replay_on_one_gpu(tmp_path):
     assert "allreduce" in out["config"]["step"]
     assert out["value"] > 0 and np.isfinite(out["loss"])
     assert "capture failed" not in res.stderr.decode()
+    d = out["distributed"]
+    assert d["allreduce_in_graph"] is False and "2 graphs" in out["config"]["launch"]      # gloo cannot be captured
+    assert d["n1_probe"]["n1_reference_ms"] > 0 and d["replicas_identical"]
+    # (RCCL's collectives can be captured, and then the whole step is ONE graph: usip_amd/step.py.  That form needs one
+    # device per rank and cannot run on this 1-GPU box; a gloo all-reduce inside a capture aborts the process, so the
+    # attempt is made with backend "nccl" only, and a refused capture falls back to this two-graph form.)

@@ -9,6 +9,7 @@ Sharding: every (src, dst) pair is independent in forward, losses an
 BatchNorm statistics are per replica in the reference (nn.DataParallel, no SyncBN) and stay
 per rank here.  Rank r owns pairs [r*B/W, (r+1)*B/W); the only exchange is the gradient sum.
 """
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -180,6 +181,7 @@ class _GraphedStep:
         # bench.py: set to a list to have every gradient all-reduce bracketed by two HIP events on the launch stream
         # (the collective itself runs on RCCL's stream; the launch stream waits for it, so the pair spans it)
         self.allreduce_events = None
+        self.allreduce_in_graph = False                      # True once a step graph contains the all-reduce (RCCL)
         self._eager_calls = 0
         self._bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
         self._bn_counters = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
@@ -248,6 +250,8 @@ class _GraphedStep:
         return self._step_eager(batch, epoch, group)
 
     def _all_reduce(self, group):
+        if getattr(self, "solo", False):                      # bench.py's single-rank probe inside a multi-rank job
+            return
         if self.allreduce_events is not None and self.device.type == "cuda":
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -293,35 +297,80 @@ class _GraphedStep:
                 return self._step_eager(batch, epoch, group)
             static = self._static_from(batch)
             torch.cuda.synchronize(self.device)
-            try:
-                # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
-                # must not invalidate the capture
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, capture_error_mode="thread_local"):
-                    loss = self._forward_backward(static, epoch)
-                last = dict(self.last)
-                gb = None
-                if self.optimizer is not None:
-                    gb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gb, capture_error_mode="thread_local"):
-                        self.optimizer.step()
-            except RuntimeError as err:                       # capture refused: keep training with plain launches
-                import warnings
-                warnings.warn("usip_amd: HIP graph capture failed (%s); continuing with eager launches" % err)
-                torch.cuda.synchronize(self.device)
-                self.use_graph = False
-                return self._step_eager(batch, epoch, group)
-            entry = self._graphs[key] = (ga, gb, static, last, loss)   # capture launches nothing: replay below
+            world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+            # One graph for the whole step when the gradient exchange can be captured: RCCL (backend "nccl") enqueues
+            # its collectives on a stream and supports stream capture, so forward + backward + all-reduce + Adam replay
+            # as ONE graph launch per step and nothing is left exposed between two replays.  gloo (the CPU tests, the
+            # several-ranks-on-one-GPU debugging mode) cannot be captured, a refused capture falls back, and
+            # USIP_GRAPH_ALLREDUCE=0 keeps the two-graph form for A/B runs.
+            # (only ever attempted with RCCL: a gloo all-reduce inside a capture aborts the process -- tried, r04aa)
+            fuse = (world > 1 and not getattr(self, "solo", False)
+                    and os.environ.get("USIP_GRAPH_ALLREDUCE", "1") not in ("0", "off")
+                    and dist.get_backend(group) == "nccl" and self.allreduce_events is None)
+            entry = None
+            if fuse:
+                try:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                        loss = self._forward_backward(static, epoch)
+                        self.bucket.all_reduce_mean(group)
+                        if self.optimizer is not None:
+                            self.optimizer.step()
+                    entry = (g1, None, static, dict(self.last), loss, True)
+                    self.allreduce_in_graph = True
+                except Exception as err:                      # noqa: BLE001  (a backend that cannot be captured says so its own way)
+                    import warnings
+                    warnings.warn("usip_amd: the gradient all-reduce could not be captured (%s); replaying two graphs "
+                                  "with the all-reduce between them" % err)
+                    torch.cuda.synchronize(self.device)
+                    entry = None
+            if entry is None:
+                try:
+                    # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
+                    # must not invalidate the capture
+                    ga = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
+                        loss = self._forward_backward(static, epoch)
+                    last = dict(self.last)
+                    gb = None
+                    if self.optimizer is not None:
+                        gb = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gb, capture_error_mode="thread_local"):
+                            self.optimizer.step()
+                except RuntimeError as err:                   # capture refused: keep training with plain launches
+                    import warnings
+                    warnings.warn("usip_amd: HIP graph capture failed (%s); continuing with eager launches" % err)
+                    torch.cuda.synchronize(self.device)
+                    self.use_graph = False
+                    return self._step_eager(batch, epoch, group)
+                entry = (ga, gb, static, last, loss, False)   # capture launches nothing: replay below
+            self._graphs[key] = entry
             while len(self._graphs) > self.max_graphs:
                 _, old = self._graphs.popitem(last=False)     # drops the graphs and, with them, their memory pool
                 del old
-        ga, gb, static, last, loss = entry
+        ga, gb, static, last, loss, fused = entry
         for k, v in batch.items():
             if v.data_ptr() != static[k].data_ptr():
                 static[k].copy_(v, non_blocking=True)
         if key[1] is not None:                                # what the Python forward would have left behind
             for bn, m in zip(self._bns, key[1]):
                 bn.momentum = m
+        if fused:
+            if hasattr(self.optimizer, "sync_hyper"):
+                self.optimizer.sync_hyper()                   # (before the replay: the update is inside it)
+            ga.replay()
+            if not getattr(self, "_fused_checked", False):
+                # once per step object: after an all-reduce every rank holds the same gradient -- if the captured
+                # collective did not do what the eager one does, say so now instead of training on garbage
+                self._fused_checked = True
+                mine = self.bucket.flat.detach().double().sum().reshape(1)
+                every = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+                dist.all_gather(every, mine, group=group)
+                if any(float(e) != float(every[0]) for e in every):
+                    raise RuntimeError("usip_amd: gradients differ across ranks after the captured all-reduce; "
+                                       "set USIP_GRAPH_ALLREDUCE=0")
+            self.last = last
+            return loss
         ga.replay()
         self._all_reduce(group)
         if gb is not None:
