@@ -302,6 +302,20 @@ int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const float* X2, c
                           const float* bias, const float* rowbias, int rb_group, const float* pool_dp,
                           const int32_t* pool_arg, int pool_group, float* Y, int y_rows, float* stats,
                           int M, int K, int P, int nb, void* stream);
+
+/* Round 4: data-gradient launches (pro 2 / 3) of the direct f32x2 kernel (csrc/gemm_x2d.hip) that also leave, from the dX
+ * tile they hold, the BatchNorm-backward partial sums of the layer that produced the activation dX is the gradient of --
+ * what autograd's native_batch_norm_backward of that layer re-reads (dX, Y) for in the reference
+ * (models/layers.py:208-216).  red_y [nb][M][P]: that layer's pre-BN output; red_coef [4][M]: its (scale, shift, mean,
+ * invstd); red_out: [2][tiles][M] sums (sum d, sum d * xhat, d = dX where its ReLU is on) followed by [tiles * M / 256]
+ * maxima of |d|; red_gsum (optional, red_group 16 or 32 positions per neighbourhood): [2][nb * M][P / red_group] sums of
+ * d and of y.  usip_mlp_gemm_x2d_red_tiles() = tiles of such a launch, 0 when the shape does not take this path (M % 256,
+ * P % 128, 256-row tiles): use usip_mlp_gemm_x2h_f32 + usip_bn_backward_reduce_f32 then. */
+int usip_mlp_gemm_x2d_red_tiles(int M, int K, int P, int nb, int red_group);
+int usip_mlp_gemm_x2h_red_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                              const float* pool_dp, const int32_t* pool_arg, int pool_group, float* Y,
+                              const float* red_y, const float* red_coef, float* red_out, float* red_gsum,
+                              int red_group, int M, int K, int P, int nb, void* stream);
 /* The same for the 128-wide layers (M <= 128, K <= 128; a row bias only with pro 1 and rb_group a multiple of 32) with
  * the weight fragments resident in registers and persistent workgroups over 64-position tiles: a CU moves the streamed
  * operand in and the output out, not the weight planes again for every tile.

@@ -609,3 +609,64 @@ def test_direct_gemm_backward_is_fp32_accurate(shape, gscale, x2_forced):
         a = ops.mlp_gemm(W, None, pro=3, X2=Yp, coef=coef4, tag="dgrad", pool=(dp, arg, G))[0]
         b = ops.mlp_gemm(W, dense, pro=2, X2=Yp, coef=coef4, tag="dgrad")[0]
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape,group", [((4, 256, 256, 8192), 0), ((2, 512, 512, 8192), 16), ((8, 512, 256, 4096), 32)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_direct_gemm_backward_leaves_the_producing_layers_bn_sums(shape, group, pooled, x2_forced):
+    """Round 4 (an option of the product, off by default because the step measured slower with it --
+    usip_amd/functional.py GEMM_RED): the data-gradient launches of the direct kernel leave, from the dX tile they hold,
+    the BatchNorm-backward partial sums (and, for a pooled-concat producer, the per-neighbourhood sums) of the layer that
+    produced the activation -- against float64 sums over the dX the SAME launch wrote, and against the stand-alone
+    reduction's coefficients."""
+    from usip_amd import _lib, ops
+    nb, K, M, P = shape
+    assert _lib.lib().usip_mlp_gemm_x2d_red_tiles(M, K, P, nb, group) == nb * (P // 128)
+    g = torch.Generator().manual_seed(K * 13 + M + P + group)
+    W = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+    Yp = (torch.randn(nb, K, P, generator=g) * 2.0 + 0.5).to(DEV)            # this layer's pre-BN output
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    cf = _bn_coef(Yp, gamma, beta)
+    Yprev = (torch.randn(nb, M, P, generator=g) * 1.5 - 0.2).to(DEV)         # the producing layer's pre-BN output
+    cprev = _bn_coef(Yprev, (1 + 0.3 * torch.randn(M, generator=g)).to(DEV), (0.3 * torch.randn(M, generator=g)).to(DEV))
+    if pooled:
+        G = 16
+        dp = torch.randn(nb, K, P // G, generator=g).to(DEV)
+        arg = torch.randint(0, G, (nb, K, P // G), generator=g, dtype=torch.int32).to(DEV)
+        _, _, coef4 = ops.bn_pool_backward_reduce(dp, arg, Yp.view(nb, K, P // G, G), cf, cf[2].contiguous(), cf[3].contiguous(),
+                                                  gamma, True)
+        dX, _, red = ops.mlp_gemm(W, None, pro=3, X2=Yp, coef=coef4, tag="dgrad", pool=(dp, arg, G), red=(Yprev, cprev),
+                                  red_group=group)
+        plain = ops.mlp_gemm(W, None, pro=3, X2=Yp, coef=coef4, tag="dgrad", pool=(dp, arg, G))[0]
+    else:
+        dZ = torch.randn(nb, K, P, generator=g).to(DEV)
+        _, _, coef4, _ = ops.bn_backward_reduce(dZ, Yp, cf, cf[2].contiguous(), cf[3].contiguous(), gamma, True)
+        dX, _, red = ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4, tag="dgrad", red=(Yprev, cprev), red_group=group)
+        plain = ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4, tag="dgrad")[0]
+    assert red is not None and torch.equal(dX, plain)                        # the sums change nothing of the product
+    on = _fma(Yprev, cprev[0].view(1, M, 1), cprev[1].view(1, M, 1)) > 0
+    d = torch.where(on, dX, torch.zeros_like(dX)).double()
+    xhat = (Yprev.double() - cprev[2].double().view(1, M, 1)) * cprev[3].double().view(1, M, 1)
+    s1, s2 = d.sum((0, 2)), (d * xhat).sum((0, 2))
+    got = red.sums.double().sum(1)
+    scale = max(float(s1.abs().max()), float(s2.abs().max()))
+    assert float((got[0] - s1).abs().max()) <= 2e-6 * scale + 1e-6 * float(d.abs().sum((0, 2)).max())
+    assert float((got[1] - s2).abs().max()) <= 2e-6 * scale + 1e-6 * float((d * xhat).abs().sum((0, 2)).max())
+    assert float(red.maxima.max()) == float(d.abs().max())
+    if group:
+        gs = red.gsum.double()
+        want_d = d.view(nb, M, P // group, group).sum(3)
+        want_y = Yprev.double().view(nb, M, P // group, group).sum(3)
+        assert float((gs[0] - want_d).abs().max()) <= 1e-5 * float(want_d.abs().max())
+        assert float((gs[1] - want_y).abs().max()) <= 1e-5 * float(want_y.abs().max())
+    # the consumer's view: the coefficients the finalisation derives from these partials = the stand-alone pass's
+    dgam, dbet, c4 = ops.bn_backward_from_partials([red], nb * P, cprev, cprev[2].contiguous(), cprev[3].contiguous())
+    dgam2, dbet2, c4b, _ = ops.bn_backward_reduce(dX, Yprev, cprev, cprev[2].contiguous(), cprev[3].contiguous(),
+                                                  torch.ones(M, device=DEV), True)
+    assert _rel(dbet, dbet2) < 1e-5 and _rel(dgam, dgam2) < 1e-5
+    assert _rel(c4[:4], c4b[:4]) < 1e-5
+    for _ in range(2):                                                       # bit-stable (fixed summation order)
+        again = ops.mlp_gemm(W, None if pooled else dZ, pro=3 if pooled else 2, X2=Yp, coef=coef4, tag="dgrad",
+                             pool=(dp, arg, G) if pooled else None, red=(Yprev, cprev), red_group=group)[2]
+        assert torch.equal(again.flat, red.flat)

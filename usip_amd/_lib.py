@@ -78,6 +78,9 @@ SIGNATURES = {
     "usip_mlp_split2h_f32": ([_f32p, _int, _int, _int, _int, ctypes.c_void_p, _stream], _int),
     "usip_mlp_gemm_x2h_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
+    "usip_mlp_gemm_x2d_red_tiles": ([_int, _int, _int, _int, _int], _int),
+    "usip_mlp_gemm_x2h_red_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _i32p, _int, _f32p, _f32p, _f32p, _f32p,
+                                   _f32p, _int, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3_used": ([_int, _int, _int, _int], _int),
     "usip_mlp_wgrad_f32x3_blocks": ([_int, _int, _int, _int], _int),
     "usip_bn_pool_backward_reduce_f32": ([_f32p, _i32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p,

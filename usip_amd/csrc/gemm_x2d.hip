@@ -174,10 +174,17 @@ __device__ __forceinline__ void epilogue_x2d(const GemmArgs& a, f32x16 (&acc)[8]
 // positions: rb_group % 4 == 0) straight from L2.  ~100 instructions per channel tile instead of the ~500 the general
 // form compiles to -- its instruction stream alone took ~10 us per tile.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int EPI, bool RB>
+// RED (data-gradient launches, EPI_NONE, no row bias): the tile just computed is dX = the gradient of the producing layer's
+// activated output; while it is in registers in the store role (8 rows x 128 B per instruction) the same lanes read the
+// producing layer's pre-BN tile (red_y, the same coalesced pattern) and take its BatchNorm-backward sums -- what the
+// stand-alone usip_bn_backward_reduce_f32 pass re-read (dX, Y) from HBM for.  Sums over a row's 32 positions: three DPP
+// steps over its 8 lanes, fixed order; per tile and channel one partial (four waves added in order); per-neighbourhood
+// sums (red_group = 16 or 32 positions) fall out of the same steps.
+template <int EPI, bool RB, bool RED = false>
 __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&acc)[8][1], float out_scale, float* scratch,
                                                   int b, int m0, int p0, int tn, int tpc)
 {
+    static_assert(!RED || (EPI == EPI_NONE && !RB), "RED: data-gradient launches only");
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* tr = scratch + wave * (32 * TRS);
@@ -197,6 +204,19 @@ __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&ac
 #pragma unroll
     for (int g = 0; g < 4; ++g) grp[g] = RB ? (pw + 8 * g + 4 * half) / a.rb_group : 0;
     const float* rbp = RB ? a.rowbias + ((long long)b * a.M + m0 + c) * ngrp : nullptr;
+    // RED state
+    float* cfr = scratch + EPI_SCRATCH_FLOATS;                  // [256 rows][scale, shift, mean, invstd]
+    const __amdgpu_buffer_rsrc_t rYp = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(RED ? a.red_y + (long long)b * a.M * a.P : a.Y), 0, RED ? (unsigned)a.M * (unsigned)a.P * 4u : 4u, 0x00020000);
+    const int yp_voff = RED ? ((m0 + rr) * a.P + pw + 4 * cc) * 4 : 0;
+    const int rgrp = RED ? a.red_group : 0, rngrp = (RED && rgrp) ? a.P / rgrp : 0;
+    float mx = 0.f;
+    u32x4 ynext = {0u, 0u, 0u, 0u};                             // the producing layer's tile, one 8-row slab ahead of its use
+    if (RED) {
+        ynext = __builtin_amdgcn_raw_buffer_load_b128(rYp, yp_voff, 0, 0);
+        for (int e = tid; e < DBM * 4; e += DNT) cfr[(e & 255) * 4 + (e >> 8)] = a.red_coef[(long long)(e >> 8) * a.M + m0 + (e & 255)];
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float rb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -230,6 +250,50 @@ __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&ac
             const float4 w = *reinterpret_cast<const float4*>(trr + 8 * k * TRS);
             const u32x4 d = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
             __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 8 * k) * a.P * 4, 0);
+            if (RED) {
+                const int row_l = i * 32 + rr + 8 * k;
+                const float4 c4 = *reinterpret_cast<const float4*>(cfr + row_l * 4);
+                const float wv[4] = {w.x, w.y, w.z, w.w};
+                const u32x4 yq = ynext;                        // requested one (i, k) item ago
+                if (i * 4 + k + 1 < 32)
+                    ynext = __builtin_amdgcn_raw_buffer_load_b128(rYp, yp_voff, ((i * 4 + k + 1) / 4 * 32 + 8 * ((i * 4 + k + 1) % 4)) * a.P * 4, 0);
+                const float yv[4] = {__uint_as_float(yq.x), __uint_as_float(yq.y), __uint_as_float(yq.z), __uint_as_float(yq.w)};
+                float gd = 0.f, gy = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dv = (__builtin_fmaf(yv[e], c4.x, c4.y) > 0.f) ? wv[e] : 0.f;
+                    gd += dv;
+                    gy += yv[e];
+                    s2 = __builtin_fmaf(dv, (yv[e] - c4.z) * c4.w, s2);
+                    mx = fmaxf(mx, fabsf(dv));
+                }
+                // lanes 8 rr .. 8 rr + 7 hold the row's 32 positions: quad sums (16 positions), then the other quad
+                gd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gd), 0xB1, 0xF, 0xF, false));
+                gd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gd), 0x4E, 0xF, 0xF, false));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0xB1, 0xF, 0xF, false));
+                s2 += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x4E, 0xF, 0xF, false));
+                if (rgrp) {
+                    gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0xB1, 0xF, 0xF, false));
+                    gy += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0x4E, 0xF, 0xF, false));
+                }
+                const float gd8 = gd + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gd), 0x141, 0xF, 0xF, false));
+                const float s28 = s2 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s2), 0x141, 0xF, 0xF, false));
+                if (rgrp == 16) {
+                    if ((cc & 3) == 0) {
+                        const long long rowid = (long long)b * a.M + m0 + row_l;
+                        a.red_gsum[rowid * rngrp + (pw + 4 * cc) / 16] = gd;
+                        a.red_gsum[((long long)a.nb * a.M + rowid) * rngrp + (pw + 4 * cc) / 16] = gy;
+                    }
+                } else if (rgrp == 32) {
+                    const float gy8 = gy + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gy), 0x141, 0xF, 0xF, false));
+                    if (cc == 0) {
+                        const long long rowid = (long long)b * a.M + m0 + row_l;
+                        a.red_gsum[rowid * rngrp + pw / 32] = gd8;
+                        a.red_gsum[((long long)a.nb * a.M + rowid) * rngrp + pw / 32] = gy8;
+                    }
+                }
+                if (cc == 0) { red[wave * DBM + row_l] = gd8; red[4 * DBM + wave * DBM + row_l] = s28; }
+            }
         }
         // gfx950 / ROCm 7.2: a buffer_store_dwordx4 with an SGPR soffset whose data registers the NEXT instruction
         // overwrites (here: the v_fma of the next channel tile re-using the tuple) stored the new value in the first
@@ -246,6 +310,21 @@ __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&ac
         const long long ntn = (long long)a.nb * tpc;
         a.stats[(long long)(m0 + tid) * ntn + tn] = s;
         a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn] = q;
+    }
+    if (RED) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float* wmx = cfr;                                       // (the coefficient table is read; reuse behind the barrier)
+        __syncthreads();
+        if (lane == 0) wmx[wave] = mx;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s += red[w * DBM + tid]; q += red[4 * DBM + w * DBM + tid]; }
+        const long long ntn = (long long)a.nb * tpc;
+        a.red_out[(long long)tn * a.M + m0 + tid] = s;          // [2][tiles][M]
+        a.red_out[(ntn + tn) * a.M + m0 + tid] = q;
+        __syncthreads();
+        if (tid == 0) a.red_out[2 * ntn * a.M + (long long)tn * (a.M / DBM) + m0 / DBM] = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
     }
 }
 
@@ -552,6 +631,7 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool inside = a.y_vec && m0 + DBM <= a.M && p0 + DBN <= a.P && (!a.rowbias || a.rb_group % 4 == 0) &&
                             (long long)a.y_rows * a.P * 4 < (1LL << 31);
         if (inside && a.rowbias) epilogue_x2d_fast<EPI, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
+        else if (inside && TWO && a.red_out) epilogue_x2d_fast<EPI_NONE, false, TWO>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
         else if (inside) epilogue_x2d_fast<EPI, false>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
         else epilogue_x2d<EPI>(a, acc, out_scale, scr, 2 * DSTAGE / 4, b, m0, p0, tn, tpc);
     }

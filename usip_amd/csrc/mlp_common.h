@@ -26,6 +26,12 @@ struct GemmArgs {
     int a_trans;                        // 1: the matrix operand is stored [M][K] (row stride lda), read transposed
     int y_rows;                         // rows per cloud of the tensor Y points into (>= M): Y[b] = Y + b*y_rows*P
     int y_vec;                          // 1: P % 4 == 0 and Y 16-B aligned: runs of 4 positions are stored as one float4
+    // gemm_x2d.hip, data-gradient launches only (all null / 0 elsewhere): the output dX is the gradient of the lazily
+    // activated output of the layer whose pre-BN tensor is red_y [nb][M][P] with coefficients red_coef [4][M] (scale,
+    // shift, mean, invstd); the epilogue leaves that layer's BatchNorm-backward partial sums in red_out =
+    // [2][tiles][M] (sum d, sum d xhat with d = dX where relu is on) + [tiles * row tiles] maxima of |d|, tiles = nb *
+    // ceil(P / 128); red_gsum (optional) [2][nb * M][P / red_group]: per-neighbourhood sums of d and of y
+    const float* red_y; const float* red_coef; float* red_out; float* red_gsum; int red_group;
 };
 
 // prologue on one element of the streamed operand, channel coefficients c0..c3

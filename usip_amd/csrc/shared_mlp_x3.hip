@@ -1097,6 +1097,39 @@ extern "C" int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const f
     return launch_x3p<4, 2, 2>(a, pl, pro, st);
 }
 
+// Data-gradient launches of the direct kernel (gemm_x2d.hip) that also leave the BatchNorm-backward partial sums of the
+// layer that PRODUCED the activation dX is the gradient of (pre-BN output red_y [nb][M][P], coefficients red_coef [4][M]:
+// scale, shift, mean, invstd).  usip_mlp_gemm_x2d_red_tiles: the number of position tiles (= rows of the partial sums) of
+// such a launch, 0 when the launch would not take that path (then call usip_mlp_gemm_x2h_f32 and the stand-alone
+// reduction).  red_out: [2][tiles][M] sums, then [tiles * M / 256] maxima; red_gsum (optional, red_group 16 or 32):
+// [2][nb * M][P / red_group].  Everything else as usip_mlp_gemm_x2h_f32 with pro 2 or 3.
+extern "C" int usip_mlp_gemm_x2d_red_tiles(int M, int K, int P, int nb, int red_group)
+{
+    if (M < 256 || M % 256 || P < 128 || P % 128 || nb < 1 || K < 1 || K > 512) return 0;
+    if (red_group != 0 && red_group != 16 && red_group != 32) return 0;
+    if (usip_mlp_x3p_tile_rows(M, P, nb) != 256 || usip_mlp_x3p_tile_cols(M, P, nb, 2, 0) != 128) return 0;
+    if ((usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) == 1 || (usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) == 8) return 0;
+    if ((long long)K * P * 4 >= (1LL << 31) || (long long)M * P * 4 >= (1LL << 31)) return 0;
+    return nb * (P / 128);
+}
+
+extern "C" int usip_mlp_gemm_x2h_red_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
+                                         const float* pool_dp, const int32_t* pool_arg, int pool_group, float* Y,
+                                         const float* red_y, const float* red_coef, float* red_out, float* red_gsum,
+                                         int red_group, int M, int K, int P, int nb, void* stream)
+{
+    if (pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL) return USIP_EINVAL;
+    if (!usip_mlp_gemm_x2d_red_tiles(M, K, P, nb, red_gsum ? red_group : 0)) return USIP_EINVAL;
+    if (!planes || !Y || !coef || !X2 || !red_y || !red_coef || !red_out || (reinterpret_cast<uintptr_t>(planes) & 15u))
+        return USIP_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(red_y)) & 15u) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD && !X) return USIP_EINVAL;
+    if (pro == PRO_BN_BWD_POOL && (!pool_dp || !pool_arg || pool_group < 1 || P % pool_group != 0)) return USIP_EINVAL;
+    GemmArgs a{nullptr, 0, X, X2, coef, nullptr, Y, nullptr, M, K, P, nb, nullptr, 1, pool_dp, pool_arg, pool_group,
+               0, M, 1, red_y, red_coef, red_out, red_gsum, red_gsum ? red_group : 0};
+    return launch_gemm_x2d(a, reinterpret_cast<const uint4*>(planes), pro, (hipStream_t)stream);
+}
+
 // f32x2 for the 128-wide layers with register-resident weight fragments (gemm_x2r_kernel): M <= 128, K <= 128, a row
 // bias only with pro 1 and rb_group a multiple of 32; `planes` = the usip_mlp_split2h_f32 image; stats: [2][M][usip_mlp_gemm_x2r_tiles(P, nb)] (one partial per workgroup).
 // Otherwise the contract of usip_mlp_gemm_x2h_f32.

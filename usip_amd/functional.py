@@ -450,8 +450,27 @@ def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
     return (dgamma, dbeta, coef4, gsum) if group else (dgamma, dbeta, coef4)
 
 
-def _dgrad(x, w2c, dz, pro, X2=None, coef=None, pool=None, M=None, a_offset=0):
-    """Data-gradient GEMM dX = W^T . dY with dY rebuilt from (dZ, Y) in the prologue."""
+# The direct f32x2 data-gradient GEMM (csrc/gemm_x2d.hip) can leave the BatchNorm-backward sums of the layer that produced
+# its output's activation (round 4, VERDICT r3 item 3: it holds the dX tile in a layout it can read that layer's pre-BN
+# tile in; tests/test_f32x2_mode_gpu.py::test_direct_gemm_backward_leaves_the_producing_layers_bn_sums).  MEASURED SLOWER
+# and therefore OFF by default: 4.88 -> 5.30 ms per step, same box, twice (profiles/r04ae_gemm_red_ab.txt).  The
+# stand-alone pass it replaces reads (dX, Y) at 11.7 TB/s -- dX was just written and sits in the 256 MB Infinity Cache
+# -- i.e. 46 us per layer, while the epilogue's reads of the Y tile are latency-bound (one 8-row slab in flight per
+# lane; more would spill: the kernel runs at the 128-VGPR limit).  USIP_GEMM_RED=1 enables it.
+GEMM_RED = _os.environ.get("USIP_GEMM_RED", "0") not in ("0", "off")
+
+
+def _dgrad(x, w2c, dz, pro, X2=None, coef=None, pool=None, M=None, a_offset=0, xcoef=None, red_group=0):
+    """Data-gradient GEMM dX = W^T . dY with dY rebuilt from (dZ, Y) in the prologue.  xcoef: the input x is the pre-BN
+    output of a training-mode BatchNorm + ReLU layer with these coefficients -- when the launch can, its epilogue takes
+    that layer's BatchNorm-backward sums and they are registered for it (PRE_BN_SUMS)."""
+    if (GEMM_RED and FUSED_NARROW_RED and GRAD_SINK and pro >= 2 and xcoef is not None and xcoef.shape[0] >= 4
+            and (M is None or M == x.shape[1]) and a_offset >= 0):
+        dx, _, r = ops.mlp_gemm(w2c, dz, pro=pro, X2=X2, coef=coef, tag="dgrad", pool=pool, M=M, a_offset=a_offset,
+                                red=(x, xcoef), red_group=red_group)
+        if r is not None:
+            _register_pre_bn_sums(dx, [r])
+        return dx
     return ops.mlp_gemm(w2c, dz, pro=pro, X2=X2, coef=coef, tag="dgrad", pool=pool, M=M, a_offset=a_offset)[0]
 
 
@@ -564,7 +583,7 @@ class _SharedMLPLayer(torch.autograd.Function):
                 ops.mlp_gemm(w2.contiguous(), dz, pro=2, X2=y, coef=coef4, tag="dgrad", M=x.shape[1] - pre,
                              a_offset=pre, out=dx, out_row_offset=pre)
             else:
-                dx = _dgrad(x, w2.contiguous(), dz, pro=2, X2=y, coef=coef4)
+                dx = _dgrad(x, w2.contiguous(), dz, pro=2, X2=y, coef=coef4, xcoef=xcoef)
         dw = None
         if need_w:
             dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef,
@@ -624,7 +643,8 @@ class _SharedMLPLayerMax(torch.autograd.Function):
                 dw = db = dgamma = dbeta = None
             return (dx.view(ctx.x_shape), None, None, dw, db, dgamma, dbeta) + (None,) * 5
         if ctx.needs_input_grad[0]:
-            dx = _dgrad(x3, w2.contiguous(), None, pro=3, X2=y, coef=coef4, pool=pool)
+            dx = _dgrad(x3, w2.contiguous(), None, pro=3, X2=y, coef=coef4, pool=pool, xcoef=xcoef,
+                        red_group=K if (POOLED_LAYER_RED and K in (16, 32)) else 0)
             dx = dx.view(ctx.x_shape)
         if ctx.needs_input_grad[3]:
             dw = ops.mlp_wgrad(None, x3, pro=3, G2=y, coef4=coef4, xcoef=xcoef, pool=pool,
@@ -732,7 +752,7 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
             dh = res[0].view(ctx.h_shape)
             ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
         if ctx.needs_input_grad[0] and not fused:
-            dh = _dgrad(h3, w2c, dz, pro=2, X2=y, coef=coef4, M=Ch, a_offset=hoff).view(ctx.h_shape)
+            dh = _dgrad(h3, w2c, dz, pro=2, X2=y, coef=coef4, M=Ch, a_offset=hoff, xcoef=hcoef).view(ctx.h_shape)
         if ctx.needs_input_grad[4] and not fused:
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
             ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff, xcoef=hcoef)

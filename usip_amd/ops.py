@@ -464,10 +464,14 @@ X2R_NARROW = _os.environ.get("USIP_X2R_NARROW", "1") not in ("0", "off")
 def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = False, pro: int = 0,
              X2=None, coef=None, tag: str = "fwd", rowbias=None, rb_group: int = 1,
              M: Optional[int] = None, a_offset: int = 0, pool=None, a_trans: bool = False, out=None,
-             out_row_offset: int = 0):
+             out_row_offset: int = 0, red=None, red_group: int = 0):
     """Y[b] = At^T . pro(X[b]) + bias (+ rowbias[b][:, p // rb_group]).
     At: K-major matrix operand, [K, lda] storage; the GEMM uses columns [a_offset, a_offset + M)
-    (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,M,tiles] when want_stats)."""
+    (default: all of them).  X [nb,K,P] -> Y [nb,M,P] (+ stats [2,M,tiles] when want_stats).
+    red = (y_prev [nb,M,P], coef_prev [>=4,M]) (data-gradient launches, pro 2 / 3): Y is the gradient of the lazily
+    activated output of the layer with that pre-BN tensor and those coefficients; when the launch takes the direct f32x2
+    kernel the call returns a THIRD value, the RedSums its epilogue left for that layer's BatchNorm backward (with .gsum
+    [2,nb,M,P/red_group] when red_group is 16 or 32), else None as the third value."""
     _need(At, "At", torch.float32)
     if a_trans:                               # At is [M_total, lda]: the operand is rows [m0, m0+M) x cols [a_offset, a_offset+K)
         M_rows, lda = At.shape
@@ -523,7 +527,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                               _opt(rowbias), int(rb_group), y_ptr, int(y_rows),
                                                               _opt(stats), M, K, P, nb, _stream(X)),
                        "usip_mlp_narrow_forward_f32")
-        return Y, stats
+        return (Y, stats, None) if red is not None else (Y, stats)
     bf16 = _matmul_mode == "bf16"
     fn_name = {"bf16": "usip_mlp_gemm_bf16", "f32x3": "usip_mlp_gemm_f32x3",
                "f32x2": "usip_mlp_gemm_f32x3"}.get(_matmul_mode, "usip_mlp_gemm_f32")
@@ -592,20 +596,36 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                                                         _opt(pool_dp), _opt(pool_arg), int(pool_group), y_ptr,
                                                         int(y_rows), _opt(stats), M, K, P, nb, _stream(X)),
                        "usip_mlp_gemm_x2r_f32")
-            return Y, stats
+            return (Y, stats, None) if red is not None else (Y, stats)
+        red_tiles = 0
+        if (red is not None and x2h and not x2r and pro >= 2 and out is None and bias is None and rowbias is None
+                and red[1] is not None and red[1].shape[0] >= 4 and tuple(red[0].shape) == (nb, M, P)
+                and red[0].is_contiguous() and red[0].data_ptr() % 16 == 0):
+            red_tiles = int(_lib.lib().usip_mlp_gemm_x2d_red_tiles(M, K, P, nb, int(red_group)))
+        if red_tiles:
+            flat = torch.empty(2 * red_tiles * M + red_tiles * (M // 256), dtype=torch.float32, device=X.device)
+            gsum = torch.empty((2, nb, M, P // red_group), dtype=torch.float32, device=X.device) if red_group else None
+            _lib.check(_lib.lib().usip_mlp_gemm_x2h_red_f32(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
+                                                            _opt(coef), int(pro), _opt(pool_dp), _opt(pool_arg),
+                                                            int(pool_group), y_ptr, _ptr(red[0]), _ptr(red[1]), _ptr(flat),
+                                                            _opt(gsum), int(red_group), M, K, P, nb, _stream(X)),
+                       "usip_mlp_gemm_x2h_red_f32")
+            r = RedSums(flat, M, blocks=red_tiles)
+            r.gsum = gsum
+            return Y, stats, r
         if x3p:
             fn = "usip_mlp_gemm_x2h_f32" if x2h else "usip_mlp_gemm_x3p_f32"
             _lib.check(getattr(_lib.lib(), fn)(_ptr(planes), None if pool is not None else _ptr(X), _opt(X2),
                                                _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                _opt(pool_dp), _opt(pool_arg), int(pool_group), y_ptr,
                                                int(y_rows), _opt(stats), M, K, P, nb, _stream(X)), fn)
-            return Y, stats
+            return (Y, stats, None) if red is not None else (Y, stats)
         _lib.check(getattr(_lib.lib(), fn_name)(a_ptr, -lda if a_trans else lda,
                                                 None if pool is not None else _ptr(X), _opt(X2),
                                                 _opt(coef), int(pro), _opt(bias), _opt(rowbias), int(rb_group),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group),
                                                 y_ptr, int(y_rows), _opt(stats), M, K, P, nb, _stream(X)), fn_name)
-    return Y, stats
+    return (Y, stats, None) if red is not None else (Y, stats)
 
 
 def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_var):
@@ -730,8 +750,11 @@ class RedSums:
     """What a fused layer backward leaves for the layer that produced its input: `sums` [2, blocks, C] partial
     BatchNorm-backward sums and `maxima` [blocks] of |dX [relu on]| -- views of one flat buffer."""
 
-    def __init__(self, flat: torch.Tensor, C: int):
-        blocks = flat.numel() // (2 * C + 1)
+    def __init__(self, flat: torch.Tensor, C: int, blocks: Optional[int] = None):
+        """blocks: rows of the partial sums when the buffer holds another number of maxima than that (the direct GEMM's
+        data-gradient epilogue: one maximum per 256-row tile)."""
+        if blocks is None:
+            blocks = flat.numel() // (2 * C + 1)
         self.flat = flat
         self.sums = flat[:2 * blocks * C].view(2, blocks, C)
         self.maxima = flat[2 * blocks * C:]
