@@ -328,7 +328,7 @@ __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&ac
     }
 }
 
-template <int PRO, int EPI, bool KTAIL, int DEPTH>
+template <int PRO, int EPI, bool KTAIL, int DEPTH, bool REDK = false, bool GEN = false>
 __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x2d_kernel(
     const GemmArgs a, const uint4* __restrict__ planes)
 {
@@ -628,12 +628,12 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                       acc[6][0][6] + acc[7][0][7];
     } else {
         float* scr = reinterpret_cast<float*>(smem + 2 * DSTAGE);
-        const bool inside = a.y_vec && m0 + DBM <= a.M && p0 + DBN <= a.P && (!a.rowbias || a.rb_group % 4 == 0) &&
-                            (long long)a.y_rows * a.P * 4 < (1LL << 31);
-        if (inside && a.rowbias) epilogue_x2d_fast<EPI, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
-        else if (inside && TWO && a.red_out) epilogue_x2d_fast<EPI_NONE, false, TWO>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
-        else if (inside) epilogue_x2d_fast<EPI, false>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
-        else epilogue_x2d<EPI>(a, acc, out_scale, scr, 2 * DSTAGE / 4, b, m0, p0, tn, tpc);
+        // GEN (chosen by the launcher when not every tile lies inside the tensor, or the stores cannot be 16-B vectors):
+        // the general epilogue; otherwise only the lean one is compiled in (both in one kernel cost registers)
+        if constexpr (GEN) epilogue_x2d<EPI>(a, acc, out_scale, scr, 2 * DSTAGE / 4, b, m0, p0, tn, tpc);
+        else if constexpr (REDK) epilogue_x2d_fast<EPI_NONE, false, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
+        else if (a.rowbias) epilogue_x2d_fast<EPI, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
+        else epilogue_x2d_fast<EPI, false>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
     }
     __syncthreads();                                           // the scratch becomes ring again
     }                                                          // tiles
@@ -662,15 +662,34 @@ int launch_gemm_x2d(const GemmArgs& a_in, const uint4* pl, int pro, hipStream_t 
         return n;
     }();
     const long long slots = (long long)(2 * cus) / 8 * 8;
+    // the lean epilogue needs every tile inside the tensor, 16-B vector stores, 32-bit offsets, a row bias per run of 4
+    const bool gen = !(a.y_vec && a.M % DBM == 0 && a.P % DBN == 0 && (!a.rowbias || a.rb_group % 4 == 0) &&
+                       (long long)a.y_rows * a.P * 4 < (1LL << 31));
     const bool one_tile_each = (usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) == 4;     // measurement: knob x2_direct = 4
     dim3 grid((unsigned)((total <= slots || (total & 7) || one_tile_each) ? total : slots)), block(DNT);
 #define USIP_X2D_CASE(P_, E_)                                                                  \
     if (pro == P_ && epi == E_) {                                                              \
-        if (tail) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, true, 1>), grid, block, 0, st, a, pl);  \
+        if (gen && tail) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, true, 1, false, true>), grid, block, 0, st, a, pl);  \
+        else if (gen) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, false, 1, false, true>), grid, block, 0, st, a, pl); \
+        else if (tail) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, true, 1>), grid, block, 0, st, a, pl);  \
         else if (deep) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, false, 2>), grid, block, 0, st, a, pl); \
         else USIP_LAUNCH((gemm_x2d_kernel<P_, E_, false, 1>), grid, block, 0, st, a, pl);      \
         USIP_LAUNCH_CHECK();                                                                   \
         return USIP_OK;                                                                        \
+    }
+    if (a.red_out) {
+        // the variant whose epilogue also takes the producing layer's BatchNorm-backward sums: its own instantiation (in
+        // one kernel with the plain epilogue it cost the plain launches 10 % through register pressure)
+        if (tail || gen || epi != EPI_NONE || (pro != PRO_BN_BWD && pro != PRO_BN_BWD_POOL)) return USIP_EINVAL;
+        if (pro == PRO_BN_BWD) {
+            if (deep) USIP_LAUNCH((gemm_x2d_kernel<PRO_BN_BWD, EPI_NONE, false, 2, true>), grid, block, 0, st, a, pl);
+            else USIP_LAUNCH((gemm_x2d_kernel<PRO_BN_BWD, EPI_NONE, false, 1, true>), grid, block, 0, st, a, pl);
+        } else {
+            if (deep) USIP_LAUNCH((gemm_x2d_kernel<PRO_BN_BWD_POOL, EPI_NONE, false, 2, true>), grid, block, 0, st, a, pl);
+            else USIP_LAUNCH((gemm_x2d_kernel<PRO_BN_BWD_POOL, EPI_NONE, false, 1, true>), grid, block, 0, st, a, pl);
+        }
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
     }
     USIP_X2D_CASE(PRO_AFFINE_RELU, EPI_STATS)
     USIP_X2D_CASE(PRO_AFFINE_RELU, EPI_NONE)
