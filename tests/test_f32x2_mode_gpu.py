@@ -267,6 +267,32 @@ def test_f32x2_falls_back_where_no_bound_exists(x2_forced):
     ops.set_matmul_mode(prev)
 
 
+def test_f32x2_falls_back_when_the_statistics_cover_more_samples_than_the_launch(x2_forced):
+    """The two-plane kernels bound |relu(bn(y))| by |gamma| sqrt(n) + |beta| with n = the positions of THEIR launch
+    (ADVICE r3): coefficients whose statistics were taken over more samples (here: the launch sees half the tensor)
+    do not carry that bound, so the launch must take the three-plane kernel -- same bits as f32x3 mode."""
+    from usip_amd import ops
+    K, M, P = 256, 256, 2048
+    g = torch.Generator().manual_seed(2)
+    At = torch.randn(K, M, generator=g).to(DEV)
+    X = torch.randn(4, K, P, generator=g).to(DEV)
+    mean, var = X.mean((0, 2)), X.var((0, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    coef = torch.stack([invstd, -mean * invstd, mean, invstd]).contiguous()
+    assert ops.bound_covers(coef, 4 * P)                    # no recorded count: taken as the launch's own
+    coef._usip_samples = 4 * P                              # what ops.bn_finalize records
+    assert ops.bound_covers(coef, 4 * P) and ops.bound_covers(coef, 8 * P) and not ops.bound_covers(coef, 2 * P)
+    half = X[:2].contiguous()
+    y_half = ops.mlp_gemm(At, half, pro=1, coef=coef)[0]
+    y_full = ops.mlp_gemm(At, X, pro=1, coef=coef)[0]
+    prev = ops.set_matmul_mode("f32x3")
+    try:
+        assert torch.equal(ops.mlp_gemm(At, half, pro=1, coef=coef)[0], y_half)        # fell back
+        assert not torch.equal(ops.mlp_gemm(At, X, pro=1, coef=coef)[0], y_full)       # the full launch did not
+    finally:
+        ops.set_matmul_mode(prev)
+
+
 def _bn_layer_inputs(g, nb, C, P, scale=1.0):
     """A pre-BatchNorm tensor with its training-mode forward coefficients [4, C] (scale, shift, mean, invstd)."""
     x = (torch.randn(nb, C, P, generator=g) * scale + 0.3 * torch.randn(1, C, 1, generator=g)).to(DEV)

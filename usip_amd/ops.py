@@ -535,7 +535,7 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
     x3p = x3 and not a_trans and K <= (512 if pro >= 2 else 640)       # weight operand split ahead of time
     # two fp16 planes: only where the streamed operand's bound is known (see usip_mlp_gemm_x2h_f32)
     x2h = (x3p and _matmul_mode == "f32x2" and coef is not None and
-           ((pro == 1 and coef.shape[0] >= 4) or (pro >= 2 and coef.shape[0] >= 5)))
+           ((pro == 1 and coef.shape[0] >= 4 and bound_covers(coef, nb * P)) or (pro >= 2 and coef.shape[0] >= 5)))
     # 128-wide layers: weight fragments resident in registers, persistent workgroups (usip_mlp_gemm_x2r_f32)
     x2r = (x2h and M <= 128 and K <= 128 and X2R and K * P < 2 ** 30          # (usip_mlp_gemm_x2r_f32's own limits)
            and (rowbias is None or (pro == 1 and rb_ok and rb_group >= 32)))
@@ -644,7 +644,20 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
                                                    float(eps), float(momentum), _opt(running_mean),
                                                    _opt(running_var), _ptr(mean), _ptr(invstd), _ptr(coef),
                                                    _stream(stats)), "usip_bn_finalize_f32")
+    # the f32x2 kernels bound |relu(bn(y))| by |gamma| sqrt(n) + |beta| with n = the samples of THEIR launch; that holds
+    # when the statistics were taken over no more samples than that (bound_covers)
+    coef._usip_samples = int(count)
     return mean, invstd, coef
+
+
+def bound_covers(coef, samples: int) -> bool:
+    """May a launch over `samples` positions per channel use the BatchNorm bound of `coef` (its [4,C] batch
+    statistics)?  |y - mean| <= sqrt(n var) holds over the n samples the statistics were taken over; a launch that
+    assumes n' = its own sample count under-estimates the bound when n' < n (a slice of the tensor, coefficients of
+    another batch).  Coefficients without a recorded count (built by hand in tests and tools) are taken as the
+    launch's own."""
+    n = getattr(coef, "_usip_samples", None)
+    return n is None or n <= samples
 
 
 def bn_apply(Y, coef, relu: bool):
@@ -724,7 +737,7 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     x3 = _x3_family() and not (M <= 64 and N <= 64) and bool(_lib.lib().usip_mlp_wgrad_f32x3_used(M, N, P, nb))
     # two fp16 planes: both operands need a bound (coef4 with its fifth row, xcoef = batch statistics)
     x2h = (x3 and _matmul_mode == "f32x2" and pro >= 2 and coef4 is not None and coef4.shape[0] >= 5 and M > 128 and N > 128
-           and xcoef is not None and xcoef.shape[0] >= 4 and P % 4 == 0)
+           and xcoef is not None and xcoef.shape[0] >= 4 and P % 4 == 0 and bound_covers(xcoef, nb * P))
     if x2h:
         fn_name = "usip_mlp_wgrad_x2h_f32"
 
@@ -820,6 +833,9 @@ def layer_backward_x2_supported(Cin: int, Cout: int, P: int, tensors=(), coef4=N
     if _matmul_mode != "f32x2" or not LAYER_BWD_X2:
         return False
     if coef4 is None or coef4.shape[0] < 5 or xcoef is None or xcoef.shape[0] < 4:
+        return False
+    nb = next((t.shape[0] for t in tensors if t is not None and t.dim() == 3), None)
+    if nb is not None and not bound_covers(xcoef, int(nb) * int(P)):
         return False
     if not _lib.lib().usip_mlp_layer_backward_x2h_supported(int(Cin), int(Cout), int(P), 1 if pooled else 0):
         return False
