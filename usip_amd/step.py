@@ -304,7 +304,7 @@ class _GraphedStep:
             # several-ranks-on-one-GPU debugging mode) cannot be captured, a refused capture falls back, and
             # USIP_GRAPH_ALLREDUCE=0 keeps the two-graph form for A/B runs.
             # (only ever attempted with RCCL: a gloo all-reduce inside a capture aborts the process -- tried, r04aa)
-            fuse = (world > 1 and not getattr(self, "solo", False)
+            fuse = (world > 1 and not getattr(self, "solo", False) and not getattr(self, "solo_fuse_off", False)
                     and os.environ.get("USIP_GRAPH_ALLREDUCE", "1") not in ("0", "off")
                     and dist.get_backend(group) == "nccl" and self.allreduce_events is None)
             entry = None
@@ -367,8 +367,17 @@ class _GraphedStep:
                 every = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
                 dist.all_gather(every, mine, group=group)
                 if any(float(e) != float(every[0]) for e in every):
-                    raise RuntimeError("usip_amd: gradients differ across ranks after the captured all-reduce; "
-                                       "set USIP_GRAPH_ALLREDUCE=0")
+                    # the captured collective did not reduce: one step was taken on un-averaged gradients.  Put the
+                    # replicas back together (rank 0's parameters and optimizer state), give up the fused form for
+                    # this step object and go on with graph A / eager all-reduce / graph B.
+                    import warnings
+                    warnings.warn("usip_amd: gradients differ across ranks after the captured all-reduce; replicas "
+                                  "re-synchronised from rank 0, continuing with the all-reduce between two graphs")
+                    self._resync_from_rank0(group)
+                    self.solo_fuse_off = True
+                    self.allreduce_in_graph = False
+                    for k in [k for k, e in self._graphs.items() if e[5]]:
+                        del self._graphs[k]
             self.last = last
             return loss
         ga.replay()
@@ -379,6 +388,23 @@ class _GraphedStep:
             gb.replay()
         self.last = last
         return loss
+
+    def _resync_from_rank0(self, group):
+        """Every replica takes rank 0's parameters, BatchNorm buffers and optimizer state (used once, if ever: when a
+        captured all-reduce turned out not to reduce)."""
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        tensors = [p.data for p in self.module.parameters()] + [b for b in self.module.buffers()]
+        opt = self.optimizer
+        if opt is not None and hasattr(opt, "state"):
+            for st in opt.state.values():
+                tensors += [v for v in st.values() if torch.is_tensor(v)]
+        seen = set()
+        for t in tensors:
+            base = t._base if t._base is not None else t
+            if base.data_ptr() in seen:
+                continue                                      # views of one flat buffer: once
+            seen.add(base.data_ptr())
+            dist.broadcast(base, src=src, group=group)
 
     def static_batch(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """The captured input buffers for batches shaped like `batch` (None before capture): a loader that
