@@ -1,6 +1,11 @@
 """The shader clock the chip holds while a given kernel of the step runs (tools/probes/clockmon.hip: a one-wave monitor
 samples s_memtime / s_memrealtime on a side stream while the kernel is launched back to back on torch's stream).
-    python tools/clock_under_kernel.py            -> one line per kernel + the replayed step"""
+    python tools/clock_under_kernel.py            -> one line per kernel + the replayed step
+CAVEAT (measured, round 4): the monitor wave takes a wave slot.  Kernels that fill the register file with persistent
+workgroups (gemm_x2d: 2 x 4 waves of 256 registers per CU) lose one workgroup slot on the CU the monitor sits on; the
+displaced workgroup runs after the others (226 -> 305 us) and the chip idles, at a high clock, meanwhile: for those
+kernels the number printed here is too high and the in-kernel probe (tools/x2d_trace.patch: 1.07 GHz) is the
+measurement.  For the streaming kernels (small workgroups, many of them) the monitor costs nothing."""
 import ctypes
 import os
 import subprocess
