@@ -328,7 +328,36 @@ __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&ac
     }
 }
 
-template <int PRO, int EPI, bool KTAIL, int DEPTH, bool REDK = false, bool GEN = false>
+// DIRECT (data-gradient launches: no statistics, no bias, every tile inside the tensor): the MFMA operands are NOT swapped
+// -- weights as A, the streamed operand as B -- so a lane holds ONE position and 16 channels per accumulator tile, and
+// every accumulator register is a store of two full 128-B lines (rows r and r + 4, 32 positions each) straight from the
+// registers: no LDS round trip, no barrier behind the tile.  (The swapped form exists for the statistics: with a lane =
+// a channel they are sums over registers.)
+__device__ __forceinline__ void epilogue_x2d_direct(const GemmArgs& a, f32x16 (&acc)[8][1], float out_scale, int b, int m0, int p0)
+{
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.Y + (long long)b * a.y_rows * a.P), 0, (unsigned)a.y_rows * (unsigned)a.P * 4u, 0x00020000);
+    const int voff = ((m0 + 4 * half) * a.P + p0 + wave * 32 + c) * 4;
+    const int rowb = a.P * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][0][4 * g + e] * out_scale;          // 2^n: exact
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), rY, voff, (i * 32 + 8 * g + e) * rowb, 0);
+            // the stores read their data registers late (see epilogue_x2d_fast): nothing may overwrite v[] at once
+            asm volatile("s_nop 7" ::: "memory");
+        }
+    }
+}
+
+template <int PRO, int EPI, bool KTAIL, int DEPTH, bool REDK = false, bool GEN = false, bool DIRECT = false>
 __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x2d_kernel(
     const GemmArgs a, const uint4* __restrict__ planes)
 {
@@ -541,7 +570,8 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             Frag& F = (u & 1) ? FB : FA;
             const f16x8& x = (i / 2 == 1) ? xl : xh;
             const f16x8& f = (i / 2 == 0) ? F.lo[i & 1] : F.hi[i & 1];
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t][0]) : "v"(x), "v"(f));
+            if constexpr (DIRECT) asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %1, %0" : "+a"(acc[t][0]) : "v"(x), "v"(f));
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[t][0]) : "v"(x), "v"(f));
         };
         auto filler = [&](int sl) {
             const int u = sl / 6, i = sl % 6;
@@ -630,12 +660,13 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float* scr = reinterpret_cast<float*>(smem + 2 * DSTAGE);
         // GEN (chosen by the launcher when not every tile lies inside the tensor, or the stores cannot be 16-B vectors):
         // the general epilogue; otherwise only the lean one is compiled in (both in one kernel cost registers)
-        if constexpr (GEN) epilogue_x2d<EPI>(a, acc, out_scale, scr, 2 * DSTAGE / 4, b, m0, p0, tn, tpc);
+        if constexpr (DIRECT) epilogue_x2d_direct(a, acc, out_scale, b, m0, p0);
+        else if constexpr (GEN) epilogue_x2d<EPI>(a, acc, out_scale, scr, 2 * DSTAGE / 4, b, m0, p0, tn, tpc);
         else if constexpr (REDK) epilogue_x2d_fast<EPI_NONE, false, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
         else if (a.rowbias) epilogue_x2d_fast<EPI, true>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
         else epilogue_x2d_fast<EPI, false>(a, acc, out_scale, scr, b, m0, p0, tn, tpc);
     }
-    __syncthreads();                                           // the scratch becomes ring again
+    if constexpr (!DIRECT) __syncthreads();                    // the scratch becomes ring again (DIRECT never used it)
     }                                                          // tiles
 }
 
@@ -667,6 +698,19 @@ int launch_gemm_x2d(const GemmArgs& a_in, const uint4* pl, int pro, hipStream_t 
                        (long long)a.y_rows * a.P * 4 < (1LL << 31));
     const bool one_tile_each = (usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) == 4;     // measurement: knob x2_direct = 4
     dim3 grid((unsigned)((total <= slots || (total & 7) || one_tile_each) ? total : slots)), block(DNT);
+    // data gradients whose output needs nothing but the scale: unswapped MFMA operands, stores straight from the registers
+    const bool direct = !gen && !tail && deep && epi == EPI_NONE && !a.red_out && !a.bias && !a.rowbias &&
+                        (usip_tuning_value(USIP_TUNE_X2_DIRECT) & 15) != 8;              // measurement: knob x2_direct = 8
+    if (direct && pro == PRO_BN_BWD) {
+        USIP_LAUNCH((gemm_x2d_kernel<PRO_BN_BWD, EPI_NONE, false, 2, false, false, true>), grid, block, 0, st, a, pl);
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
+    }
+    if (direct && pro == PRO_BN_BWD_POOL) {
+        USIP_LAUNCH((gemm_x2d_kernel<PRO_BN_BWD_POOL, EPI_NONE, false, 2, false, false, true>), grid, block, 0, st, a, pl);
+        USIP_LAUNCH_CHECK();
+        return USIP_OK;
+    }
 #define USIP_X2D_CASE(P_, E_)                                                                  \
     if (pro == P_ && epi == E_) {                                                              \
         if (gen && tail) USIP_LAUNCH((gemm_x2d_kernel<P_, E_, true, 1, false, true>), grid, block, 0, st, a, pl);  \

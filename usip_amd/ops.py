@@ -565,11 +565,15 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                     depth = 2 if (not tail and (K // 16) % 2 == 0 and (_lib.lib().usip_tuning_value(6) & 15) != 2) else 1
                     tiles_ = nb * ((P + 127) // 128) * ((M + 255) // 256)
                     wg = tiles_ if (tiles_ <= 512 or tiles_ % 8) else 512
-                    # (+ the two epilogue instantiations: <.., RED, general>; the general one runs DEPTH 1)
+                    # (+ the epilogue instantiations: <.., RED, general, DIRECT>; the general one runs DEPTH 1; DIRECT =
+                    # data gradients that need nothing but the scale: stores straight from the registers)
                     gen = M % 256 != 0 or P % 128 != 0
-                    return "gemm_x2d_kernel<%d, %d, %s, %d, %s, %s> |wg=%d" % (
+                    direct = (not gen and not tail and depth == 2 and e == 0 and red is None and bias is None
+                              and rowbias is None and pro >= 2 and (_lib.lib().usip_tuning_value(6) & 15) != 8)
+                    return "gemm_x2d_kernel<%d, %d, %s, %d, %s, %s, %s> |wg=%d" % (
                         pro, e, "true" if tail else "false", 1 if gen else depth,
-                        "true" if red is not None else "false", "true" if gen else "false", wg)
+                        "true" if red is not None else "false", "true" if gen else "false",
+                        "true" if direct else "false", wg)
             return "gemm_x3p_kernel<%d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3,
                                                                    nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
         if x3:
