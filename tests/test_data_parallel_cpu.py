@@ -56,6 +56,27 @@ def _worker(rank, world, port, q):
     gathered = [torch.empty_like(flat_p) for _ in range(world)]
     dist.all_gather(gathered, flat_p)
     ok = ok and torch.equal(gathered[0], gathered[1])
+    # replicas that drifted apart (what a captured all-reduce that did not reduce would leave behind) are put back
+    # together from rank 0: parameters, BatchNorm buffers, optimizer state -- usip_amd.step._resync_from_rank0
+    import types
+    from usip_amd import step as step_mod
+    if rank == 1:
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.add_(0.5)
+            for b_ in net.buffers():
+                if b_.dtype.is_floating_point:
+                    b_.add_(1.0)
+            for st_ in opt.state.values():
+                st_["exp_avg"].add_(2.0)
+    owner = next(c for c in vars(step_mod).values() if isinstance(c, type) and "_resync_from_rank0" in vars(c))
+    owner._resync_from_rank0(types.SimpleNamespace(module=net, optimizer=opt), None)
+    for t in [p_.detach() for p_ in net.parameters()] + [b_ for b_ in net.buffers() if b_.dtype.is_floating_point] + \
+            [st_["exp_avg"] for st_ in opt.state.values()]:
+        flat_t = t.reshape(-1).float()
+        both = [torch.empty_like(flat_t) for _ in range(world)]
+        dist.all_gather(both, flat_t)
+        ok = ok and torch.equal(both[0], both[1])
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -399,7 +399,10 @@ class _GraphedStep:
             for st in opt.state.values():
                 tensors += [v for v in st.values() if torch.is_tensor(v)]
         seen = set()
+        nccl = dist.get_backend(group) == "nccl"
         for t in tensors:
+            if nccl and not t.is_cuda:
+                continue                                      # (a host-side step counter: RCCL moves device memory only)
             base = t._base if t._base is not None else t
             if base.data_ptr() in seen:
                 continue                                      # views of one flat buffer: once
