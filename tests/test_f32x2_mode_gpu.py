@@ -594,6 +594,40 @@ def test_direct_gemm_forward_is_fp32_accurate(shape, heavy, x2_forced):
         assert torch.equal(ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)[0], Y)
 
 
+@pytest.mark.parametrize("shape", [(4, 256, 256, 8192), (2, 512, 512, 8192), (8, 256, 512, 4096), (4, 64, 256, 8192)])
+@pytest.mark.parametrize("stats", [False, True])
+def test_all_dma_forward_gemm_equals_the_direct_one_bit_for_bit(shape, stats, x2_forced):
+    """csrc/gemm_x2e.hip (both operands by LDS-DMA, one 8-wave workgroup per CU; opt-in, knob x2_direct = 10) computes
+    what csrc/gemm_x2d.hip computes, in the same order: outputs bit-identical, statistics equal after the sum over the
+    tiles (its 256-position tile fills the first of two 128-position slots), with and without a row bias."""
+    from usip_amd import _lib, ops
+    nb, K, M, P = shape
+    g = torch.Generator().manual_seed(11)
+    At = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+    X = (torch.randn(nb, K, P, generator=g) * 1.7 + 0.2).to(DEV)
+    bias = torch.randn(M, generator=g).to(DEV)
+    mu, var = X.mean(dim=(0, 2)), X.var(dim=(0, 2), unbiased=False)
+    istd = torch.rsqrt(var + 1e-5)
+    coef = torch.stack([istd, -mu * istd, mu, istd]).contiguous()
+    rowbias = torch.randn(nb, M, P // 64, generator=g).to(DEV)
+    ops.PLANES_CACHE = {}
+    try:
+        for rb in (None, rowbias):
+            kw = dict(want_stats=stats, pro=1, coef=coef, rowbias=rb, rb_group=64 if rb is not None else 1)
+            y0, s0 = ops.mlp_gemm(At, X, bias, **kw)
+            _lib.lib().usip_set_tuning(b"x2_direct", 10)
+            y1, s1 = ops.mlp_gemm(At, X, bias, **kw)
+            _lib.lib().usip_set_tuning(b"x2_direct", 0)
+            assert torch.equal(y0, y1)
+            if stats:
+                assert not torch.equal(s0, s1)                  # (it did run: its second slots are zero)
+                t0, t1 = s0.double().sum(dim=2), s1.double().sum(dim=2)
+                assert float((t0 - t1).abs().max() / t0.abs().max()) < 1e-6
+    finally:
+        _lib.lib().usip_set_tuning(b"x2_direct", 0)
+        ops.PLANES_CACHE = None
+
+
 @pytest.mark.parametrize("shape", [s for s in DIRECT_SHAPES if s[1] <= 512])
 @pytest.mark.parametrize("gscale", [1.0, 1e-6])
 def test_direct_gemm_backward_is_fp32_accurate(shape, gscale, x2_forced):

@@ -49,6 +49,8 @@ for rnd in range(2):
         t = raw[:, :, :63].reshape(2, 4, 21, 3)
         period = np.diff(t[:, :, :, 0], axis=2)
         bar = t[:, :, :, 2] - t[:, :, :, 1]
-        print("knob %4d: %6.1f us per launch | workgroup lifetime %7.0f cycles -> %.2f GHz | stage period mean %5.0f min %5d max %5d | barrier %4.0f"
-              % (kn, us, life, life / (us * 1e3), period.mean(), period.min(), period.max(), bar.mean()), flush=True)
+        wait = t[:, :, :, 1] - t[:, :, :, 0]
+        print("knob %4d: %6.1f us per launch | workgroup lifetime %7.0f cycles -> %.2f GHz | stage period mean %5.0f min %5d max %5d | counted wait %4.0f (max %d) | barrier %4.0f (per wave: %s)"
+              % (kn, us, life, life / (us * 1e3), period.mean(), period.min(), period.max(), wait.mean(), wait.max(), bar.mean(),
+                 " ".join("%d" % v for v in bar.mean(axis=2).reshape(-1))), flush=True)
 _lib.lib().usip_set_tuning(b"x2_direct", 0)

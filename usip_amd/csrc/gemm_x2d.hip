@@ -676,6 +676,7 @@ namespace usip_mlp {
 
 int launch_gemm_x2d(const GemmArgs& a_in, const uint4* pl, int pro, hipStream_t st)
 {
+    if (!a_in.red_out && gemm_x2e_takes(a_in, pro)) return launch_gemm_x2e(a_in, pl, st);
     GemmArgs a = a_in;
     a.a_trans = usip_tuning_value(USIP_TUNE_X2_DIRECT) >> 4;   // measurement aid, see the kernel (0 in the product)
     const int tpc = (a.P + DBN - 1) / DBN, nmt = (a.M + DBM - 1) / DBM;

@@ -235,6 +235,9 @@ int launch_wgrad_x3_256(const WgradArgs& a, int pro, bool xpro, unsigned blocks,
 // f32x2 forward / data gradient with the streamed operand global -> registers -> MFMA (gemm_x2d.hip); `pl` = the
 // usip_mlp_split2h_f32 image with 256-row tiles; tiles of 256 channels x 128 positions
 int launch_gemm_x2d(const GemmArgs& a, const uint4* pl, int pro, hipStream_t st);
+// gemm_x2e.hip: the forward launches of that family with both operands by LDS-DMA (one 8-wave workgroup per CU)
+bool gemm_x2e_takes(const GemmArgs& a, int pro);
+int launch_gemm_x2e(const GemmArgs& a, const uint4* pl, hipStream_t st);
 // the same from two fp16 planes per operand (pro 2 / 3 with the [5][M] coef4, xcoef = [4][N] batch statistics)
 int launch_wgrad_x2h_256(const WgradArgs& a, int pro, unsigned blocks, hipStream_t st);
 
