@@ -34,6 +34,10 @@ const char* usip_version(void);
 /* Launch-geometry knobs for measurement sweeps (tools/): they change HOW a result is computed (rows per
  * workgroup, prefetch depth, tile order), never the result.  0 restores the library's heuristic.  No reference
  * counterpart.  Returns USIP_EINVAL for an unknown name. */
+/* "x2_direct" (USIP_TUNE_X2_DIRECT), low four bits: 1 = the LDS-staged f32x2 GEMM of round 3 instead of csrc/gemm_x2d.hip,
+ * 2 = one stage of operand loads in flight, 4 = one tile per workgroup, 8 = the LDS-transposing epilogue for data gradients
+ * too, 10 = csrc/gemm_x2e.hip (both operands by LDS-DMA, 8-wave workgroups) for the forward launches that fit it; bits 4-5
+ * skip the main loop / the epilogue (time splits: wrong results, tools/x2_knob_bench.py only). */
 enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_X3_WGRAD_TILE, USIP_TUNE_X3_GEMM_TILE,
        USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_X2_DIRECT, USIP_TUNE_COUNT };
 int usip_set_tuning(const char* name, int value);
