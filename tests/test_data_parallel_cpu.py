@@ -126,3 +126,33 @@ def test_product_forward_refuses_host_tensors():
     x = torch.randn(1, 3, 64)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(x, torch.randn(1, 4, 64), x[:, :, :8].contiguous())
+
+
+def test_flat_adam_takes_a_per_parameter_adam_checkpoint():
+    """the CPU / gloo path trains with torch.optim.Adam (one state per parameter), the GPU path with FlatAdam
+    (one state over the flat buffer).  A checkpoint of the former loads into the latter: moments end to end in
+    parameter order, the step count, the (decayed) learning rate; FlatAdam's own checkpoint round-trips."""
+    from usip_amd.networks import DetectorOptions, build_detector
+    from usip_amd.step import FlatAdam
+    torch.manual_seed(1)
+    net = build_detector("som", DetectorOptions(surface_normal_len=3))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    for p in net.parameters():
+        p.grad = torch.randn_like(p)
+    opt.step()
+    opt.param_groups[0]["lr"] = 2.5e-4
+    sd = opt.state_dict()
+    n = sum(p.numel() for p in net.parameters())
+    flat = torch.nn.Parameter(torch.zeros(n))
+    fa = FlatAdam(flat, lr=1e-3)
+    fa.load_state_dict(sd)
+    st = fa.state[flat]
+    want = torch.cat([opt.state[p]["exp_avg_sq"].reshape(-1) for p in net.parameters()])
+    assert torch.equal(st["exp_avg_sq"], want)
+    assert torch.equal(st["exp_avg"], torch.cat([opt.state[p]["exp_avg"].reshape(-1) for p in net.parameters()]))
+    assert float(st["step"]) == 1.0 and fa.param_groups[0]["lr"] == 2.5e-4
+    own = fa.state_dict()
+    fb = FlatAdam(torch.nn.Parameter(torch.zeros(n)), lr=1e-3)
+    fb.load_state_dict(own)
+    assert torch.equal(fb.state[fb.param]["exp_avg"], st["exp_avg"]) and fb.param_groups[0]["lr"] == 2.5e-4
+    assert own["state"][0]["step"].dim() == 0

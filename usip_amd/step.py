@@ -117,8 +117,22 @@ class FlatAdam:
                     param_groups=[{k: (v if k != "params" else [0]) for k, v in self.param_groups[0].items()}])
 
     def load_state_dict(self, sd):
+        """Takes its own checkpoints AND a per-parameter torch.optim.Adam one of the same module (what the CPU / gloo
+        path writes): the per-parameter moments are laid end to end in parameter order -- the order the flat buffer
+        holds the parameters in."""
         st = self.state[self.param]
-        for k, v in sd["state"][0].items():
+        state = sd["state"]
+        if len(state) > 1 or (len(state) == 1 and torch.as_tensor(state[next(iter(state))]["exp_avg"]).numel() != st["exp_avg"].numel()):
+            keys = sorted(state)
+            n = sum(torch.as_tensor(state[k]["exp_avg"]).numel() for k in keys)
+            if n != st["exp_avg"].numel():
+                raise ValueError("FlatAdam.load_state_dict: the checkpoint holds %d moments, the flat parameter has %d"
+                                 % (n, st["exp_avg"].numel()))
+            for name in ("exp_avg", "exp_avg_sq"):
+                st[name].copy_(torch.cat([torch.as_tensor(state[k][name]).reshape(-1).to(st[name].dtype) for k in keys]))
+            st["step"].fill_(float(torch.as_tensor(state[keys[0]]["step"])))
+            state = None
+        for k, v in (state[0].items() if state is not None else ()):
             st[k].copy_(torch.as_tensor(v).reshape(st[k].shape))
         for k, v in (sd.get("param_groups") or [{}])[0].items():     # a decayed learning rate survives a resume
             if k != "params":
