@@ -501,6 +501,8 @@ def main():
                                ("" if args.no_optimizer else "+adam"),
                        "launch": ("HIP graph replay (ONE graph per step: forward, backward, RCCL all-reduce, Adam)"
                                   if getattr(st, "allreduce_in_graph", False) else
+                                  "HIP graph replay (ONE graph per step: forward, backward, Adam)"
+                                  if any(e[5] for e in getattr(st, "_graphs", {}).values()) else
                                   "HIP graph replay (2 graphs per step, all-reduce between them)") if graphed else "eager",
                        "parallelism": "dp%d" % world, "tuning": args.tune or None},
             "pairs_per_s": clouds / elapsed / 2, "loss": loss_val,

@@ -321,17 +321,21 @@ class _GraphedStep:
             fuse = (world > 1 and not getattr(self, "solo", False) and not getattr(self, "solo_fuse_off", False)
                     and os.environ.get("USIP_GRAPH_ALLREDUCE", "1") not in ("0", "off")
                     and dist.get_backend(group) == "nccl" and self.allreduce_events is None)
+            # a single process has nothing between backward and update either: one graph (USIP_GRAPH_ONE=0: two, for A/B)
+            fuse = fuse or ((world == 1 or getattr(self, "solo", False)) and self.optimizer is not None
+                            and os.environ.get("USIP_GRAPH_ONE", "1") not in ("0", "off"))
             entry = None
             if fuse:
                 try:
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                         loss = self._forward_backward(static, epoch)
-                        self.bucket.all_reduce_mean(group)
+                        if world > 1 and not getattr(self, "solo", False):
+                            self.bucket.all_reduce_mean(group)
                         if self.optimizer is not None:
                             self.optimizer.step()
                     entry = (g1, None, static, dict(self.last), loss, True)
-                    self.allreduce_in_graph = True
+                    self.allreduce_in_graph = world > 1 and not getattr(self, "solo", False)
                 except Exception as err:                      # noqa: BLE001  (a backend that cannot be captured says so its own way)
                     import warnings
                     warnings.warn("usip_amd: the gradient all-reduce could not be captured (%s); replaying two graphs "
@@ -373,7 +377,7 @@ class _GraphedStep:
             if hasattr(self.optimizer, "sync_hyper"):
                 self.optimizer.sync_hyper()                   # (before the replay: the update is inside it)
             ga.replay()
-            if not getattr(self, "_fused_checked", False):
+            if self.allreduce_in_graph and not getattr(self, "_fused_checked", False):
                 # once per step object: after an all-reduce every rank holds the same gradient -- if the captured
                 # collective did not do what the eager one does, say so now instead of training on garbage
                 self._fused_checked = True
