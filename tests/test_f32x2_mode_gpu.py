@@ -594,6 +594,41 @@ def test_direct_gemm_forward_is_fp32_accurate(shape, heavy, x2_forced):
         assert torch.equal(ops.mlp_gemm(At, X, bias=bias, want_stats=True, pro=1, coef=coef)[0], Y)
 
 
+@pytest.mark.parametrize("pooled", [False, True])
+def test_data_gradient_stores_straight_from_the_registers_at_chip_filling_size(pooled, x2_forced):
+    """The DIRECT epilogue of csrc/gemm_x2d.hip (data gradients: unswapped MFMA operands, 128 dword stores per wave and
+    tile, `s_nop 7` behind each group) at the size where the store hazard of round 4 showed -- 2048 tiles, two persistent
+    workgroups per CU: 20 launches agree in every bit, and with the LDS-transposing epilogue (knob x2_direct = 8)."""
+    from usip_amd import _lib, ops
+    nb, C, P, K = 16, 512, 8192, 16
+    g = torch.Generator().manual_seed(21)
+    y, gamma_y, mean_y, invstd_y, coef_y = _bn_layer_inputs(g, nb, C, P)
+    w2 = (torch.randn(C, C, generator=g) * 0.06).to(DEV)
+    ops.PLANES_CACHE = {}
+    try:
+        if pooled:
+            M = P // K
+            pooled_v, arg = ops.group_max_act(y.view(nb, C, M, K), coef_y, True)
+            dpooled = torch.randn(nb, C, M, generator=g).to(DEV)
+            coef4 = ops.bn_pool_backward_reduce(dpooled, arg, y.view(nb, C, M, K), coef_y, mean_y, invstd_y, gamma_y, True)[2]
+            run = lambda: ops.mlp_gemm(w2, None, pro=3, X2=y, coef=coef4, tag="dgrad", pool=(dpooled, arg, K))[0]
+        else:
+            dz = torch.randn(nb, C, P, generator=g).to(DEV)
+            coef4 = ops.bn_backward_reduce(dz, y, coef_y, mean_y, invstd_y, gamma_y, True)[2]
+            run = lambda: ops.mlp_gemm(w2, dz, pro=2, X2=y, coef=coef4, tag="dgrad")[0]
+        ref = run().clone()
+        for _ in range(20):
+            assert torch.equal(run(), ref)
+        _lib.lib().usip_set_tuning(b"x2_direct", 8)
+        other = run()
+        _lib.lib().usip_set_tuning(b"x2_direct", 0)
+        assert torch.equal(other, ref)
+        assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
+    finally:
+        _lib.lib().usip_set_tuning(b"x2_direct", 0)
+        ops.PLANES_CACHE = None
+
+
 @pytest.mark.parametrize("shape", [(4, 256, 256, 8192), (2, 512, 512, 8192), (8, 256, 512, 4096), (4, 64, 256, 8192)])
 @pytest.mark.parametrize("stats", [False, True])
 def test_all_dma_forward_gemm_equals_the_direct_one_bit_for_bit(shape, stats, x2_forced):
