@@ -470,3 +470,18 @@ def test_nearest_first_index_when_squared_distances_differ_but_distances_tie():
     assert np.array_equal(d.cpu().numpy(), want_d.numpy())
     assert np.array_equal(arg.cpu().numpy(), want_arg.numpy())
     assert int(arg[0, 1]) == 200 and int(arg[0, 2]) == 100 and int(arg[1, 3]) == 900
+
+
+@pytest.mark.parametrize("B,M", [(3, 37), (16, 515), (40, 513)])
+def test_ball_query_coords_rows_per_wave_variants_equal_the_dist_in_pair(B, M):
+    """The fused coords-in kernel picks 1, 2 or 4 node rows per wave by the number of rows of the launch (round 4: two
+    rows at the detector's 16 x 512 -- 55 instead of 64 us -- because 2048 waves do not hide the L2 round trips); every
+    variant, with node counts that leave a partial wave, equals usip_pairwise_dist_f32 + usip_ball_query_f32 bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(100 + B)
+    N, K = 2052, 64
+    x = (torch.rand(B, 3, N, generator=g) * 6 - 3).to(DEV)
+    node = x[:, :, torch.randint(0, N, (M,), generator=g).to(DEV)].contiguous()
+    d = ops.pairwise_dist(node, x)
+    for r in (float(d[0, 0, 7]), 1.3, 0.0):
+        assert torch.equal(ops.ball_query_coords(node, x, r, K), ops.ball_query(d, r, K))

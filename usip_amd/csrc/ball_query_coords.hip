@@ -11,11 +11,11 @@
 // the neighbours of radius^2 with a correctly rounded sqrt (sqrt_threshold, on the host).
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 
 namespace {
 
-constexpr int R = 4;          // node rows per wave
 
 // Largest float T with sqrt_rn(T) <= radius (host sqrtf and the device's __fsqrt_rn are both
 // correctly rounded IEEE operations, so the threshold can be derived on the host).
@@ -33,7 +33,10 @@ static float sqrt_threshold(float radius)
     return t;
 }
 
-template <bool VEC>
+// R = node rows per wave: every point a wave loads is tested against R nodes (fewer L2 bytes per test), but a launch has
+// only B * M / R waves -- 2048 at R = 4 for the detector's 16 clouds of 512 nodes, two per SIMD, too few to hide the L2
+// round trip of the next block of points behind the tests of the current one.
+template <bool VEC, int R>
 __global__ __launch_bounds__(256) void ball_query_coords_kernel(
     const float* __restrict__ node, const float* __restrict__ x, int32_t* __restrict__ out,
     float T, int K, int M, int N)
@@ -159,12 +162,17 @@ extern "C" int usip_ball_query_coords_f32(const float* node, const float* x, int
     const float T = sqrt_threshold(radius);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (N >= 4) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    static const int forced = [] { const char* e = getenv("USIP_BQ_ROWS"); return e ? atoi(e) : 0; }();
+    // rows per wave: 4 when that still gives every SIMD four waves (>= 4096 waves), else 2, else 1
+    const long long rows = (long long)B * M;
+    int R = rows >= 4 * 4096 ? 4 : (rows >= 2 * 4096 ? 2 : 1);
+    if (forced == 1 || forced == 2 || forced == 4) R = forced;
     dim3 grid(usip_ceil_div(M, 4 * R), B), block(256);
     const size_t lds = (size_t)4 * R * K * sizeof(int);
-    if (vec)
-        USIP_LAUNCH((ball_query_coords_kernel<true>), grid, block, lds, st, node, x, out_idx, T, K, M, N);
-    else
-        USIP_LAUNCH((ball_query_coords_kernel<false>), grid, block, lds, st, node, x, out_idx, T, K, M, N);
+#define USIP_BQC(V_, R_) USIP_LAUNCH((ball_query_coords_kernel<V_, R_>), grid, block, lds, st, node, x, out_idx, T, K, M, N)
+    if (vec) { if (R == 4) USIP_BQC(true, 4); else if (R == 2) USIP_BQC(true, 2); else USIP_BQC(true, 1); }
+    else     { if (R == 4) USIP_BQC(false, 4); else if (R == 2) USIP_BQC(false, 2); else USIP_BQC(false, 1); }
+#undef USIP_BQC
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }
