@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# hand-built BatchNorm coefficients of the kernel tests carry no recorded sample count: take them as the launch's own
+# (the library's default is strict -- usip_amd/ops.py::bound_covers; the whole-step test switches this off again)
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

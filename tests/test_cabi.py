@@ -40,19 +40,34 @@ def test_dropin_modules_have_reference_entry_points():
         assert callable(getattr(ball_query, fn))         # ball_query.cpp:45-48
 
 
-def test_device_entry_points_reject_host_and_noncontiguous_tensors():
-    """CHECK_INPUT of the reference -> RuntimeError (index_max.cpp:119-121, ball_query.cpp:10-12).
-    There is no CPU fallback behind the device entry points."""
+def test_device_entry_points_take_host_tensors_to_the_host_twins_and_never_mix():
+    """"`forward_cuda_shared_mem` of both modules accepts CPU tensors so networks.py runs on CPU unchanged"
+    (BASELINE configs[0]).  ALL tensor arguments on the host -> the product's own host twins (csrc/host_cpu.cpp; never
+    oracle/); a host/device mix or a wrong dtype is still the reference's CHECK_INPUT RuntimeError
+    (index_max.cpp:119-121, ball_query.cpp:10-12); the tensor-level device wrappers (usip_amd.ops) refuse host tensors."""
     import usip_amd
+    from usip_amd import ops
     im, bq = usip_amd.install()
-    d = torch.randn(2, 3, 16)
-    i = torch.zeros(2, 16, dtype=torch.int32)
+    g = load_golden("index_max_cases.npz")
+    d, i, K = torch.from_numpy(g["ties_data"]), torch.from_numpy(g["ties_index"]), int(g["ties_K"])
+    for fn in (im.forward_cuda_shared_mem, im.forward_cuda):
+        out = fn(d, i, K)
+        assert out.dtype == torch.int32 and not out.is_cuda and np.array_equal(out.numpy(), g["ties_out"])
+    # strided views, as networks.py may hand over: read through their strides like the reference's accessor
+    wide = torch.zeros(d.shape[0], d.shape[1], 2 * d.shape[2])
+    wide[:, :, ::2] = d
+    assert np.array_equal(im.forward_cuda_shared_mem(wide[:, :, ::2], i, K).numpy(), g["ties_out"])
+    gd = load_golden("dist_ball_cases.npz")
+    dist = torch.from_numpy(gd["dist"])
+    for fn in (bq.forward_cuda_shared_mem, bq.forward_cuda):
+        out = fn(dist, float(gd["radius"]), int(gd["K"]))
+        assert out.dtype == torch.int32 and np.array_equal(out.numpy(), gd["ball_idx_unpinned"])
+    with pytest.raises(RuntimeError, match="int32|Int"):
+        im.forward_cuda_shared_mem(d, i.long(), K)
     with pytest.raises(RuntimeError, match="CUDA tensor"):
-        im.forward_cuda_shared_mem(d, i, 4)
+        ops.index_max(d, i, K)
     with pytest.raises(RuntimeError, match="CUDA tensor"):
-        im.forward_cuda(d, i, 4)
-    with pytest.raises(RuntimeError, match="CUDA tensor"):
-        bq.forward_cuda_shared_mem(torch.rand(2, 3, 16), 0.5, 4)
+        ops.ball_query(dist, 0.5, 4)
 
 
 @pytest.mark.parametrize("tag", ["random", "ties", "floor", "empty", "nan", "tiny", "n_lt_wave"])

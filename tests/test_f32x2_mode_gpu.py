@@ -267,7 +267,7 @@ def test_f32x2_falls_back_where_no_bound_exists(x2_forced):
     ops.set_matmul_mode(prev)
 
 
-def test_f32x2_falls_back_when_the_statistics_cover_more_samples_than_the_launch(x2_forced):
+def test_f32x2_falls_back_when_the_statistics_cover_more_samples_than_the_launch(x2_forced, monkeypatch):
     """The two-plane kernels bound |relu(bn(y))| by |gamma| sqrt(n) + |beta| with n = the positions of THEIR launch
     (ADVICE r3): coefficients whose statistics were taken over more samples (here: the launch sees half the tensor)
     do not carry that bound, so the launch must take the three-plane kernel -- same bits as f32x3 mode."""
@@ -279,8 +279,11 @@ def test_f32x2_falls_back_when_the_statistics_cover_more_samples_than_the_launch
     mean, var = X.mean((0, 2)), X.var((0, 2), unbiased=False)
     invstd = torch.rsqrt(var + 1e-5)
     coef = torch.stack([invstd, -mean * invstd, mean, invstd]).contiguous()
-    assert ops.bound_covers(coef, 4 * P)                    # no recorded count: taken as the launch's own
-    coef._usip_samples = 4 * P                              # what ops.bn_finalize records
+    assert ops.bound_covers(coef, 4 * P)                    # no recorded count + the tests' opt-in: the launch's own
+    monkeypatch.delenv("USIP_ASSUME_LAUNCH_SAMPLES")
+    assert not ops.bound_covers(coef, 4 * P)                # the library's default: no count, no bound
+    ops.declare_samples(coef, 4 * P)                        # what ops.bn_finalize records (by address: it survives
+    assert ops.bound_covers(coef.detach()[:], 4 * P)        # detach(), views and ctx.saved_tensors)
     assert ops.bound_covers(coef, 4 * P) and ops.bound_covers(coef, 8 * P) and not ops.bound_covers(coef, 2 * P)
     half = X[:2].contiguous()
     y_half = ops.mlp_gemm(At, half, pro=1, coef=coef)[0]

@@ -475,18 +475,24 @@ def _config3_case():
     return _CFG3
 
 
-def test_config3_shape_parity_vs_oracle(matmul_mode_natural):
+def test_config3_shape_parity_vs_oracle(matmul_mode_natural, monkeypatch):
     """oracle parity AT THE SIZE THE BENCH TIMES, natural dispatch, all three fp32-accurate modes.
     Every index tensor bit-exact; node / keypoints / sigmas / the three losses / BatchNorm buffers within 1e-5 of the
     oracle (oracle/detector.py = the reference's ATen calls); gradients free-running with the flip-tolerant bound of
     test_detector_step_matches_reference (a handful of max-pool / ReLU decisions within rounding distance of a tie move
     gradient entries by O(1e-2): DESIGN.md 3)."""
+    from usip_amd import ops
     from usip_amd.step import DetectorStep, batch_to_device
     c = _config3_case()
     st = DetectorStep("ball", c["opt"], DEV)
     st.load_numpy_state(c["filled"])
+    # the library's own (strict) rule for BatchNorm bounds: every coefficient tensor the step hands to a two-plane
+    # kernel -- forward, and out of ctx.saved_tensors in backward -- must carry its recorded sample count (ADVICE r4)
+    monkeypatch.delenv("USIP_ASSUME_LAUNCH_SAMPLES", raising=False)
+    unknown = ops.UNKNOWN_SAMPLE_LOOKUPS
     st.step(batch_to_device(c["batch_np"], DEV))
     torch.cuda.synchronize()
+    assert ops.UNKNOWN_SAMPLE_LOOKUPS == unknown
     ref = c["res"]
     for k, v in st.detector.last_indices.items():
         assert np.array_equal(v.cpu().numpy(), ref[k].numpy()), k

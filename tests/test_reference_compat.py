@@ -61,3 +61,80 @@ def test_reference_networks_builds_unchanged_on_our_modules():
         assert res["ours"][cls + "/fused"] == res["theirs"][cls], cls    # usip_amd.networks' own classes too
         assert res["ours"][cls + "/layer_module"] == "usip_amd.layers"
         assert res["theirs"][cls + "/layer_module"] == "models.layers"
+
+
+FORWARD_SCRIPT = textwrap.dedent("""
+    import sys, types, json
+    import numpy as np, torch
+    import matplotlib; matplotlib.use("Agg")
+    sys.path.insert(0, %r); sys.path.insert(0, %r)
+    sys.modules["torchvision"] = types.ModuleType("torchvision")
+    import usip_amd
+    from usip_amd import synth
+    im, bq = usip_amd.install()                # `import index_max` / `import ball_query` -> usip_amd.dropin (HOST twins here)
+    assert "oracle" not in sys.modules
+    rec = {}
+    def wrap(mod, name, key):
+        inner = getattr(mod, name)
+        def f(*a):
+            out = inner(*a)
+            assert not out.is_cuda and out.dtype == torch.int32
+            rec[key if key == "ball_idx" else "%%s_%%d" %% (key, sum(k.startswith(key) for k in rec))] = out.numpy().copy()
+            return out
+        setattr(mod, name, f)
+    wrap(im, "forward_cuda_shared_mem", "index_max")
+    wrap(bq, "forward_cuda_shared_mem", "ball_idx")
+    from models import networks                # the reference's own networks.py AND its own layers.py, unchanged
+    assert networks.index_max is im and networks.ball_query is bq
+    assert type(networks.RPN_Detector).__module__ != "usip_amd.networks"
+    torch.set_num_threads(8)
+    class Opt: pass
+    out = {}
+    for fixture, cls in (("detector_som_cfg1.npz", "RPN_Detector"), ("detector_ball_micro.npz", "RPN_Detector_Ball")):
+        g = np.load(%r + "/" + fixture)
+        opt = Opt()
+        opt.activation, opt.normalization, opt.k = "relu", "batch", 1
+        opt.bn_momentum, opt.bn_momentum_decay_step, opt.bn_momentum_decay = 0.1, None, 0.6
+        opt.surface_normal_len = int(g["in/src_sn"].shape[1])
+        opt.node_knn_k_1, opt.loss_sigma_lower_bound = int(g["cfg_knn"]), float(g["cfg_sigma_lb"])
+        net = getattr(networks, cls)(opt)
+        assert type(net.mlp1).__module__ == "models.layers"
+        sd = net.state_dict()
+        filled = synth.fill_parameters({k: tuple(v.shape) for k, v in sd.items()})
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)).reshape(sd[k].shape) for k, v in filled.items()})
+        net.train()
+        rec.clear()
+        t = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in/")}
+        node, kp, sg, _ = net(torch.cat((t["src_pc"], t["dst_pc"]), 0), torch.cat((t["src_sn"], t["dst_sn"]), 0),
+                              torch.cat((t["src_node"], t["dst_node"]), 0), True, None)
+        res = {"calls": sorted(rec)}
+        for k, v in rec.items():
+            res["idx_equal/" + k] = bool(np.array_equal(v, g["idx/" + k]))
+        for k, v in (("node", node), ("keypoints", kp), ("sigmas", sg)):
+            a, b = v.detach().numpy().astype(np.float64), g[k].astype(np.float64)
+            res["rel/" + k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        out[cls] = res
+    print(json.dumps(out))
+""") % (ROOT, REF, os.path.join(ROOT, "tests", "golden"))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_reference_networks_forward_runs_on_cpu_over_the_dropin_modules():
+    """VERDICT r4 missing #3 / #5, SURVEY 8b: the reference's OWN models/networks.py + models/layers.py, unchanged, on
+    PyTorch CPU, with `index_max` / `ball_query` = usip_amd.dropin (whose forward_cuda_shared_mem hands host tensors to
+    the product's host twins in csrc/host_cpu.cpp; oracle/ is never imported).  RPN_Detector at BASELINE configs[0] size
+    (N=1024, M=64, batch 2 pairs) and RPN_Detector_Ball forward in train mode: every index tensor the two modules return
+    equals the fixture the reference produced with its own C++ (index_max) / the pinned restatement (ball_query), and
+    node / keypoints / sigmas agree to 1e-5."""
+    import json
+    p = subprocess.run([sys.executable, "-c", FORWARD_SCRIPT], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    assert res["RPN_Detector"]["calls"] == ["index_max_0", "index_max_1"]          # networks.py:118,131
+    assert res["RPN_Detector_Ball"]["calls"] == ["ball_idx"]                       # networks.py:698
+    for cls, r in res.items():
+        for k, v in r.items():
+            if k.startswith("idx_equal/"):
+                assert v is True, (cls, k)
+            if k.startswith("rel/"):
+                assert v <= 1e-5, (cls, k, v)

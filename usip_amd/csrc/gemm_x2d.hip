@@ -540,7 +540,7 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 2 * hf; j < 2 * hf + 2; ++j)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst + j * 4096), "v"(a_voff), "s"(rAv), "s"(kt * DSTAGE + j * 4096) : "memory");
+                         :: "s"(dst + j * 4096), "v"(a_voff), "s"(rAv), "s"(kt * DSTAGE + j * 4096) : "memory", "m0");
     };
     constexpr int NX = POOL ? 24 : (TWO ? 16 : 8);             // register loads of one stage of the streamed operand
     // Memory instructions issued AFTER the last DMA instruction of the previous stage (slot 5) when this stage's barrier

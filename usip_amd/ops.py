@@ -5,6 +5,7 @@ memory + stream plumbing only), enqueues the HIP kernels on torch's CURRENT stre
 returns without synchronising.  Host tensors raise RuntimeError: there is no CPU path here.
 """
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -650,18 +651,38 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
                                                    _stream(stats)), "usip_bn_finalize_f32")
     # the f32x2 kernels bound |relu(bn(y))| by |gamma| sqrt(n) + |beta| with n = the samples of THEIR launch; that holds
     # when the statistics were taken over no more samples than that (bound_covers)
-    coef._usip_samples = int(count)
+    declare_samples(coef, int(count))
     return mean, invstd, coef
+
+
+# data_ptr of a [4,C] forward-coefficient tensor -> the number of samples its statistics were taken over.  Keyed by
+# ADDRESS, not by a Python attribute: the tensor a backward pass gets back from ctx.saved_tensors, a detach() or a row
+# view is another Python object over the same memory, and an attribute would be gone.  bn_finalize
+# re-declares on every call, so an address that the allocator hands out again carries its newest producer's count.
+_SAMPLES = {}
+UNKNOWN_SAMPLE_LOOKUPS = 0          # bound_covers calls that found no recorded count (a whole step must leave this at 0)
+
+
+def declare_samples(coef, count: int):
+    """Record that the batch statistics in `coef` were taken over `count` samples per channel."""
+    if len(_SAMPLES) > 8192:
+        _SAMPLES.clear()            # addresses of long-dead tensors; live ones are re-declared by their next bn_finalize
+    _SAMPLES[coef.data_ptr()] = int(count)
 
 
 def bound_covers(coef, samples: int) -> bool:
     """May a launch over `samples` positions per channel use the BatchNorm bound of `coef` (its [4,C] batch
     statistics)?  |y - mean| <= sqrt(n var) holds over the n samples the statistics were taken over; a launch that
     assumes n' = its own sample count under-estimates the bound when n' < n (a slice of the tensor, coefficients of
-    another batch).  Coefficients without a recorded count (built by hand in tests and tools) are taken as the
-    launch's own."""
-    n = getattr(coef, "_usip_samples", None)
-    return n is None or n <= samples
+    another batch) and could overflow the fp16 planes.  Coefficients WITHOUT a recorded count do not cover anything
+    (the launch takes the bound-free f32x3 path); hand-built coefficients in tests and tools either call
+    declare_samples or set USIP_ASSUME_LAUNCH_SAMPLES=1 (tests/conftest.py), which takes them as the launch's own."""
+    global UNKNOWN_SAMPLE_LOOKUPS
+    n = _SAMPLES.get(coef.data_ptr())
+    if n is None:
+        UNKNOWN_SAMPLE_LOOKUPS += 1
+        return os.environ.get("USIP_ASSUME_LAUNCH_SAMPLES") == "1"
+    return n <= samples
 
 
 def bn_apply(Y, coef, relu: bool):

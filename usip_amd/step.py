@@ -56,9 +56,10 @@ class FlatGradBucket:
         for p in self.params:                                 # a new step: every parameter may be written once again
             p._usip_sink_used = False
 
-    def all_reduce_mean(self, group=None):
-        """sum over ranks then / world: gradients of the mean-of-means loss (equal shards)."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def all_reduce_mean(self, group=None, even_alone=False):
+        """sum over ranks then / world: gradients of the mean-of-means loss (equal shards).  even_alone: issue the
+        collective in a one-rank process group too (the one-GPU test that puts RCCL's all-reduce through a HIP graph)."""
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or even_alone):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
 
@@ -134,8 +135,14 @@ class FlatAdam:
             state = None
         for k, v in (state[0].items() if state is not None else ()):
             st[k].copy_(torch.as_tensor(v).reshape(st[k].shape))
-        for k, v in (sd.get("param_groups") or [{}])[0].items():     # a decayed learning rate survives a resume
-            if k != "params":
+        group = (sd.get("param_groups") or [{}])[0]
+        # the kernel implements plain Adam (what the reference constructs): a checkpoint that asks for more is refused,
+        # not silently trained without it
+        if float(group.get("weight_decay", 0.0) or 0.0) != 0.0 or group.get("amsgrad", False) or group.get("maximize", False):
+            raise ValueError("FlatAdam.load_state_dict: weight_decay / amsgrad / maximize are not implemented "
+                             "(models/keypoint_detector.py:42-45 uses none of them)")
+        for k, v in group.items():                            # a decayed learning rate survives a resume
+            if k in ("lr", "betas", "eps"):
                 self.param_groups[0][k] = tuple(v) if k == "betas" else v
         self.sync_hyper()
 
@@ -187,7 +194,8 @@ class _GraphedStep:
                 self._wt = (flat_wt, table, tiles,
                             {ptr: flat_wt[o:o + ci * co].view(ci, co) for ptr, (o, ci, co) in views.items()})
         self.last: Dict[str, torch.Tensor] = {}
-        # key -> (graph A, graph B or None, static batch, last, loss), least recently used first.  Every entry owns
+        # key -> dict(a = graph A, b = graph B or None, static = captured input buffers, last, loss, fused = one graph
+        # for the whole step, reduces = that graph holds the all-reduce, checked), least recently used first.  Every entry owns
         # a private memory pool with all activations of a step (GBs at N=16384), so the cache is bounded: a
         # training run with epoch-decayed BatchNorm momentum or varying cloud sizes evicts instead of growing.
         self._graphs: "OrderedDict" = OrderedDict()
@@ -196,6 +204,7 @@ class _GraphedStep:
         # (the collective itself runs on RCCL's stream; the launch stream waits for it, so the pair spans it)
         self.allreduce_events = None
         self.allreduce_in_graph = False                      # True once a step graph contains the all-reduce (RCCL)
+        self.exchange_even_alone = False                     # tests: treat a ONE-rank process group as data-parallel
         self._eager_calls = 0
         self._bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
         self._bn_counters = [m.num_batches_tracked for m in self._bns if m.num_batches_tracked is not None]
@@ -258,10 +267,18 @@ class _GraphedStep:
         """forward + losses + backward (+ gradient all-reduce) (+ Adam when constructed with it).
         eager=True forces plain launches for this call (bench.py does so on the steps it instruments with
         HIP events, which a graph replay cannot carry)."""
+        self._replay_this_call = True
         batch = self._prepare(batch)
-        if self.use_graph and not eager:
+        if self.use_graph and not eager and self._replay_this_call:
             return self._step_graph(batch, epoch, group)
         return self._step_eager(batch, epoch, group)
+
+    def _exchanges(self, group) -> bool:
+        """True when this step object exchanges gradients: a process group of more than one rank (or, for the one-GPU
+        RCCL test, of exactly one with exchange_even_alone), and not bench.py's solo probe."""
+        if getattr(self, "solo", False) or not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(group) > 1 or self.exchange_even_alone
 
     def _all_reduce(self, group):
         if getattr(self, "solo", False):                      # bench.py's single-rank probe inside a multi-rank job
@@ -269,11 +286,11 @@ class _GraphedStep:
         if self.allreduce_events is not None and self.device.type == "cuda":
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            self.bucket.all_reduce_mean(group)
+            self.bucket.all_reduce_mean(group, self.exchange_even_alone)
             e.record()
             self.allreduce_events.append((s, e))
         else:
-            self.bucket.all_reduce_mean(group)
+            self.bucket.all_reduce_mean(group, self.exchange_even_alone)
 
     def _step_eager(self, batch, epoch, group):
         loss = self._forward_backward(batch, epoch)
@@ -318,30 +335,46 @@ class _GraphedStep:
             # several-ranks-on-one-GPU debugging mode) cannot be captured, a refused capture falls back, and
             # USIP_GRAPH_ALLREDUCE=0 keeps the two-graph form for A/B runs.
             # (only ever attempted with RCCL: a gloo all-reduce inside a capture aborts the process -- tried, r04aa)
-            fuse = (world > 1 and not getattr(self, "solo", False) and not getattr(self, "solo_fuse_off", False)
+            distributed = self._exchanges(group)
+            fuse = (distributed and not getattr(self, "solo_fuse_off", False)
                     and os.environ.get("USIP_GRAPH_ALLREDUCE", "1") not in ("0", "off")
-                    and dist.get_backend(group) == "nccl" and self.allreduce_events is None)
+                    and (dist.get_backend(group) == "nccl" or getattr(self, "_test_fused_without_reduce", False))
+                    and self.allreduce_events is None)
             # a single process has nothing between backward and update either: one graph (USIP_GRAPH_ONE=0: two, for A/B)
-            fuse = fuse or ((world == 1 or getattr(self, "solo", False)) and self.optimizer is not None
+            fuse = fuse or (not distributed and self.optimizer is not None
                             and os.environ.get("USIP_GRAPH_ONE", "1") not in ("0", "off"))
             entry = None
             if fuse:
+                g1 = loss = None
                 try:
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):
                         loss = self._forward_backward(static, epoch)
-                        if world > 1 and not getattr(self, "solo", False):
-                            self.bucket.all_reduce_mean(group)
+                        # (_test_fused_without_reduce: tests/ only -- stands in for a captured collective that turns out
+                        # to be a no-op, the failure the check below exists for)
+                        if distributed and not getattr(self, "_test_fused_without_reduce", False):
+                            self.bucket.all_reduce_mean(group, self.exchange_even_alone)
                         if self.optimizer is not None:
                             self.optimizer.step()
-                    entry = (g1, None, static, dict(self.last), loss, True)
-                    self.allreduce_in_graph = world > 1 and not getattr(self, "solo", False)
+                    ok = True
                 except Exception as err:                      # noqa: BLE001  (a backend that cannot be captured says so its own way)
                     import warnings
                     warnings.warn("usip_amd: the gradient all-reduce could not be captured (%s); replaying two graphs "
                                   "with the all-reduce between them" % err)
                     torch.cuda.synchronize(self.device)
-                    entry = None
+                    ok = False
+                if distributed:
+                    # every rank adopts the one-graph form or none does: a rank whose capture failed would otherwise
+                    # issue an eager all-reduce its peers never join (they replay theirs from the graph) -- and hang
+                    ok = self._all_ranks_agree(ok, group)
+                if ok:
+                    entry = dict(a=g1, b=None, static=static, last=dict(self.last), loss=loss, fused=True,
+                                 reduces=distributed, checked=not distributed)
+                    self.allreduce_in_graph = distributed
+                else:
+                    del g1
+                    if distributed:
+                        self.solo_fuse_off = True             # one refusal is enough: later captures go two-graph directly
             if entry is None:
                 try:
                     # thread_local: calls other threads make meanwhile (a collective watchdog polling its events)
@@ -361,30 +394,29 @@ class _GraphedStep:
                     torch.cuda.synchronize(self.device)
                     self.use_graph = False
                     return self._step_eager(batch, epoch, group)
-                entry = (ga, gb, static, last, loss, False)   # capture launches nothing: replay below
-            self._graphs[key] = entry
+                entry = dict(a=ga, b=gb, static=static, last=last, loss=loss, fused=False, reduces=False, checked=True)
+            self._graphs[key] = entry                         # capture launches nothing: replay below
             while len(self._graphs) > self.max_graphs:
                 _, old = self._graphs.popitem(last=False)     # drops the graphs and, with them, their memory pool
                 del old
-        ga, gb, static, last, loss, fused = entry
+        static = entry["static"]
         for k, v in batch.items():
             if v.data_ptr() != static[k].data_ptr():
                 static[k].copy_(v, non_blocking=True)
         if key[1] is not None:                                # what the Python forward would have left behind
             for bn, m in zip(self._bns, key[1]):
                 bn.momentum = m
-        if fused:
+        if entry["fused"]:
             if hasattr(self.optimizer, "sync_hyper"):
                 self.optimizer.sync_hyper()                   # (before the replay: the update is inside it)
-            ga.replay()
-            if self.allreduce_in_graph and not getattr(self, "_fused_checked", False):
-                # once per step object: after an all-reduce every rank holds the same gradient -- if the captured
-                # collective did not do what the eager one does, say so now instead of training on garbage
-                self._fused_checked = True
-                mine = self.bucket.flat.detach().double().sum().reshape(1)
-                every = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
-                dist.all_gather(every, mine, group=group)
-                if any(float(e) != float(every[0]) for e in every):
+            entry["a"].replay()
+            self.last = entry["last"]
+            if entry["reduces"] and not entry["checked"]:
+                # once per CAPTURED GRAPH (a re-capture for another shape or BatchNorm momentum is checked again): after
+                # an all-reduce every rank holds the same gradient -- if the captured collective did not do what the
+                # eager one does, say so now instead of training on garbage
+                entry["checked"] = True
+                if not self._gradients_agree(group):
                     # the captured collective did not reduce: one step was taken on un-averaged gradients.  Put the
                     # replicas back together (rank 0's parameters and optimizer state), give up the fused form for
                     # this step object and go on with graph A / eager all-reduce / graph B.
@@ -394,18 +426,45 @@ class _GraphedStep:
                     self._resync_from_rank0(group)
                     self.solo_fuse_off = True
                     self.allreduce_in_graph = False
-                    for k in [k for k, e in self._graphs.items() if e[5]]:
+                    self.fused_fallbacks = getattr(self, "fused_fallbacks", 0) + 1
+                    for k in [k for k, e in self._graphs.items() if e["reduces"]]:
                         del self._graphs[k]
-            self.last = last
-            return loss
-        ga.replay()
+            return entry["loss"]
+        entry["a"].replay()
         self._all_reduce(group)
-        if gb is not None:
+        if entry["b"] is not None:
             if hasattr(self.optimizer, "sync_hyper"):
                 self.optimizer.sync_hyper()                   # a changed learning rate reaches the captured update
-            gb.replay()
-        self.last = last
-        return loss
+            entry["b"].replay()
+        self.last = entry["last"]
+        return entry["loss"]
+
+    def _all_ranks_agree(self, ok: bool, group) -> bool:
+        """Logical AND of `ok` over the ranks (an eager MIN all-reduce of one flag)."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(flag.item()))
+
+    def _gradients_agree(self, group) -> bool:
+        """True when every rank holds the same reduced gradient: the fp64 sum of the flat bucket, compared as BIT
+        PATTERNS (a NaN gradient is the same NaN everywhere after a sum all-reduce; comparing floats would call that
+        a disagreement and re-synchronise for nothing)."""
+        mine = self.bucket.flat.detach().double().sum().reshape(1).view(torch.int64)
+        every = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(every, mine, group=group)
+        return all(torch.equal(e, every[0]) for e in every)
+
+    def allreduce_form(self) -> str:
+        """How the gradient exchange is issued right now (bench.py logs it): "one graph" = captured RCCL all-reduce,
+        "two graphs" = eager all-reduce between graph A and graph B, "eager", or "none" (single process)."""
+        if not self._exchanges(None):
+            return "none"
+        if not self.use_graph:
+            return "eager"
+        if self.allreduce_in_graph:
+            return "one graph (captured all-reduce)"
+        return "two graphs (eager all-reduce between them)" + (
+            "; captured form refused or failed its check" if getattr(self, "solo_fuse_off", False) else "")
 
     def _resync_from_rank0(self, group):
         """Every replica takes rank 0's parameters, BatchNorm buffers and optimizer state (used once, if ever: when a
@@ -431,7 +490,7 @@ class _GraphedStep:
         """The captured input buffers for batches shaped like `batch` (None before capture): a loader that
         writes into them saves the per-step device copies."""
         for entry in self._graphs.values():
-            static = entry[2]
+            static = entry["static"]
             if all(k in static and static[k].shape == v.shape for k, v in batch.items()):
                 return {k: static[k] for k in batch}
         return None
@@ -464,22 +523,35 @@ class DetectorStep(_GraphedStep):
         opt.random_pc_dropout_lower_limit < 0.99, a keep ratio U(limit, 1) and that many point indices WITHOUT
         replacement are drawn on the host every step (random.uniform + np.random.choice, as there) and ONE index set
         selects the same points of src and dst clouds and normals.  The indices travel as batch["keep_idx"] (int64 [n]
-        device tensor; pass it yourself to fix the choice -- the parity fixture does).  The number of kept points
-        changes from step to step, so with graph=True every new count captures a new graph (bounded cache)."""
+        device tensor; pass it yourself to fix the choice -- the parity fixture does).  With several ranks rank 0 draws
+        and broadcasts, so the whole (sharded) batch sees one set per step as under nn.DataParallel.  The number of kept
+        points changes from step to step, so such steps run from plain launches even with graph=True."""
         limit = getattr(self.opt, "random_pc_dropout_lower_limit", 1.0)
+        self._replay_this_call = True
         if "keep_idx" not in batch and limit < 0.99:
             import random
             import numpy as np
             n_in = int(getattr(self.opt, "input_pc_num", batch["src_pc"].shape[2]))
-            keep = round(random.uniform(limit, 1.0) * n_in)
-            idx = np.random.choice(n_in, keep, replace=False)
-            batch = dict(batch, keep_idx=torch.from_numpy(idx).to(self.device))
+            # ONE draw per step for the whole batch, as in the reference (a single process behind nn.DataParallel):
+            # rank 0 draws, every rank trains on the same keep ratio and index set -- equal cloud sizes per step
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if not multi or dist.get_rank() == 0:
+                keep = round(random.uniform(limit, 1.0) * n_in)
+                idx = torch.from_numpy(np.random.choice(n_in, keep, replace=False)).to(self.device)
+            if multi:
+                count = torch.tensor([keep if dist.get_rank() == 0 else 0], dtype=torch.int64, device=self.device)
+                dist.broadcast(count, src=0)
+                if dist.get_rank() != 0:
+                    idx = torch.empty(int(count.item()), dtype=torch.int64, device=self.device)
+                dist.broadcast(idx, src=0)
+            batch = dict(batch, keep_idx=idx)
         if "keep_idx" in batch:
-            if self.use_graph:                                # a new point count almost every step: replay cannot pay off
-                import warnings
-                warnings.warn("usip_amd: random point dropout changes the cloud size every step; HIP-graph replay is "
-                              "switched off for this step object")
-                self.use_graph = False
+            if self.use_graph and not getattr(self, "_warned_dropout", False):
+                import warnings                                # a new point count almost every step: replay cannot pay off
+                warnings.warn("usip_amd: random point dropout changes the cloud size every step; steps that carry "
+                              "keep_idx run from plain launches, not from a HIP graph")
+                self._warned_dropout = True
+            self._replay_this_call = False                    # this call only: a later batch without keep_idx replays again
             batch = dict(batch)
             idx = batch.pop("keep_idx").long()
             self.last_keep = int(idx.numel())                 # points per cloud this step trains on
