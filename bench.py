@@ -534,6 +534,7 @@ def main():
         ar = sorted(s.elapsed_time(e) * 1e3 for s, e in ar_events)
         props = torch.cuda.get_device_properties(dev)
         mine = dict(rank=rank, local_rank=local_rank, device_index=dev.index, pid=os.getpid(),
+                    cores=sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
                     device_name=props.name, device_uuid=str(getattr(props, "uuid", "")),
                     pci_bus_id=int(getattr(props, "pci_bus_id", -1)), step_ms_wall=elapsed / args.steps * 1e3,
                     allreduce_us_p50=ar[len(ar) // 2] if ar else None,
@@ -609,7 +610,7 @@ def main():
             except Exception:                              # noqa: BLE001  (gloo debugging runs have no RCCL)
                 rccl = None
             out["ranks_seen"] = [{k: c[k] for k in ("rank", "local_rank", "device_index", "device_uuid", "pci_bus_id",
-                                                    "device_name", "pid")} for c in census]
+                                                    "device_name", "pid", "cores")} for c in census]
             out["distributed"] = {
                 "backend": backend, "rccl_version": rccl if backend == "nccl" else None, "world_size": world,
                 "distinct_devices": len({(c["device_index"], c["device_uuid"], c["pci_bus_id"]) for c in census}),

@@ -77,6 +77,38 @@ def _worker(rank, world, port, q):
         both = [torch.empty_like(flat_t) for _ in range(world)]
         dist.all_gather(both, flat_t)
         ok = ok and torch.equal(both[0], both[1])
+    # the two agreement primitives of the one-graph form (usip_amd/step.py): capture success is a logical AND over the
+    # ranks, and reduced gradients are compared as bit patterns -- a NaN everywhere is agreement, not a reason to re-sync
+    dev = torch.device("cpu")
+    ns = types.SimpleNamespace(device=dev, bucket=types.SimpleNamespace(flat=torch.full((8,), 3.0)))
+    ok = ok and owner._all_ranks_agree(ns, True, None) is True
+    ok = ok and owner._all_ranks_agree(ns, rank == 0, None) is False          # one rank's capture failed: nobody fuses
+    ok = ok and owner._gradients_agree(ns, None) is True
+    ns.bucket.flat = torch.full((8,), float("nan"))
+    ok = ok and owner._gradients_agree(ns, None) is True
+    ns.bucket.flat = torch.full((8,), float(rank))
+    ok = ok and owner._gradients_agree(ns, None) is False
+    # random point dropout (keypoint_detector.py:160-168): ONE keep ratio and index set per step for the whole batch --
+    # rank 0 draws, the others receive (host RNGs are deliberately seeded differently here)
+    import random
+    random.seed(100 + rank)
+    np.random.seed(200 + rank)
+    opt_d = DetectorOptions(surface_normal_len=3)
+    opt_d.random_pc_dropout_lower_limit, opt_d.input_pc_num = 0.5, 64
+    pre = types.SimpleNamespace(opt=opt_d, device=dev, use_graph=False, _SIAMESE=step_mod.DetectorStep._SIAMESE)
+    b = {k: torch.from_numpy(v) for k, v in mine.items()}
+    kept = step_mod.DetectorStep._prepare(pre, b)
+    n_kept = torch.tensor([kept["src_pc"].shape[2]])
+    both = [torch.empty_like(n_kept) for _ in range(world)]
+    dist.all_gather(both, n_kept)
+    ok = ok and int(both[0]) == int(both[1]) and 32 <= int(both[0]) <= 64 and pre._replay_this_call is False
+    # the points kept are the same columns on every rank: rank 1's first cloud gathered with rank 0's choice
+    col0 = kept["src_pc"][0, 0, :4].clone()
+    probe = torch.from_numpy(mine["src_pc"])[0, 0]
+    pos = torch.tensor([int((probe == v).nonzero()[0]) for v in col0])
+    both = [torch.empty_like(pos) for _ in range(world)]
+    dist.all_gather(both, pos)
+    ok = ok and torch.equal(both[0], both[1])
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -156,3 +188,22 @@ def test_flat_adam_takes_a_per_parameter_adam_checkpoint():
     fb.load_state_dict(own)
     assert torch.equal(fb.state[fb.param]["exp_avg"], st["exp_avg"]) and fb.param_groups[0]["lr"] == 2.5e-4
     assert own["state"][0]["step"].dim() == 0
+
+
+def test_flat_adam_refuses_checkpoint_options_it_does_not_implement():
+    """FlatAdam is plain Adam (what models/keypoint_detector.py:42-45 constructs); a checkpoint that asks for
+    weight decay or amsgrad is refused instead of being trained without it."""
+    import pytest
+    from usip_amd.step import FlatAdam
+    p = torch.nn.Parameter(torch.zeros(16))
+    p.grad = torch.zeros(16)
+    opt = FlatAdam(p, lr=1e-3)
+    sd = opt.state_dict()
+    sd["param_groups"][0]["lr"] = 5e-4
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]["lr"] == 5e-4
+    for key, val in (("weight_decay", 1e-4), ("amsgrad", True)):
+        bad = opt.state_dict()
+        bad["param_groups"][0][key] = val
+        with pytest.raises(ValueError, match="not implemented"):
+            opt.load_state_dict(bad)

@@ -1024,7 +1024,18 @@ def test_full_size_f32_and_f32x3_steps_agree():
     assert rel_norm <= 1e-6, rel_norm
 
 
-def test_bench_gpus_2_spawns_its_own_ranks():
+def _bench_line_and_record(res, out_dir, world):
+    """(compact line bench.py printed LAST, full record it wrote next to it)."""
+    import json
+    import os
+    text = res.stdout.decode()
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and text.strip().splitlines()[-1] == lines[0], text[-2000:]
+    assert len(lines[0]) <= (8000 if world == 1 else 12000), len(lines[0])
+    return json.loads(lines[0]), json.load(open(os.path.join(str(out_dir), "bench_full_n%d.json" % world)))
+
+
+def test_bench_gpus_2_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with NO launcher in the command: bench.py starts the two ranks itself (what the
     driver's SCALE run invokes).  gloo + both ranks on cuda:0 because this box has one GPU and RCCL refuses two
     ranks per device; the line must report two ranks, their census, and the all-reduce it timed."""
@@ -1033,16 +1044,18 @@ def test_bench_gpus_2_spawns_its_own_ranks():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, USIP_DIST_BACKEND="gloo", USIP_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, USIP_DIST_BACKEND="gloo", USIP_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               USIP_BENCH_OUT=str(tmp_path))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--pairs", "2",
            "--points", "4096", "--nodes", "128", "--no-cpu-baseline", "--no-kernel-timing"]
     res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert res.returncode == 0, res.stderr.decode()[-3000:]
-    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout.decode()[-2000:]
-    out = json.loads(lines[0])
+    line, out = _bench_line_and_record(res, tmp_path, 2)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and [r["rank"] for r in line["ranks"]] == [0, 1]
+    assert line["ranks"][0]["checksum"] == line["ranks"][1]["checksum"] and line["distributed"]["replicas_identical"]
+    assert line["distributed"]["allreduce_form"].startswith("two graphs")
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
     assert [r["rank"] for r in out["ranks_seen"]] == [0, 1]
     assert len({r["pid"] for r in out["ranks_seen"]}) == 2
@@ -1075,16 +1088,16 @@ def test_bench_two_ranks_graph_replay_on_one_gpu(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, USIP_DIST_BACKEND="gloo", USIP_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, USIP_DIST_BACKEND="gloo", USIP_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               USIP_BENCH_OUT=str(tmp_path))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "2", "--pairs", "2", "--points", "4096", "--nodes", "128", "--no-cpu-baseline",
            "--no-kernel-timing"]
     res = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert res.returncode == 0, res.stderr.decode()[-3000:]
-    lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout.decode()[-2000:]
-    out = json.loads(lines[0])
+    line, out = _bench_line_and_record(res, tmp_path, 2)
+    assert line["distributed"]["n1_probe"]["ratio"] > 0 and line["distributed"]["allreduce_in_graph"] is False
     assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["launch"].startswith("HIP graph replay"), out["config"]["launch"]
     assert "allreduce" in out["config"]["step"]
