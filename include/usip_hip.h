@@ -37,9 +37,13 @@ const char* usip_version(void);
 /* "x2_direct" (USIP_TUNE_X2_DIRECT), low four bits: 1 = the LDS-staged f32x2 GEMM of round 3 instead of csrc/gemm_x2d.hip,
  * 2 = one stage of operand loads in flight, 4 = one tile per workgroup, 8 = the LDS-transposing epilogue for data gradients
  * too, 10 = csrc/gemm_x2e.hip (both operands by LDS-DMA, 8-wave workgroups) for the forward launches that fit it; bits 4-5
- * skip the main loop / the epilogue (time splits: wrong results, tools/x2_knob_bench.py only). */
+ * skip the main loop / the epilogue (time splits: wrong results, tools/x2_knob_bench.py only).
+ * "r5_forms" (USIP_TUNE_R5_FORMS), bit flags that bring back round 4's form of a kernel for same-box A/B runs: 1 = the f32x2
+ * weight gradient with half-line loads (wgrad_x3_kernel<.., 2> instead of wgrad_x2l_kernel); and that switch ON forms round 5
+ * measured and did not keep: 2 / 4 = two / four loop iterations' loads in flight in the BatchNorm-backward reduction (default
+ * one), 8 = several batches of rows per workgroup with prefetch in group_max4 (default one). */
 enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_X3_WGRAD_TILE, USIP_TUNE_X3_GEMM_TILE,
-       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_X2_DIRECT, USIP_TUNE_COUNT };
+       USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_X2_DIRECT, USIP_TUNE_R5_FORMS, USIP_TUNE_COUNT };
 int usip_set_tuning(const char* name, int value);
 int usip_tuning_value(int knob);
 
@@ -390,6 +394,15 @@ int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int p
                        const float* xcoef, const float* pool_dp, const int32_t* pool_arg, int pool_group,
                        float* workspace, float* dW, int ldw, int coloff,
                        int M, int N, int P, int nb, void* stream);
+/* Deferred weight-gradient reductions (round 5; no reference counterpart -- the reference's autograd produces every dW
+ * where its layer's backward runs, models/layers.py:208-216).  Between usip_wgrad_defer(1) and usip_wgrad_flush(stream) every
+ * entry point that ends in the fixed-order sum of its partial tiles (usip_mlp_wgrad_*, usip_mlp_narrow_backward_f32,
+ * usip_mlp_layer_backward_x2h_f32) launches its tile kernel and RECORDS the sum instead of launching it; the flush issues all
+ * recorded sums in at most two launches (same summation order: same bits) and returns how many it issued (>= 0; < 0 error).
+ * The caller keeps every workspace alive until the flush.  usip_wgrad_defer(0) leaves the mode and drops what is recorded. */
+int usip_wgrad_defer(int on);
+int usip_wgrad_flush(void* stream);
+
 /* Backward of a NARROW layer (64 inputs, 64 or 128 outputs) in one pass over its tensors: data gradient AND weight
  * gradient from one staged tile of (dZ, Y, X) -- these layers are HBM-bound and the two separate products read
  * (dZ, Y) twice.  Replaces the pair usip_mlp_gemm_f32(pro = 2) + usip_mlp_wgrad_f32(pro = 2) for the grouped

@@ -186,6 +186,55 @@ def test_wgrad_f32x2_is_fp32_accurate(shape, gscale, x2_forced):
     assert torch.equal(ops.mlp_wgrad(dZ, X, pro=2, G2=Yp, coef4=coef4, xcoef=xcoef), dW)      # deterministic
 
 
+@pytest.mark.parametrize("shape", [(2, 512, 512, 4096), (3, 256, 256, 8192), (2, 512, 256, 2048), (1, 384, 200, 1000),
+                                   (2, 640, 512, 560), (16, 256, 256, 8192), (1, 512, 640, 36)])
+@pytest.mark.parametrize("pooled", [False, True])
+def test_full_line_wgrad_equals_the_half_line_kernel_bit_for_bit(shape, pooled, x2_forced):
+    """Round 5: wgrad_x2l_kernel (every load event = whole 128-B lines: rows [0,128) / [128,256) x 32 positions, two stage
+    PAIRS in LDS, one barrier per pair) against round 4's wgrad_x3_kernel<.., 2> (knob r5_forms = 1), which fetched half a
+    line per row and stage.  Same stages, same order, same MFMAs: the weight gradient must be the SAME BITS -- plain
+    (dZ, Y) and pooled (dpooled, arg, Y) prologues, row / column remainders (384 x 200, 512 x 640), an odd number of
+    16-position stages (P = 1000, 560, 36), one and many clouds."""
+    from usip_amd import _lib, ops
+    nb, M, N, P = shape
+    K = 8
+    if pooled and P % K:
+        P -= P % K
+    g = torch.Generator().manual_seed(M * 3 + N + P + int(pooled))
+    Yp = (torch.randn(nb, M, P, generator=g) * 2.0 + 0.5).to(DEV)
+    X = (torch.randn(nb, N, P, generator=g) * 3.0 - 1.0).to(DEV)
+    gm, bm = (1 + 0.3 * torch.randn(M, generator=g)).to(DEV), (0.3 * torch.randn(M, generator=g)).to(DEV)
+    gn, bn = (1 + 0.3 * torch.randn(N, generator=g)).to(DEV), (0.3 * torch.randn(N, generator=g)).to(DEV)
+    cf, xcoef = _bn_coef(Yp, gm, bm), _bn_coef(X, gn, bn)
+    if pooled:
+        dp = torch.randn(nb, M, P // K, generator=g).to(DEV)
+        arg = torch.randint(0, K, (nb, M, P // K), generator=g, dtype=torch.int32).to(DEV)
+        dZ = torch.zeros(nb, M, P // K, K, device=DEV).scatter_(3, arg.long().unsqueeze(-1), dp.unsqueeze(-1)).view(nb, M, P)
+        kw = dict(pro=3, G2=Yp, pool=(dp, arg, K))
+    else:
+        dZ = torch.randn(nb, M, P, generator=g).to(DEV)
+        kw = dict(pro=2, G2=Yp)
+    _, _, coef4, _ = ops.bn_backward_reduce(dZ, Yp, cf, cf[2].contiguous(), cf[3].contiguous(), gm, True)
+    assert coef4.shape[0] == 5
+    args = (None, X) if pooled else (dZ, X)
+    new = ops.mlp_wgrad(*args, coef4=coef4, xcoef=xcoef, **kw)
+    _lib.lib().usip_set_tuning(b"r5_forms", 1)
+    try:
+        old = ops.mlp_wgrad(*args, coef4=coef4, xcoef=xcoef, **kw)
+    finally:
+        _lib.lib().usip_set_tuning(b"r5_forms", 0)
+    assert torch.isfinite(new).all() and float(new.abs().max()) > 0
+    assert torch.equal(new, old)
+    # and it is the two-plane kernel that ran (f32x3 gives other bits)
+    prev = ops.set_matmul_mode("f32x3")
+    try:
+        assert not torch.equal(ops.mlp_wgrad(*args, coef4=coef4, xcoef=xcoef, **kw), new)
+    finally:
+        ops.set_matmul_mode(prev)
+    for _ in range(3):
+        assert torch.equal(ops.mlp_wgrad(*args, coef4=coef4, xcoef=xcoef, **kw), new)        # run-to-run
+
+
 def test_two_plane_split_is_exact_for_hard_values(x2_forced):
     """Single products isolated by a diagonal weight matrix: values with all 24 mantissa bits set, powers of two,
     exact zeros, elements 2^-20 below the tensor's largest.  With both operands scaled towards the top of the fp16

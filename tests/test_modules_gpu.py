@@ -855,6 +855,59 @@ def test_descriptor_graph_replay_equals_eager():
 
 
 
+@pytest.mark.parametrize("model", ["ball", "som"])
+def test_deferred_weight_gradient_reductions_change_no_bit(model, matmul_mode, monkeypatch):
+    """Round 5: inside a step the fixed-order sums of the weight gradients' partial tiles are recorded during backward and
+    issued together behind it (usip_wgrad_defer / usip_wgrad_flush: two launches instead of one per layer).  Same summation
+    order: losses, the gradient bucket and the parameters after three Adam steps are the SAME BITS as with every sum
+    launched behind its producer (USIP_DEFER_WGRAD=0) -- eagerly and from a HIP graph."""
+    from usip_amd import ops, synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8)
+    batch = batch_to_device(synth.make_pair_batch(22, 2, 2048, 64, 4, "sphere"), DEV)
+
+    def run(defer, graph):
+        monkeypatch.setenv("USIP_DEFER_WGRAD", "1" if defer else "0")
+        torch.manual_seed(17)
+        st = DetectorStep(model, opt, DEV, with_optimizer=True, graph=graph)
+        losses = [st.step(batch).detach().clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        return losses, st.bucket.flat.clone(), st.bucket.flat_param.detach().clone(), getattr(st, "deferred_reductions", 0)
+
+    l0, g0, p0, n0 = run(False, False)
+    assert n0 == 0
+    for graph in (False, True):
+        l1, g1, p1, n1 = run(True, graph)
+        assert n1 >= 8                                      # every layer's weight gradient went through the one flush
+        assert all(torch.equal(a, b) for a, b in zip(l0, l1))
+        assert torch.equal(g0, g1) and torch.equal(p0, p1)
+    assert ops._DEFER_KEEP is None                          # the mode never outlives a step
+
+
+def test_deferred_mode_is_left_when_backward_raises(monkeypatch):
+    """An exception inside backward must not leave the library recording reductions for whoever calls it next."""
+    from usip_amd import ops, synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    st = DetectorStep("ball", DetectorOptions(surface_normal_len=4, node_knn_k_1=8), DEV)
+    batch = batch_to_device(synth.make_pair_batch(23, 1, 1024, 32, 4, "sphere"), DEV)
+    real = ops.wgrad_flush
+
+    def boom(device):
+        raise RuntimeError("injected")
+    monkeypatch.setattr(ops, "wgrad_flush", boom)
+    with pytest.raises(RuntimeError, match="injected"):
+        st.step(batch)
+    monkeypatch.setattr(ops, "wgrad_flush", real)
+    assert ops._DEFER_KEEP is None
+    g = torch.Generator().manual_seed(0)
+    G, X = torch.randn(2, 64, 512, generator=g).to(DEV), torch.randn(2, 32, 512, generator=g).to(DEV)
+    dW = ops.mlp_wgrad(G, X)                                # launched AND reduced at once again
+    want = torch.einsum("bmp,bnp->mn", G.double(), X.double())
+    assert float((dW.double() - want).abs().max() / want.abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("model", ["ball", "som", "lite", "knn"])
 def test_training_is_reproducible_bit_for_bit(model, matmul_mode):
     """Every reduction on the path has a fixed order (BatchNorm partials, split-K weight gradients, chamfer and

@@ -22,6 +22,8 @@ SIGNATURES = {
     "usip_version": ([], ctypes.c_char_p),
     "usip_set_tuning": ([ctypes.c_char_p, _int], _int),
     "usip_tuning_value": ([_int], _int),
+    "usip_wgrad_defer": ([_int], _int),
+    "usip_wgrad_flush": ([_stream], _int),
     "usip_index_max_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_index_max_f32_cpu": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _int], _int),
     "usip_ball_query_f32": ([_f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),

@@ -101,62 +101,85 @@ __device__ __forceinline__ void argmax_step(float& best, int& bk, float& braw)
     if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
 }
 
+// A workgroup walks `nbatch` consecutive batches (one batch = RPT rows per thread group = 4 KiB per wave) and requests
+// batch j + 1 before it reduces batch j.  nbatch = 1 (one load latency per wave, 16384 workgroups per launch) is what the
+// library uses: round 5 built the loop expecting ball_query's gain (its waves loop over a 64 KiB row and read 6.7 TB/s
+// against 4.2-5.2 here) and measured it SLOWER inside the step, same box, alternating: 54.4-55.4 us per launch against
+// 46.8-47.8 (profiles/r05b_forms_ab.txt) -- many short workgroups spread this pass's reads over the chip better than
+// fewer long ones.  Kept behind knob r5_forms bit 3 as the measured form of that idea.  Same comparisons in the same
+// order: same results either way.
 template <int L>
 __global__ __launch_bounds__(256) void group_max4_kernel(
     const float* __restrict__ z, float* __restrict__ pooled, int32_t* __restrict__ arg, long long rows,
-    const float* __restrict__ coef, int relu, int C, int M, float* __restrict__ zarg)
+    const float* __restrict__ coef, int relu, int C, int M, float* __restrict__ zarg, int nbatch)
 {
     constexpr int RPB = 256 / L, RPT = 4;
     const int sub = threadIdx.x % L;
-    const long long row0 = (long long)blockIdx.x * RPB * RPT + threadIdx.x / L;
-    float4 v[RPT];
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const long long row = min(row0 + (long long)j * RPB, rows - 1);          // clamped: branch-free loads
-        v[j] = usip_load_stream4(z + (row * L + sub) * 4);
-    }
     const bool small = rows < (1LL << 31);
+    const long long first = (long long)blockIdx.x * nbatch;             // this workgroup's first batch
+    auto row_of = [&](long long batch, int j) { return batch * RPB * RPT + threadIdx.x / L + (long long)j * RPB; };
+    float4 v[RPT], nv[RPT];
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const long long row = row0 + (long long)j * RPB;
-        float4 w = v[j];
-        if (coef) {
-            const int ch = small ? (int)(((unsigned)min(row, rows - 1) / (unsigned)M) % (unsigned)C)
-                                 : (int)((min(row, rows - 1) / M) % C);
-            const float s0 = coef[ch], s1 = coef[C + ch];
-            w.x = __builtin_fmaf(w.x, s0, s1); w.y = __builtin_fmaf(w.y, s0, s1);
-            w.z = __builtin_fmaf(w.z, s0, s1); w.w = __builtin_fmaf(w.w, s0, s1);
-            if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
-        }
-        float best = w.x, braw = v[j].x;                  // braw: the INPUT value at the arg-max (the pre-BN output when
-        int bk = sub * 4;                                 // coef is given): the pooled layer's backward needs exactly it
-        if (w.y > best) { best = w.y; bk = sub * 4 + 1; braw = v[j].y; }
-        if (w.z > best) { best = w.z; bk = sub * 4 + 2; braw = v[j].z; }
-        if (w.w > best) { best = w.w; bk = sub * 4 + 3; braw = v[j].w; }
-        if constexpr (L == 4 || L == 16) {
-            // every lane of the row ends up with the row's (max, first arg-max): the comparison is symmetric, so any
-            // pairing of lanes that covers the row works -- xor 1, xor 2 inside a quad, then the two mirror steps
-            argmax_step<L, 0xB1>(best, bk, braw);          // quad_perm [1,0,3,2]
-            argmax_step<L, 0x4E>(best, bk, braw);          // quad_perm [2,3,0,1]
-            if constexpr (L == 16) {
-                argmax_step<L, 0x141>(best, bk, braw);     // row_half_mirror
-                argmax_step<L, 0x140>(best, bk, braw);     // row_mirror
-            }
-        } else {
+    for (int j = 0; j < RPT; ++j) v[j] = usip_load_stream4(z + (min(row_of(first, j), rows - 1) * L + sub) * 4);
+    for (int bi = 0; bi < nbatch; ++bi) {
+        const long long batch = first + bi;
+        if (bi + 1 < nbatch) {                                           // (uniform) the next batch: clamped, branch-free
 #pragma unroll
-            for (int off = L / 2; off > 0; off >>= 1) {
-                const float ov = __shfl_xor(best, off);
-                const int ok = __shfl_xor(bk, off);
-                const float orw = __shfl_xor(braw, off);
-                if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
+            for (int j = 0; j < RPT; ++j) nv[j] = usip_load_stream4(z + (min(row_of(batch + 1, j), rows - 1) * L + sub) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const long long row = row_of(batch, j);
+            float4 w = v[j];
+            if (coef) {
+                const int ch = small ? (int)(((unsigned)min(row, rows - 1) / (unsigned)M) % (unsigned)C)
+                                     : (int)((min(row, rows - 1) / M) % C);
+                const float s0 = coef[ch], s1 = coef[C + ch];
+                w.x = __builtin_fmaf(w.x, s0, s1); w.y = __builtin_fmaf(w.y, s0, s1);
+                w.z = __builtin_fmaf(w.z, s0, s1); w.w = __builtin_fmaf(w.w, s0, s1);
+                if (relu) { w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f); }
+            }
+            float best = w.x, braw = v[j].x;              // braw: the INPUT value at the arg-max (the pre-BN output when
+            int bk = sub * 4;                             // coef is given): the pooled layer's backward needs exactly it
+            if (w.y > best) { best = w.y; bk = sub * 4 + 1; braw = v[j].y; }
+            if (w.z > best) { best = w.z; bk = sub * 4 + 2; braw = v[j].z; }
+            if (w.w > best) { best = w.w; bk = sub * 4 + 3; braw = v[j].w; }
+            if constexpr (L == 4 || L == 16) {
+                // every lane of the row ends up with the row's (max, first arg-max): the comparison is symmetric, so any
+                // pairing of lanes that covers the row works -- xor 1, xor 2 inside a quad, then the two mirror steps
+                argmax_step<L, 0xB1>(best, bk, braw);      // quad_perm [1,0,3,2]
+                argmax_step<L, 0x4E>(best, bk, braw);      // quad_perm [2,3,0,1]
+                if constexpr (L == 16) {
+                    argmax_step<L, 0x141>(best, bk, braw); // row_half_mirror
+                    argmax_step<L, 0x140>(best, bk, braw); // row_mirror
+                }
+            } else {
+#pragma unroll
+                for (int off = L / 2; off > 0; off >>= 1) {
+                    const float ov = __shfl_xor(best, off);
+                    const int ok = __shfl_xor(bk, off);
+                    const float orw = __shfl_xor(braw, off);
+                    if (ov > best || (ov == best && ok < bk)) { best = ov; bk = ok; braw = orw; }
+                }
+            }
+            if (sub == 0 && row < rows) {
+                pooled[row] = best;
+                arg[row] = bk;
+                if (zarg) zarg[row] = braw;
             }
         }
-        if (sub == 0 && row < rows) {
-            pooled[row] = best;
-            arg[row] = bk;
-            if (zarg) zarg[row] = braw;
-        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) v[j] = nv[j];
     }
+}
+
+// batches per workgroup for group_max4_kernel: 1; with the knob as many as leave >= 8 workgroups per CU (2048), at most 8
+static int group_max4_batches(long long batches)
+{
+    if (!(usip_tuning_value(USIP_TUNE_R5_FORMS) & 8)) return 1;
+    int nb = 1;
+    while (nb < 8 && batches / (nb * 2) >= 2048) nb *= 2;
+    return nb;
 }
 
 __global__ __launch_bounds__(256) void group_max_bwd4_kernel(
@@ -319,10 +342,12 @@ extern "C" int usip_group_max_act_f32(const float* y, const float* coef, int rel
     hipStream_t st = (hipStream_t)stream;
 #define USIP_GM4(L_)                                                                             \
     if (L4 == L_) {                                                                              \
-        const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));                 \
+        const long long batches = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));                \
+        const int nbatch = group_max4_batches(batches);                                          \
+        const long long blocks = (batches + nbatch - 1) / nbatch;                                \
         if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                           \
         USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, y, pooled, arg, rows, \
-                    coef, relu, C, M, yarg);                                                     \
+                    coef, relu, C, M, yarg, nbatch);                                             \
     }
     USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
 #undef USIP_GM4
@@ -341,10 +366,12 @@ extern "C" int usip_group_max_f32(const float* z, float* pooled, int32_t* arg, l
     if (K % 4 == 0 && (L4 & (L4 - 1)) == 0 && L4 <= 64 && (reinterpret_cast<uintptr_t>(z) & 15u) == 0) {
 #define USIP_GM4(L_)                                                                             \
         if (L4 == L_) {                                                                          \
-            const long long blocks = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));             \
+            const long long batches = (rows + 4 * (256 / L_) - 1) / (4 * (256 / L_));            \
+            const int nbatch = group_max4_batches(batches);                                      \
+            const long long blocks = (batches + nbatch - 1) / nbatch;                            \
             if (blocks > 0x7fffffffLL) return USIP_EINVAL;                                       \
             USIP_LAUNCH((group_max4_kernel<L_>), dim3((unsigned)blocks), dim3(256), 0, st, z, pooled, arg, rows, \
-                        (const float*)nullptr, 0, 1, 1, (float*)nullptr);                        \
+                        (const float*)nullptr, 0, 1, 1, (float*)nullptr, nbatch);                \
         }
         USIP_GM4(1) USIP_GM4(2) USIP_GM4(4) USIP_GM4(8) USIP_GM4(16) USIP_GM4(32) USIP_GM4(64)
 #undef USIP_GM4

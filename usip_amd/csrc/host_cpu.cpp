@@ -108,7 +108,7 @@ extern "C" const char* usip_version(void) { return "usip_hip 0.4 gfx950 abi=4 fl
 #include <string.h>
 static int g_tuning[USIP_TUNE_COUNT];
 static const char* const g_tuning_names[USIP_TUNE_COUNT] = {
-    "index_max_ch", "index_max_unroll", "x3_wgrad_tile", "x3_gemm_tile", "gemm_split3", "index_max_threads", "x2_direct",
+    "index_max_ch", "index_max_unroll", "x3_wgrad_tile", "x3_gemm_tile", "gemm_split3", "index_max_threads", "x2_direct", "r5_forms",
 };
 extern "C" int usip_tuning_value(int knob) { return (knob >= 0 && knob < USIP_TUNE_COUNT) ? g_tuning[knob] : 0; }
 extern "C" int usip_set_tuning(const char* name, int value)

@@ -444,13 +444,12 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradArgs a)
 // many slices (one tile of 64 x 7 .. 128 x 128 outputs cut into ~1024 position slices): with Q = 4 every lane walked
 // 256 slices and the kernel was that chain of dependent loads (23 us for 1.8 MB at 64 x 7, 31 us at 128 x 128).
 template <int Q>
-__global__ __launch_bounds__(64 * Q) void wgrad_reduce_kernel(const float* __restrict__ part,
-                                                              float* __restrict__ dW, long long elems, int slices,
-                                                              int N, int ldw, int coloff)
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dW, long long elems,
+                                                  int slices, int N, int ldw, int coloff, long long block)
 {
     __shared__ float red[Q][64];
     const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const long long i = (long long)blockIdx.x * 64 + e;
+    const long long i = block * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < elems) {
         const int per = (slices + Q - 1) / Q, k0 = q * per, k1 = min(slices, k0 + per);
@@ -471,6 +470,33 @@ __global__ __launch_bounds__(64 * Q) void wgrad_reduce_kernel(const float* __res
         for (int g = 0; g < Q; g += 4) t += (red[g][e] + red[g + 1][e]) + (red[g + 2][e] + red[g + 3][e]);
         dW[(i / N) * ldw + coloff + (i % N)] = t;
     }
+}
+
+template <int Q>
+__global__ __launch_bounds__(64 * Q) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                              float* __restrict__ dW, long long elems, int slices,
+                                                              int N, int ldw, int coloff)
+{
+    wgrad_reduce_body<Q>(part, dW, elems, slices, N, ldw, coloff, blockIdx.x);
+}
+
+// Round 5: ALL reductions of a backward pass in one launch per Q.  A training step's weight gradients are read by the
+// optimizer (or the all-reduce) only, so the fifteen fixed-order sums of partial tiles it used to launch one by one
+// behind their producers (5-12 us each, most of it the launch) are recorded (usip_wgrad_defer) and issued together at
+// the end of backward (usip_wgrad_flush).  The job table travels BY VALUE in the kernel arguments, so a captured HIP
+// graph holds it; every block finds its job by a scan over at most USIP_REDUCE_JOBS block offsets.  Same body, same
+// per-lane slice shares, same summation order as wgrad_reduce_kernel<Q>: the same bits.
+constexpr int USIP_REDUCE_JOBS = 24;
+struct ReduceJob { const float* part; float* dW; long long elems; int slices, N, ldw, coloff, block0, pad; };
+struct ReduceJobs { int n, pad; ReduceJob j[USIP_REDUCE_JOBS]; };
+
+template <int Q>
+__global__ __launch_bounds__(64 * Q) void wgrad_reduce_multi_kernel(const ReduceJobs J)
+{
+    int k = 0;
+    for (int t = 1; t < J.n; ++t) if ((int)blockIdx.x >= J.j[t].block0) k = t;
+    const ReduceJob jb = J.j[k];
+    wgrad_reduce_body<Q>(jb.part, jb.dW, jb.elems, jb.slices, jb.N, jb.ldw, jb.coloff, (long long)blockIdx.x - jb.block0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -562,7 +588,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 // GROUP (K consecutive positions form one neighbourhood, K % 4 == 0, K/4 a power of two <= 64):
 // also gsum[0][row][m] = sum_k dYhat, gsum[1][row][m] = sum_k y -- what the pooled-concat layer
 // needs to push the gradient through its broadcast input without a second pass.
-template <bool GROUP>
+template <bool GROUP, int UNR>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const float* __restrict__ dZ, const float* __restrict__ Y, const float* __restrict__ coef,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partial,
@@ -582,48 +608,78 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const int G = P / K;
         float* g0 = gsum + rowid * G;
         float* g1 = gsum + ((long long)nrows + rowid) * G;
-        for (int p = threadIdx.x * 4; p < ((P + 1023) / 1024) * 1024; p += 1024) {
-            float gd = 0.f, gy = 0.f;
-            if (p < P) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + p);
-                const float4 dv = *reinterpret_cast<const float4*>(dz + p);
-                const float d0 = (!relu || __builtin_fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f;
-                const float d1 = (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
-                const float d2 = (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f;
-                const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
-                gd = (d0 + d1) + (d2 + d3);
-                gy = (yv.x + yv.y) + (yv.z + yv.w);
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
-                s1 += gd;
-                s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
-                s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
-                s2 = __builtin_fmaf(d2, (yv.z - mu) * is, s2);
-                s2 = __builtin_fmaf(d3, (yv.w - mu) * is, s2);
+        // UNR iterations' loads (UNR x 2 x 16 B per lane; UNR = 2: 4 KiB per wave) are in flight before the first is used -- round 5: the
+        // loop issued one pair of loads and waited for it (vmcnt(0)) eight times per row; the arithmetic and its order are
+        // unchanged (same bits).  Ordinary (temporal) loads: the pair (dZ, Y) is next read by the data / weight gradient kernels.
+        const int pend4 = ((P + 1023) / 1024) * 1024;
+        for (int p0 = threadIdx.x * 4; p0 < pend4; p0 += UNR * 1024) {
+            float4 yq[UNR], dq[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int p = min(p0 + u * 1024, P - 4);         // clamped: branch-free loads (P % 4 == 0)
+                yq[u] = *reinterpret_cast<const float4*>(y + p);
+                dq[u] = *reinterpret_cast<const float4*>(dz + p);
             }
-            for (int off = lpg / 2; off > 0; off >>= 1) {        // lpg lanes = one neighbourhood
-                gd += __shfl_xor(gd, off);
-                gy += __shfl_xor(gy, off);
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int p = p0 + u * 1024;
+                if (p >= pend4) break;
+                float gd = 0.f, gy = 0.f;
+                if (p < P) {
+                    const float4 yv = yq[u];
+                    const float4 dv = dq[u];
+                    const float d0 = (!relu || __builtin_fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f;
+                    const float d1 = (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
+                    const float d2 = (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f;
+                    const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
+                    gd = (d0 + d1) + (d2 + d3);
+                    gy = (yv.x + yv.y) + (yv.z + yv.w);
+                    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+                    s1 += gd;
+                    s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
+                    s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
+                    s2 = __builtin_fmaf(d2, (yv.z - mu) * is, s2);
+                    s2 = __builtin_fmaf(d3, (yv.w - mu) * is, s2);
+                }
+                for (int off = lpg / 2; off > 0; off >>= 1) {    // lpg lanes = one neighbourhood
+                    gd += __shfl_xor(gd, off);
+                    gy += __shfl_xor(gy, off);
+                }
+                if (p < P && (threadIdx.x % lpg) == 0) { g0[p / K] = gd; g1[p / K] = gy; }
             }
-            if (p < P && (threadIdx.x % lpg) == 0) { g0[p / K] = gd; g1[p / K] = gy; }
         }
     } else {
         const float* y = Y + rowid * P;
         const float sc = coef[ch], sh = coef[C + ch], mu = mean[ch], is = invstd[ch];
         const bool vec = (P % 4 == 0) && (((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y)) & 15u) == 0);
         if (vec) {
-            for (int p = threadIdx.x * 4; p < P; p += 1024) {
-                const float4 yv = *reinterpret_cast<const float4*>(y + p);
-                const float4 dv = *reinterpret_cast<const float4*>(dz + p);
-                const float d0 = (!relu || __builtin_fmaf(yv.x, sc, sh) > 0.f) ? dv.x : 0.f;
-                const float d1 = (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f) ? dv.y : 0.f;
-                const float d2 = (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f) ? dv.z : 0.f;
-                const float d3 = (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f) ? dv.w : 0.f;
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
-                s1 += (d0 + d1) + (d2 + d3);
-                s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
-                s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
-                s2 = __builtin_fmaf(d2, (yv.z - mu) * is, s2);
-                s2 = __builtin_fmaf(d3, (yv.w - mu) * is, s2);
+            // (two iterations' loads in flight, as in the GROUP form above; same arithmetic, same order)
+            for (int p0 = threadIdx.x * 4; p0 < P; p0 += UNR * 1024) {
+                float4 yq[UNR], dq[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int p = min(p0 + u * 1024, P - 4);     // clamped: branch-free loads
+                    yq[u] = *reinterpret_cast<const float4*>(y + p);
+                    dq[u] = *reinterpret_cast<const float4*>(dz + p);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    // a sub-iteration beyond the row adds exact zeros (the clamped load returned finite data): no branch
+                    // for the compiler to sink the second pair of loads into
+                    const bool in = p0 + u * 1024 < P;
+                    const float4 yv = yq[u];
+                    const float4 dv = dq[u];
+                    const float d0 = (in && (!relu || __builtin_fmaf(yv.x, sc, sh) > 0.f)) ? dv.x : 0.f;
+                    const float d1 = (in && (!relu || __builtin_fmaf(yv.y, sc, sh) > 0.f)) ? dv.y : 0.f;
+                    const float d2 = (in && (!relu || __builtin_fmaf(yv.z, sc, sh) > 0.f)) ? dv.z : 0.f;
+                    const float d3 = (in && (!relu || __builtin_fmaf(yv.w, sc, sh) > 0.f)) ? dv.w : 0.f;
+                    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+                    s1 += (d0 + d1) + (d2 + d3);
+                    s2 = __builtin_fmaf(d0, (yv.x - mu) * is, s2);
+                    s2 = __builtin_fmaf(d1, (yv.y - mu) * is, s2);
+                    s2 = __builtin_fmaf(d2, (yv.z - mu) * is, s2);
+                    s2 = __builtin_fmaf(d3, (yv.w - mu) * is, s2);
+                }
             }
         } else {
             for (int p = threadIdx.x; p < P; p += 256) {
@@ -820,10 +876,73 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
 
 }  // namespace
 
+// Deferred reductions (see wgrad_reduce_multi_kernel): recorded under a lock because autograd runs backward nodes on its
+// own thread while the step object switches the mode from the caller's.
+#include <mutex>
+#include <vector>
+namespace {
+std::mutex g_defer_lock;
+bool g_defer_on = false;
+std::vector<ReduceJob> g_defer_jobs;
+
+template <int Q>
+int flush_q(std::vector<ReduceJob>& jobs, hipStream_t st)
+{
+    size_t at = 0;
+    while (at < jobs.size()) {
+        ReduceJobs J{};
+        long long blocks = 0;
+        while (at < jobs.size() && J.n < USIP_REDUCE_JOBS) {
+            ReduceJob jb = jobs[at];
+            const long long nb = (jb.elems + 63) / 64;
+            if (blocks + nb > 0x7fffffffLL) break;
+            jb.block0 = (int)blocks;
+            blocks += nb;
+            J.j[J.n++] = jb;
+            ++at;
+        }
+        if (J.n == 0) return USIP_EINVAL;
+        USIP_LAUNCH((wgrad_reduce_multi_kernel<Q>), dim3((unsigned)blocks), dim3(64 * Q), 0, st, J);
+        USIP_LAUNCH_CHECK();
+    }
+    return USIP_OK;
+}
+}  // namespace
+
+extern "C" int usip_wgrad_defer(int on)
+{
+    std::lock_guard<std::mutex> g(g_defer_lock);
+    g_defer_on = on != 0;
+    g_defer_jobs.clear();                                     // entering or leaving the mode: nothing stale survives
+    return USIP_OK;
+}
+
+extern "C" int usip_wgrad_flush(void* stream)
+{
+    std::vector<ReduceJob> many, few;
+    {
+        std::lock_guard<std::mutex> g(g_defer_lock);
+        for (const ReduceJob& jb : g_defer_jobs) (jb.slices > 64 ? many : few).push_back(jb);
+        g_defer_jobs.clear();
+    }
+    const int n = (int)(many.size() + few.size());
+    hipStream_t st = (hipStream_t)stream;
+    if (!many.empty()) { const int rc = flush_q<16>(many, st); if (rc != USIP_OK) return rc < 0 ? rc : -rc; }
+    if (!few.empty()) { const int rc = flush_q<4>(few, st); if (rc != USIP_OK) return rc < 0 ? rc : -rc; }
+    return n;
+}
+
 // fixed-order sum of weight-gradient partial tiles, for the other translation units of the shared MLP
 int usip_mlp::launch_wgrad_reduce(const float* part, float* dW, long long elems, int slices, int N, int ldw, int coloff,
                                   hipStream_t st)
 {
+    {
+        std::lock_guard<std::mutex> g(g_defer_lock);
+        if (g_defer_on) {                                     // the caller keeps `part` alive until usip_wgrad_flush
+            g_defer_jobs.push_back(ReduceJob{part, dW, elems, slices, N, ldw, coloff, 0, 0});
+            return USIP_OK;
+        }
+    }
     if (slices > 64)
         USIP_LAUNCH(wgrad_reduce_kernel<16>, dim3((unsigned)((elems + 63) / 64)), dim3(1024), 0, st, part, dW, elems,
                     slices, N, ldw, coloff);
@@ -1120,12 +1239,18 @@ extern "C" int usip_bn_backward_reduce_f32(const float* dZ, const float* Y, cons
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)nb * C;
     if (rows > 0x7fffffffLL) return USIP_EINVAL;
-    if (gsum)
-        USIP_LAUNCH((bn_bwd_reduce_kernel<true>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean,
-                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group, want_bound);
-    else
-        USIP_LAUNCH((bn_bwd_reduce_kernel<false>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean,
-                    invstd, partial, gsum, relu, plain, C, P, (int)rows, group, want_bound);
+    // loads of UNR loop iterations in flight per lane (the sums are the same bits for every UNR).  Round 5 measured 2 and 4
+    // against 1 inside the step, same box, alternating (profiles/r05b_forms_ab.txt): 46.1-48.0 / 46.1 / 45.3 us per launch --
+    // this pass is not short of bytes in flight (32 waves per CU already hold 64 KiB), so 1 stays; knob r5_forms bit 1 -> 2,
+    // bit 2 -> 4
+    const int forms = usip_tuning_value(USIP_TUNE_R5_FORMS);
+    const int unr = (forms & 2) ? 2 : (forms & 4) ? 4 : 1;
+#define USIP_BNRED(G_, U_)                                                                                        \
+    USIP_LAUNCH((bn_bwd_reduce_kernel<G_, U_>), dim3((unsigned)rows), dim3(256), 0, st, dZ, Y, coef_fwd, mean, invstd, \
+                partial, gsum, relu, plain, C, P, (int)rows, group, want_bound)
+    if (gsum) { if (unr == 1) USIP_BNRED(true, 1); else if (unr == 4) USIP_BNRED(true, 4); else USIP_BNRED(true, 2); }
+    else { if (unr == 1) USIP_BNRED(false, 1); else if (unr == 4) USIP_BNRED(false, 4); else USIP_BNRED(false, 2); }
+#undef USIP_BNRED
     USIP_LAUNCH_CHECK();
     USIP_LAUNCH(bn_bwd_finalize_kernel, dim3(usip_ceil_div(C, 64)), dim3(64), 0, st, partial, nb, C,
                 (double)nb * (double)P, gamma, coef_fwd, mean, invstd, dgamma, dbeta, plain ? nullptr : coef4,

@@ -19,6 +19,7 @@
 //     ds_read_b128 without padding, 48 KiB for both stages of both operands (two workgroups per CU).
 #include "mlp_common.h"
 #include "split_common.h"
+#include <type_traits>
 
 using namespace usip_mlp;
 
@@ -664,6 +665,236 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 
 // ------------------------------------------------------------------------------------------------
+// The f32x2 weight gradient (wgrad_x3_kernel<PRO, true, 2>) with FULL-LINE loads.  Round 5.
+// wgrad_x3_kernel fetches, per 16-position stage, 64 B of each of a tile's 256 + 256 (+ 256) operand rows: half a
+// 128-B line per row and stage, the other half one stage later -- by which time the 32 workgroups of an XCD have
+// touched 3 MB of lines in a 4 MB L2.  rocprofv3 FETCH_SIZE of the round-4 step: 641 MB per launch against 492 MB of
+// operands (256 x 256 and 512 x 256 launches, 5.6 TB/s of counted traffic: the launch IS at what HBM delivers, a
+// quarter of it fetched twice), 827 against 537 MB for the pooled 512 x 512 launch.  Round 4 tried "both halves back to
+// back" by loading two stages per event and lost a stage of prefetch distance (25 % fewer bytes, 15 % slower).
+// Here the 16-position stages, their order, their MFMAs and the registers per thread stay exactly as they are --
+// partial tiles are BIT-IDENTICAL to wgrad_x3_kernel's -- and only WHICH 16 KB per operand a load event fetches
+// changes: event 2j covers rows [0, 128) x the 32 positions of stage pair j, event 2j+1 rows [128, 256) x the same 32
+// positions: eight consecutive lanes read one whole line.  A pair of stages is complete in LDS when both its events
+// are stored, so LDS holds two PAIRS (8 stage images = 128 KiB; one workgroup per CU as before), every event is
+// still issued one stage before it is stored, and the stores of a pair's first stage and the reads of its second
+// touch different buffers: ONE barrier per 32 positions instead of two.
+template <int PRO>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_x2l_kernel(const WgradArgs a)
+{
+    constexpr int TM = 4, TN = 2, WN = 4, BM = 256, BN = 256, NT = 512;
+    constexpr int PL = BM * 32, STAGE = 2 * PL;                // bytes: one plane, one operand stage (two fp16 planes)
+    constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
+    static_assert(PRO == PRO_BN_BWD || PRO == PRO_BN_BWD_POOL, "two-plane weight gradient: both operands carry a bound");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE];   // [G | X][pair buffer][stage of the pair][plane][row][16 p]
+    unsigned char* Gs = smem;
+    unsigned char* Xs = smem + 4 * STAGE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int nmt = (a.M + BM - 1) / BM, nnt = (a.N + BN - 1) / BN;
+    const int total = gridDim.x;
+    int L = blockIdx.x;
+    if ((total & 7) == 0) L = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+    const int tile = L % (nmt * nnt), slice = L / (nmt * nnt);
+    const int m0 = (tile / nnt) * BM, n0 = (tile % nnt) * BN;
+    const int b = slice / a.segs, seg = slice % a.segs;
+    const int pbeg = seg * a.seglen, pend = min(a.P, pbeg + a.seglen);
+    const int nst = (pend - pbeg + 15) / 16;
+    const int npair = (nst + 1) / 2;                           // an odd last stage is multiplied with G = 0: adds +-0
+
+    // thread -> per event two (row, 4 positions) pieces per operand: rows h * 128 + i * 64 + tid / 8 (h = the event's
+    // row half), positions kq .. kq + 3 of the pair's 32: lanes 8 r .. 8 r + 7 cover one 128-B line of row r
+    const int rl = tid >> 3;
+    const int kq = (tid & 7) * 4, sub = kq >> 4, kk = kq & 15;
+    // (row + 64) >> 3 and (row + 128) >> 3 keep the parity of row >> 3: the swizzle of lds_off is that of row rl
+    const int lds0 = lds_off(rl, kk >> 3) + (kk & 7) * 2 + sub * STAGE;
+    const int pgrp = POOL ? a.P / a.pool_group : 0;
+    const float* const Gb = POOL ? nullptr : a.G + (long long)b * a.M * a.P;
+    const float* const G2b = a.G2 + (long long)b * a.M * a.P;
+    const float* const Xb = a.X + (long long)b * a.N * a.P;
+    const float* const Pdb = POOL ? a.pool_dp + (long long)b * a.M * pgrp : nullptr;
+    const int* const Pab = POOL ? a.pool_arg + (long long)b * a.M * pgrp : nullptr;
+    int goff[2][2], xoff[2][2], pgoff[2][2];                   // element offsets inside the cloud (max(M, N) * P < 2^30: launcher)
+    bool gok[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = h * 128 + i * 64 + rl;
+            const int grow = min(m0 + row, a.M - 1), xrow = min(n0 + row, a.N - 1);
+            gok[h][i] = m0 + row < a.M;
+            goff[h][i] = grow * a.P;
+            xoff[h][i] = xrow * a.P;
+            pgoff[h][i] = POOL ? grow * pgrp : 0;
+        }
+    // operand scales: as in wgrad_x3_kernel<.., 2>
+    float gscale, xscale;
+    {
+        float* redm = reinterpret_cast<float*>(smem);          // free until the first stage is written (barrier below)
+        float gb = 0.f, xb = 0.f;
+        for (int i = tid; i < (a.M + 63) / 64; i += NT) gb = fmaxf(gb, a.coef[4 * a.M + i]);
+        const float rn = sqrtf((float)a.nb * (float)a.P);
+        for (int k = tid; k < a.N; k += NT) {
+            const float c0 = a.xcoef[k], c1 = a.xcoef[a.N + k], mu = a.xcoef[2 * a.N + k], is = a.xcoef[3 * a.N + k];
+            xb = fmaxf(xb, fabsf(c0) / is * rn + fabsf(__builtin_fmaf(mu, c0, c1)));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { gb = fmaxf(gb, __shfl_xor(gb, off)); xb = fmaxf(xb, __shfl_xor(xb, off)); }
+        if (lane == 0) { redm[wave] = gb; redm[8 + wave] = xb; }
+        __syncthreads();
+        gb = redm[0]; xb = redm[8];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) { gb = fmaxf(gb, redm[w]); xb = fmaxf(xb, redm[8 + w]); }
+        gscale = pow2_scale(gb, X2H_TOP);
+        xscale = pow2_scale(xb, X2H_TOP);
+        __syncthreads();                                       // everyone has read redm before the stages overwrite it
+    }
+    float gc[2][2][4], xc[2][2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int grow = min(m0 + h * 128 + i * 64 + rl, a.M - 1), xrow = min(n0 + h * 128 + i * 64 + rl, a.N - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gc[h][i][j] = a.coef[j * a.M + grow] * gscale;
+            xc[h][i][0] = a.xcoef[xrow] * xscale;
+            xc[h][i][1] = a.xcoef[a.N + xrow] * xscale;
+        }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    float4 rg[2], rg2[2], rx[2];
+    auto load_event = [&](auto hc, int pair) {
+        constexpr int H = decltype(hc)::value;
+        const int pc = min(pbeg + pair * 32 + kq, a.P - 4);    // clamped: always a valid, aligned float4
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (POOL) {
+                const int g = pc / a.pool_group;
+                rg[i] = make_float4(Pdb[pgoff[H][i] + g], __int_as_float(Pab[pgoff[H][i] + g]),
+                                    __int_as_float(pc % a.pool_group), 0.f);
+            } else {
+                rg[i] = *reinterpret_cast<const float4*>(Gb + goff[H][i] + pc);
+            }
+            rg2[i] = *reinterpret_cast<const float4*>(G2b + goff[H][i] + pc);
+            rx[i] = *reinterpret_cast<const float4*>(Xb + xoff[H][i] + pc);
+        }
+    };
+    auto store_event = [&](auto hc, int pbuf, int pair) {
+        constexpr int H = decltype(hc)::value;
+        const bool pok = pbeg + pair * 32 + kq < pend;         // float4 granularity: P % 4 == 0, segments start at 32 p
+        unsigned char* const gdst = Gs + pbuf * 2 * STAGE + lds0 + H * 4096;
+        unsigned char* const xdst = Xs + pbuf * 2 * STAGE + lds0 + H * 4096;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float4 v = rg[i];
+            const float4 w = rg2[i];
+            if (POOL) {
+                const int hit = __float_as_int(v.y) - __float_as_int(v.z);
+                const float g = v.x;
+                v = make_float4(hit == 0 ? g : 0.f, hit == 1 ? g : 0.f, hit == 2 ? g : 0.f, hit == 3 ? g : 0.f);
+            }
+            const float c0 = gc[H][i][0], c1 = gc[H][i][1], c2 = gc[H][i][2], c3 = gc[H][i][3];
+            v.x = pro_apply<PRO_BN_BWD>(v.x, w.x, c0, c1, c2, c3);
+            v.y = pro_apply<PRO_BN_BWD>(v.y, w.y, c0, c1, c2, c3);
+            v.z = pro_apply<PRO_BN_BWD>(v.z, w.z, c0, c1, c2, c3);
+            v.w = pro_apply<PRO_BN_BWD>(v.w, w.w, c0, c1, c2, c3);
+            if (!(gok[H][i] && pok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned p0[2], p1[2];
+            split_pair_h(v.x, v.y, p0[0], p1[0]);
+            split_pair_h(v.z, v.w, p0[1], p1[1]);
+            *reinterpret_cast<uint2*>(gdst + 0 * PL + i * 2048) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(gdst + 1 * PL + i * 2048) = make_uint2(p1[0], p1[1]);
+            float4 x = rx[i];
+            const float s0 = xc[H][i][0], s1 = xc[H][i][1];
+            x.x = fmaxf(__builtin_fmaf(x.x, s0, s1), 0.f); x.y = fmaxf(__builtin_fmaf(x.y, s0, s1), 0.f);
+            x.z = fmaxf(__builtin_fmaf(x.z, s0, s1), 0.f); x.w = fmaxf(__builtin_fmaf(x.w, s0, s1), 0.f);
+            split_pair_h(x.x, x.y, p0[0], p1[0]);
+            split_pair_h(x.z, x.w, p0[1], p1[1]);
+            *reinterpret_cast<uint2*>(xdst + 0 * PL + i * 2048) = make_uint2(p0[0], p0[1]);
+            *reinterpret_cast<uint2*>(xdst + 1 * PL + i * 2048) = make_uint2(p1[0], p1[1]);
+        }
+    };
+
+    const int c = lane & 31, kh = lane >> 5;
+    int fa_off[TM], fb_off[TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) fa_off[t] = lds_off((wm * TM + t) * 32 + c, kh);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) fb_off[t] = lds_off((wn * TN + t) * 32 + c, kh);
+#define USIP_X2L_PRODUCT(PA_, PB_)                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[PA_][i]), __builtin_bit_cast(f16x8, fb[PB_][j]), acc[i][j], 0, 0, 0);
+#define USIP_X2L_READ_FRAGS(SB_)                                                                                   \
+        bf16x8 fa[2][TM], fb[2][TN];                                                                               \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
+            _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
+                fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + (SB_) * STAGE + s * PL + fa_off[t]);              \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                         \
+                fb[s][t] = *reinterpret_cast<const bf16x8*>(Xs + (SB_) * STAGE + s * PL + fb_off[t]);              \
+        }
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    if (npair > 0) {
+        load_event(H0{}, 0);
+        store_event(H0{}, 0, 0);
+        load_event(H1{}, 0);
+        store_event(H1{}, 0, 0);
+        load_event(H0{}, min(1, npair - 1));
+        __syncthreads();
+        int pb = 0;
+        for (int pr = 0; pr + 1 < npair; ++pr) {
+            {   // first stage of pair pr; rows [0, 128) of pair pr + 1 go to LDS, rows [128, 256) are requested
+                USIP_X2L_READ_FRAGS(pb * 2)
+                USIP_X2L_PRODUCT(1, 0) USIP_X2L_PRODUCT(0, 1)
+                store_event(H0{}, pb ^ 1, pr + 1);
+                load_event(H1{}, pr + 1);
+                USIP_X2L_PRODUCT(0, 0)
+            }
+            {   // second stage (its buffers are not written in this iteration: no barrier in between)
+                USIP_X2L_READ_FRAGS(pb * 2 + 1)
+                USIP_X2L_PRODUCT(1, 0) USIP_X2L_PRODUCT(0, 1)
+                store_event(H1{}, pb ^ 1, pr + 1);
+                load_event(H0{}, min(pr + 2, npair - 1));      // (last: a harmless repeat)
+                USIP_X2L_PRODUCT(0, 0)
+            }
+            __syncthreads();
+            pb ^= 1;
+        }
+        {
+            USIP_X2L_READ_FRAGS(pb * 2)
+            USIP_X2L_PRODUCT(1, 0) USIP_X2L_PRODUCT(0, 1) USIP_X2L_PRODUCT(0, 0)
+        }
+        {
+            USIP_X2L_READ_FRAGS(pb * 2 + 1)
+            USIP_X2L_PRODUCT(1, 0) USIP_X2L_PRODUCT(0, 1) USIP_X2L_PRODUCT(0, 0)
+        }
+    }
+#undef USIP_X2L_PRODUCT
+#undef USIP_X2L_READ_FRAGS
+    {
+        const float out_scale = 1.0f / (gscale * xscale);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= out_scale;
+    }
+    wgrad_store_partial<TM, TN>(a, acc, slice, m0, n0, wm, wn, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // f32x2 GEMM for the 128-wide layers (M <= 128 outputs, K <= 128 inputs: conv5 of RPN_Detector_Ball, the second
 // PointNet of RPN_Detector, the descriptor's layers) with the WEIGHT FRAGMENTS RESIDENT IN REGISTERS.
 // The tile kernel above re-reads the layer's 64 KB of weight planes from L2 for every 128-position tile: at K = 128
@@ -1208,6 +1439,12 @@ void wgrad_x3_plan(int M, int N, int P, int nb, int* seglen, int* segs, int* til
 int launch_wgrad_x2h_256(const WgradArgs& a, int pro, unsigned blocks, hipStream_t st)
 {
     dim3 grid(blocks), block(512);
+    // round 5: full-line loads (wgrad_x2l_kernel; same partial tiles bit for bit).  Its row offsets are 32-bit element
+    // offsets inside a cloud; knob r5_forms bit 0 keeps round 4's kernel for A/B runs
+    const bool line = !(usip_tuning_value(USIP_TUNE_R5_FORMS) & 1) &&
+                      (long long)(a.M > a.N ? a.M : a.N) * a.P < (1LL << 30);
+    if (line && pro == PRO_BN_BWD) { USIP_LAUNCH((wgrad_x2l_kernel<PRO_BN_BWD>), grid, block, 0, st, a); USIP_LAUNCH_CHECK(); return USIP_OK; }
+    if (line && pro == PRO_BN_BWD_POOL) { USIP_LAUNCH((wgrad_x2l_kernel<PRO_BN_BWD_POOL>), grid, block, 0, st, a); USIP_LAUNCH_CHECK(); return USIP_OK; }
     if (pro == PRO_BN_BWD) USIP_LAUNCH((wgrad_x3_kernel<PRO_BN_BWD, true, 2>), grid, block, 0, st, a);
     else if (pro == PRO_BN_BWD_POOL) USIP_LAUNCH((wgrad_x3_kernel<PRO_BN_BWD_POOL, true, 2>), grid, block, 0, st, a);
     else return USIP_EINVAL;

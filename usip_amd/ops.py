@@ -720,6 +720,39 @@ def bn_backward_reduce(dZ, Y, coef_fwd, mean, invstd, gamma, relu: bool, group: 
     return dgamma, dbeta, coef4, gsum
 
 
+# Deferred weight-gradient reductions (include/usip_hip.h: usip_wgrad_defer / usip_wgrad_flush): inside a training step the
+# fixed-order sums of partial tiles are recorded by the library and issued together after backward.  The partial-tile
+# workspaces must outlive the flush, so while the mode is on every workspace allocated here is kept in _DEFER_KEEP.
+_DEFER_KEEP = None
+
+
+def _keep(ws):
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.append(ws)
+    return ws
+
+
+def wgrad_defer(on: bool):
+    """Enter (True) or leave (False) the deferred mode; leaving drops whatever is recorded and not flushed."""
+    global _DEFER_KEEP
+    _lib.check(_lib.lib().usip_wgrad_defer(1 if on else 0), "usip_wgrad_defer")
+    _DEFER_KEEP = [] if on else None
+
+
+def wgrad_flush(device) -> int:
+    """Issue every recorded reduction on `device`'s current stream (two launches at most); -> how many were issued.
+    The mode stays on; the workspaces are released (stream-ordered: their memory is reused only behind the flush)."""
+    global _DEFER_KEEP
+    dev = torch.device(device)
+    with torch.cuda.device(dev), prof.kernel("wgrad_reduce_all", 0.0):
+        n = int(_lib.lib().usip_wgrad_flush(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    if n < 0:
+        raise RuntimeError("usip_amd: usip_wgrad_flush failed (%d)" % n)
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP = []
+    return n
+
+
 def bn_pool_backward_reduce(dpooled, arg, Y4, coef_fwd, mean, invstd, gamma, relu: bool,
                             dgamma_out=None, dbeta_out=None, yarg=None):
     """BN(+ReLU) backward sums for a layer that fed only a max over K: -> (dgamma, dbeta, coef4).
@@ -753,7 +786,7 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     N = X.shape[1]
     dev = X.device
     ws_n = _lib.lib().usip_mlp_wgrad_workspace(M, N, P, nb)
-    ws = torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev)
+    ws = _keep(torch.empty(max(int(ws_n), 1), dtype=torch.float32, device=dev))
     dW = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
     ldw = dW.shape[1]
     bf16 = _matmul_mode == "bf16"
@@ -832,7 +865,7 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
     ldw = w2.shape[1]
     dW = dw_out if dw_out is not None else torch.empty_like(w2)
     dx = torch.empty((nb, Cin, P), dtype=torch.float32, device=dev)
-    ws = torch.empty(int(_lib.lib().usip_mlp_narrow_backward_workspace(Cout, P, nb)), dtype=torch.float32, device=dev)
+    ws = _keep(torch.empty(int(_lib.lib().usip_mlp_narrow_backward_workspace(Cout, P, nb)), dtype=torch.float32, device=dev))
     red = None
     if want_red:
         if xcoef is None or xcoef.shape[0] < 4:
@@ -892,7 +925,7 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     dx = torch.empty((nb, Cin, P), dtype=torch.float32, device=dev)
     lib = _lib.lib()
     blocks = int(lib.usip_mlp_layer_backward_x2h_blocks(Cin, Cout, P, nb))
-    ws = torch.empty(int(lib.usip_mlp_layer_backward_x2h_workspace(Cin, Cout, P, nb)), dtype=torch.float32, device=dev)
+    ws = _keep(torch.empty(int(lib.usip_mlp_layer_backward_x2h_workspace(Cin, Cout, P, nb)), dtype=torch.float32, device=dev))
     red = torch.empty(2 * blocks * Cin + blocks, dtype=torch.float32, device=dev) if want_red else None
     planes = weight_planes(w2, wcol, Cin, Cout, 2, P, nb)      # W as the data-gradient operand: K-major [Cout][ldw]
     pdp = parg = gsum = None

@@ -249,7 +249,18 @@ class _GraphedStep:
             ops.PLANES_CACHE = plan.refresh() if plan is not None else {}
             Fh.PRE_BN_SUMS.clear()
             loss = self.forward_losses(batch, epoch)
-            loss.backward()
+            # the weight gradients are read by the all-reduce / the optimizer only: their fifteen fixed-order sums of
+            # partial tiles are recorded during backward and issued together behind it (USIP_DEFER_WGRAD=0: one by one)
+            defer = self.device.type == "cuda" and os.environ.get("USIP_DEFER_WGRAD", "1") not in ("0", "off")
+            if defer:
+                ops.wgrad_defer(True)
+            try:
+                loss.backward()
+                if defer:
+                    self.deferred_reductions = ops.wgrad_flush(self.device)
+            finally:
+                if defer:
+                    ops.wgrad_defer(False)
             if plan is None and ops.PLANES_CACHE and not torch.cuda.is_current_stream_capturing():
                 self._planes_plan = ops.PlanesPlan(ops.PLANES_CACHE, [self.bucket.flat_param,
                                                                       self._wt[0] if self._wt is not None else None])
