@@ -652,7 +652,7 @@ def main():
                 """Matrix products per fp32 product of a split-product launch: 6 (three bf16 planes), 3 (two fp16
                 planes: template argument NPL = 2, kernel names x2h / x2d / x2r / layer_bwd_x2), 0 for every other kernel."""
                 key = (r.get("rocprof_key") or "").split(" |wg=")[0]
-                if "x2h" in key or "x2d_kernel" in key or "x2r_kernel" in key or "layer_bwd_x2_kernel" in key or \
+                if "x2h" in key or "x2d_kernel" in key or "x2r_kernel" in key or "x2l_kernel" in key or "layer_bwd_x2_kernel" in key or \
                         (("x3p_kernel" in key or "wgrad_x3_kernel" in key) and key.rstrip(">").endswith(", 2")):
                     return 3
                 if "x3" in key or ("bf16_kernel" in key and key.rstrip(">").endswith(", 3")):

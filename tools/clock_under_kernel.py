@@ -8,6 +8,7 @@ kernels the number printed here is too high and the in-kernel probe (tools/x2d_t
 measurement.  For the streaming kernels (small workgroups, many of them) the monitor costs nothing."""
 import ctypes
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import subprocess
 import sys
 

@@ -1,5 +1,6 @@
 """group_max_act (fused BN + ReLU + max over K, csrc/group.hip) at the step's four pooling shapes; HIP events, median."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

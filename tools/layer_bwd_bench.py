@@ -2,6 +2,7 @@
 (16 clouds x 32768 positions): narrow_bwd.hip (fp32 MFMA) for the 64-input layers, the pooled data-gradient +
 weight-gradient pair for conv5."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

@@ -1,5 +1,6 @@
 """A few launches of one form of the fused f32x2 layer backward for counter passes: layer_bwd_one.py <Cin> <Cout> [pool]"""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

@@ -1,6 +1,7 @@
 """The fused f32x2 layer backward launched N times on the same inputs: every output must be bit-identical.
   python tools/layer_bwd_race.py [N]"""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

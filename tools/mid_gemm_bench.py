@@ -1,6 +1,7 @@
 """The second-stage / head layers (512 positions per cloud, 16 clouds): fp32 MFMA kernel against the f32x2 tile kernel
 with 256-row and 128-row tiles.  python tools/mid_gemm_bench.py"""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

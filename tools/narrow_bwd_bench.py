@@ -1,6 +1,7 @@
 """Fused narrow-layer backward (csrc/narrow_bwd.hip) vs the generic data-gradient + weight-gradient pair at the
 Ball front end's shapes (B'=16 clouds, 512 nodes x 64 neighbours).  HIP events, median of 10."""
-import os, sys
+import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers), sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from usip_amd import ops

@@ -1,6 +1,7 @@
 """The narrow forward layers (64 -> 64, 64 -> 128; BN+ReLU prologue, statistics) on the streaming f32x3 kernel
 (narrow_fwd.hip) against the register-resident f32x2 kernel (gemm_x2r_kernel), same box, same operands."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

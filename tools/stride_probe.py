@@ -1,7 +1,8 @@
 """Does the power-of-two row stride of the activation tensors (P = 32768 positions per cloud -> 128 KiB between the
 channel rows of a tile) cost HBM channel conflicts?  Time the narrow forward GEMM and the BN-backward reduction at
 P = 32768 and at slightly different P (same bytes to 1 %)."""
-import os, sys
+import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers), sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from usip_amd import ops

@@ -1,6 +1,7 @@
 """A/B of one library tuning knob on the f32x2 GEMMs at the step's wide-layer shapes:
     python tools/x2_knob_bench.py <knob> <value> [<value> ...]      (value 0 = the library's default)"""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

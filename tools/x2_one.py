@@ -1,5 +1,6 @@
 """A few launches of the f32x2 forward GEMM (512 x 512, BN+ReLU prologue, statistics) for counter passes."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

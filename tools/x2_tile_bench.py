@@ -1,6 +1,7 @@
 """A/B of the f32x2 data-gradient GEMM tile (x3_gemm_tile knob: 0 = 256 x 128, 4 waves, two workgroups per CU;
 5 = 256 x 256, 8 waves, one workgroup per CU) at the step's wide-layer shapes."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

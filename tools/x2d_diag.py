@@ -1,5 +1,6 @@
 """Where does the direct f32x2 GEMM differ from the LDS-staged one?  Per (cloud, 256-row tile, 128-position tile)."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

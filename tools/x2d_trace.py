@@ -7,6 +7,7 @@ exports usip_x2d_trace_read; it also adds the loop-ablation knobs (x2_direct = 6
 Result of round 4: profiles/r04_mfma_sustained_clock.txt, parts 5 and 7."""
 import ctypes
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import numpy as np

@@ -1,6 +1,7 @@
 """A few launches of the register-resident f32x2 GEMM (128 x 128 over 524288 positions, BN+ReLU prologue, statistics;
 then its data-gradient form) for counter passes."""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

@@ -4,6 +4,7 @@ their error against an fp64 product on the same operands.
     python tools/x3_bench.py
 """
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

@@ -1,6 +1,7 @@
 """One kernel under the profiler: the 512x512 forward GEMM (BN+ReLU prologue, statistics epilogue) in a chosen mode.
     python tools/x3_probe.py f32x3|f32|bf16 [M K P nb]"""
 import os
+os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers)
 import sys
 
 import torch

@@ -686,9 +686,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int PL = BM * 32, STAGE = 2 * PL;                // bytes: one plane, one operand stage (two fp16 planes)
     constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
     static_assert(PRO == PRO_BN_BWD || PRO == PRO_BN_BWD_POOL, "two-plane weight gradient: both operands carry a bound");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE];   // [G | X][pair buffer][stage of the pair][plane][row][16 p]
+    // [G | X][pair buffer][stage of the pair][plane][row][16 p].  The image of a pair's SECOND stage starts SHIFT = 64 B
+    // late: a 16-lane group of a store instruction covers two rows x both stages of the pair, and with the images exactly
+    // 16 KiB apart the two stages of a row met in the same eight banks (SQ_LDS_BANK_CONFLICT = 28 % of the LDS cycles in
+    // the first build, profiles/r05d_pmc_wgrad.txt); 16 banks apart the group's 16 lanes cover all 32 banks once.
+    constexpr int SHIFT = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE + 2 * SHIFT];
     unsigned char* Gs = smem;
-    unsigned char* Xs = smem + 4 * STAGE;
+    unsigned char* Xs = smem + 4 * STAGE + SHIFT;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rl = tid >> 3;
     const int kq = (tid & 7) * 4, sub = kq >> 4, kk = kq & 15;
     // (row + 64) >> 3 and (row + 128) >> 3 keep the parity of row >> 3: the swizzle of lds_off is that of row rl
-    const int lds0 = lds_off(rl, kk >> 3) + (kk & 7) * 2 + sub * STAGE;
+    const int lds0 = lds_off(rl, kk >> 3) + (kk & 7) * 2 + sub * (STAGE + SHIFT);
     const int pgrp = POOL ? a.P / a.pool_group : 0;
     const float* const Gb = POOL ? nullptr : a.G + (long long)b * a.M * a.P;
     const float* const G2b = a.G2 + (long long)b * a.M * a.P;
@@ -838,9 +843,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bf16x8 fa[2][TM], fb[2][TN];                                                                               \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
             _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
-                fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + (SB_) * STAGE + s * PL + fa_off[t]);              \
+                fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + (SB_) * STAGE + ((SB_) & 1) * SHIFT + s * PL + fa_off[t]);              \
             _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                         \
-                fb[s][t] = *reinterpret_cast<const bf16x8*>(Xs + (SB_) * STAGE + s * PL + fb_off[t]);              \
+                fb[s][t] = *reinterpret_cast<const bf16x8*>(Xs + (SB_) * STAGE + ((SB_) & 1) * SHIFT + s * PL + fb_off[t]);              \
         }
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;

@@ -804,6 +804,8 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
         if x3:
             blocks = _lib.lib().usip_mlp_wgrad_f32x3_blocks(M, N, P, nb)
             if blocks < 0:
+                if x2h and not (_lib.lib().usip_tuning_value(7) & 1) and max(M, N) * P < (1 << 30):
+                    return "wgrad_x2l_kernel<%d> |wg=%d" % (pro, -blocks)         # round 5: the full-line form
                 return "wgrad_x3_kernel<%d, %s, %d> |wg=%d" % (pro, "true" if xcoef is not None else "false",
                                                                2 if x2h else 3, -blocks)
         planes = ", 1" if bf16 else (", 3" if x3 else "")
