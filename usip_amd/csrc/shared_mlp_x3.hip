@@ -690,10 +690,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // late: a 16-lane group of a store instruction covers two rows x both stages of the pair, and with the images exactly
     // 16 KiB apart the two stages of a row met in the same eight banks (SQ_LDS_BANK_CONFLICT = 28 % of the LDS cycles in
     // the first build, profiles/r05d_pmc_wgrad.txt); 16 banks apart the group's 16 lanes cover all 32 banks once.
-    constexpr int SHIFT = 64;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * STAGE + 2 * SHIFT];
+    constexpr int SHIFT = 64, PAIR = 2 * (STAGE + SHIFT);      // bytes of one pair buffer: image 0 at 0, image 1 at STAGE + SHIFT
+    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * PAIR];
     unsigned char* Gs = smem;
-    unsigned char* Xs = smem + 4 * STAGE + SHIFT;
+    unsigned char* Xs = smem + 2 * PAIR;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -796,8 +796,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto store_event = [&](auto hc, int pbuf, int pair) {
         constexpr int H = decltype(hc)::value;
         const bool pok = pbeg + pair * 32 + kq < pend;         // float4 granularity: P % 4 == 0, segments start at 32 p
-        unsigned char* const gdst = Gs + pbuf * 2 * STAGE + lds0 + H * 4096;
-        unsigned char* const xdst = Xs + pbuf * 2 * STAGE + lds0 + H * 4096;
+        unsigned char* const gdst = Gs + pbuf * PAIR + lds0 + H * 4096;
+        unsigned char* const xdst = Xs + pbuf * PAIR + lds0 + H * 4096;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float4 v = rg[i];
@@ -843,9 +843,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         bf16x8 fa[2][TM], fb[2][TN];                                                                               \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                            \
             _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
-                fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + (SB_) * STAGE + ((SB_) & 1) * SHIFT + s * PL + fa_off[t]);              \
+                fa[s][t] = *reinterpret_cast<const bf16x8*>(Gs + ((SB_) >> 1) * PAIR + ((SB_) & 1) * (STAGE + SHIFT) + s * PL + fa_off[t]);              \
             _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                         \
-                fb[s][t] = *reinterpret_cast<const bf16x8*>(Xs + (SB_) * STAGE + ((SB_) & 1) * SHIFT + s * PL + fb_off[t]);              \
+                fb[s][t] = *reinterpret_cast<const bf16x8*>(Xs + ((SB_) >> 1) * PAIR + ((SB_) & 1) * (STAGE + SHIFT) + s * PL + fb_off[t]);              \
         }
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
