@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # USIP_LIB=<path>: load another BUILD of the same library (same-box A/B of two builds, tools/ab_build.sh); never a fallback
 LIB_PATH = os.environ.get("USIP_LIB") or os.path.join(_HERE, "libusip_hip.so")
-ABI = 4                      # = "abi=<n>" of usip_version(): bumped with every incompatible change of include/usip_hip.h
+ABI = 5                      # = "abi=<n>" of usip_version(): bumped with every incompatible change of include/usip_hip.h
 _lib = None
 
 _f32p = ctypes.c_void_p

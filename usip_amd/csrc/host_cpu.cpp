@@ -101,7 +101,7 @@ extern "C" int usip_pairwise_dist_f32_cpu(const float* a, const float* x, float*
 #ifndef USIP_BUILD_FLAGS
 #define USIP_BUILD_FLAGS "unknown"
 #endif
-extern "C" const char* usip_version(void) { return "usip_hip 0.4 gfx950 abi=4 flags=" USIP_BUILD_FLAGS; }
+extern "C" const char* usip_version(void) { return "usip_hip 0.5 gfx950 abi=5 flags=" USIP_BUILD_FLAGS; }
 
 // Launch-geometry knobs (speed only, never results): 0 = the library's own heuristic.  tools/ sweeps set them to
 // measure alternatives on the GPU; the product never does.
