@@ -54,6 +54,7 @@ def _fallback_worker(rank, world, port, q):
     import warnings
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["USIP_GRAPH_ALLREDUCE"] = "1"                   # the one-graph form is opt-in
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     st, batch = _make_step(rank)
@@ -105,6 +106,7 @@ def test_a_captured_allreduce_that_does_not_reduce_is_caught_and_the_two_graph_f
 def _rccl_one_rank_worker(port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["USIP_GRAPH_ALLREDUCE"] = "1"                   # the one-graph form is opt-in
     torch.cuda.set_device(0)
     dev = torch.device(DEV)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -133,6 +135,18 @@ def _rccl_one_rank_worker(port, q):
     out["entries"] = [(x["fused"], x["reduces"], x["checked"]) for x in g._graphs.values()]
     out["graph_equal"] = bool(torch.equal(_params_bits(g), _params_bits(e)))
     out["fallbacks"] = getattr(g, "fused_fallbacks", 0)
+    # (3) the DEFAULT (no opt-in): graph A / eager RCCL all-reduce / graph B
+    os.environ.pop("USIP_GRAPH_ALLREDUCE")
+    d, _ = _make_step(0, graph=True)
+    d.exchange_even_alone = True
+    e2, _ = _make_step(0, graph=False)
+    for _ in range(5):
+        d.step(batch)
+        e2.step(batch)
+    torch.cuda.synchronize()
+    out["default_form"] = d.allreduce_form()
+    out["default_entries"] = [(x["fused"], x["reduces"]) for x in d._graphs.values()]
+    out["default_equal"] = bool(torch.equal(_params_bits(d), _params_bits(e2)))
     q.put(out)
     dist.destroy_process_group()
 
@@ -154,6 +168,8 @@ def test_rccl_allreduce_runs_eagerly_and_inside_the_captured_step_on_one_rank():
     assert out["in_graph"] and out["forms"][-1] == "one graph (captured all-reduce)", out
     assert out["entries"] == [(True, True, True)] and out["fallbacks"] == 0, out
     assert out["graph_equal"], out                              # replaying RCCL from the graph changes no bit
+    assert out["default_form"].startswith("two graphs") and out["default_entries"] == [(False, False)], out
+    assert out["default_equal"], out                            # graph A / eager RCCL all-reduce / graph B: the same bits
 
 
 def test_bench_eight_ranks_gloo_one_gpu(tmp_path):

@@ -342,13 +342,15 @@ class _GraphedStep:
             world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
             # One graph for the whole step when the gradient exchange can be captured: RCCL (backend "nccl") enqueues
             # its collectives on a stream and supports stream capture, so forward + backward + all-reduce + Adam replay
-            # as ONE graph launch per step and nothing is left exposed between two replays.  gloo (the CPU tests, the
-            # several-ranks-on-one-GPU debugging mode) cannot be captured, a refused capture falls back, and
-            # USIP_GRAPH_ALLREDUCE=0 keeps the two-graph form for A/B runs.
+            # as ONE graph launch per step and nothing is left exposed between two replays.  OPT-IN since round 5
+            # (USIP_GRAPH_ALLREDUCE=1): the form has run on ONE rank only (tests/test_data_parallel_gpu.py) and the first
+            # multi-device run is the driver's -- until a run on N devices has validated it the default is the plain
+            # graph A / eager all-reduce / graph B.  gloo (the CPU tests, the several-ranks-on-one-GPU
+            # debugging mode) cannot be captured at all, and a refused capture falls back.
             # (only ever attempted with RCCL: a gloo all-reduce inside a capture aborts the process -- tried, r04aa)
             distributed = self._exchanges(group)
             fuse = (distributed and not getattr(self, "solo_fuse_off", False)
-                    and os.environ.get("USIP_GRAPH_ALLREDUCE", "1") not in ("0", "off")
+                    and os.environ.get("USIP_GRAPH_ALLREDUCE", "0") in ("1", "on")
                     and (dist.get_backend(group) == "nccl" or getattr(self, "_test_fused_without_reduce", False))
                     and self.allreduce_events is None)
             # a single process has nothing between backward and update either: one graph (USIP_GRAPH_ONE=0: two, for A/B)
