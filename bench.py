@@ -201,7 +201,7 @@ def kernel_leg(dev, traffic_db, iters=12):
 def cpu_baseline(args, model, dev=None):
     """the oracle (PyTorch-CPU restatement of the same step, proven equal to the reference by the golden
     fixtures) on a bounded sample -- 1 pair = 2 clouds of the same workload -- for BOTH detectors: (A)
-    RPN_Detector_Ball, the K=64 headline model, and (B) RPN_Detector, the reference's default.  3 warm-up + 5 timed
+    RPN_Detector_Ball, the K=64 headline model, and (B) RPN_Detector, the reference's default.  1 warm-up + 3 timed
     steps each, median.  `value` is the model this run benchmarks; the other is under `models`.
 
     The oracle's result for the benchmarked model is not thrown away: the HIP step (eager, the arithmetic mode this run
@@ -221,20 +221,21 @@ def cpu_baseline(args, model, dev=None):
     batch = {k: torch.from_numpy(v) for k, v in batch_np.items()}
     me = model if model in ("ball", "som") else "ball"
     res, parity = {}, None
+    WARM, TIMED = 1, 3           # ~6 s (Ball) / ~3.4 s (SOM) per step: ~38 s of CPU work for both models (contract: 10-30 s each)
     for mdl in ("ball", "som"):
         filled = synth.fill_parameters(detector_param_shapes(mdl, 4))
         P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in filled.items()
              if not ("running_" in k or "num_batches" in k)}
         bufs = {k: torch.from_numpy(v.copy()) for k, v in filled.items() if "running_" in k}
         times, last = [], None
-        for i in range(3 + 5):
+        for i in range(WARM + TIMED):
             for p in P.values():
                 p.grad = None
             t0 = time.perf_counter()
             last = od.detector_step(P, bufs, batch, mdl, opt.node_knn_k_1, opt.loss_sigma_lower_bound,
                                     opt.keypoint_on_pc_alpha)
             times.append(time.perf_counter() - t0)
-        t = sorted(times[3:])
+        t = sorted(times[WARM:])
         res[mdl] = dict(value=2.0 / t[len(t) // 2], s_per_step=round(t[len(t) // 2], 3), p10=round(t[0], 3),
                         p90=round(t[-1], 3))
         if mdl == me and dev is not None:
@@ -259,7 +260,7 @@ def cpu_baseline(args, model, dev=None):
     return dict(value=res[me]["value"], unit="point-clouds/s", cores=cores, host_cores=host_cores, kind="port",
                 thread_cap="16 (ATen's strided reductions slow down beyond that: 62 s/step at 256 threads vs ~6 s)",
                 models={"RPN_Detector_Ball": res["ball"], "RPN_Detector": res["som"]},
-                sample="1 pair (2 clouds) N=%d M=%d, oracle/detector.py fwd+losses+bwd, median of 5 after 3 warm-up; "
+                sample="1 pair (2 clouds) N=%d M=%d, oracle/detector.py fwd+losses+bwd, median of 3 after 1 warm-up; "
                        "value = %s (%.2f s/step)" % (args.n, args.m, {"ball": "RPN_Detector_Ball", "som": "RPN_Detector"}[me],
                                                      res[me]["s_per_step"])), parity
 
