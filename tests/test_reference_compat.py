@@ -113,6 +113,25 @@ FORWARD_SCRIPT = textwrap.dedent("""
         for k, v in (("node", node), ("keypoints", kp), ("sigmas", sg)):
             a, b = v.detach().numpy().astype(np.float64), g[k].astype(np.float64)
             res["rel/" + k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+        # ModelDetector.optimize without the Adam update (keypoint_detector.py:158-207), on the reference's own losses
+        from models import losses
+        B = t["src_pc"].shape[0]
+        opt.keypoint_on_pc_alpha = float(g["cfg_alpha"])
+        kp_t = torch.matmul(t["R"], kp[:B]) * t["scale"].unsqueeze(1).unsqueeze(2) + t["shift"]
+        net.zero_grad()
+        lc, pure, weighted = losses.ChamferLoss_Brute(opt)(kp_t, kp[B:], sg[:B], sg[B:])
+        crit = losses.KeypointOnPCLoss(opt)
+        loss = lc + torch.mean(crit(kp[:B], t["src_pc"], None)) * opt.keypoint_on_pc_alpha \
+            + torch.mean(crit(kp[B:], t["dst_pc"], None)) * opt.keypoint_on_pc_alpha
+        loss.backward()
+        res["rel/loss"] = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
+        worst = 0.0
+        for k, p_ in net.named_parameters():
+            want = float(g["grad_norm/" + k])
+            got = float(np.sqrt((p_.grad.detach().numpy().astype(np.float64) ** 2).sum()))
+            if want > 1e-12:
+                worst = max(worst, abs(got - want) / want)
+        res["rel/grad_norms"] = worst
         out[cls] = res
     print(json.dumps(out))
 """) % (ROOT, REF, os.path.join(ROOT, "tests", "golden"))
@@ -125,7 +144,10 @@ def test_reference_networks_forward_runs_on_cpu_over_the_dropin_modules():
     the product's host twins in csrc/host_cpu.cpp; oracle/ is never imported).  RPN_Detector at BASELINE configs[0] size
     (N=1024, M=64, batch 2 pairs) and RPN_Detector_Ball forward in train mode: every index tensor the two modules return
     equals the fixture the reference produced with its own C++ (index_max) / the pinned restatement (ball_query), and
-    node / keypoints / sigmas agree to 1e-5."""
+    node / keypoints / sigmas agree to 1e-5.  Then the rest of ModelDetector.optimize on the reference's own losses.py --
+    probabilistic chamfer + 2 x keypoint-on-pc, backward -- gives the fixture's loss and the L2 norm of every parameter
+    gradient (the CPU run of BASELINE configs[0] as a whole: the same ATen calls as when the fixture was made, and the
+    same indices, so the agreement is to rounding of the thread partition)."""
     import json
     p = subprocess.run([sys.executable, "-c", FORWARD_SCRIPT], capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -137,4 +159,4 @@ def test_reference_networks_forward_runs_on_cpu_over_the_dropin_modules():
             if k.startswith("idx_equal/"):
                 assert v is True, (cls, k)
             if k.startswith("rel/"):
-                assert v <= 1e-5, (cls, k, v)
+                assert v <= (1e-4 if k == "rel/grad_norms" else 1e-5), (cls, k, v)
