@@ -41,7 +41,8 @@ const char* usip_version(void);
  * "r5_forms" (USIP_TUNE_R5_FORMS), bit flags that bring back round 4's form of a kernel for same-box A/B runs: 1 = the f32x2
  * weight gradient with half-line loads (wgrad_x3_kernel<.., 2> instead of wgrad_x2l_kernel); and that switch ON forms round 5
  * measured and did not keep: 2 / 4 = two / four loop iterations' loads in flight in the BatchNorm-backward reduction (default
- * one), 8 = several batches of rows per workgroup with prefetch in group_max4 (default one). */
+ * one), 8 = several batches of rows per workgroup with prefetch in group_max4 (default one); 32 = the 128-row-tile split GEMM with
+ * round 4's two-slot weight ring (DMA one stage ahead, issued at the top of the stage) instead of the three-slot one. */
 enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_X3_WGRAD_TILE, USIP_TUNE_X3_GEMM_TILE,
        USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_X2_DIRECT, USIP_TUNE_R5_FORMS, USIP_TUNE_COUNT };
 int usip_set_tuning(const char* name, int value);

@@ -156,9 +156,14 @@ __global__ __launch_bounds__(512) void split3_multi_kernel(const usip_split3_des
 //              (4, 2): 256 x 128, 256 threads, two workgroups per CU   (the wide layers: every streamed element is
 //                      prepared for 256 channels instead of 128 -- half the preparation per MFMA, half the L2 reads)
 //              (4, 4): 256 x 256, 512 threads, one workgroup per CU
-template <int PRO, int EPI, int TM, int WN, int NPL = 3>
+//   ASLOTS = 3 (round 5, 128-row tiles only: 12 KB more LDS still leave two workgroups per CU): the weight stage is
+//   requested TWO stages ahead into a three-slot ring.  The M-sized launches of the second stage and the head (8192
+//   positions: 128-320 workgroups, one per CU, a lone wave per SIMD) walk K = 256..640 serially and were paced by the
+//   one-stage-ahead DMA's L2 round trip (~1.3 us per 16-k stage for ~0.5 us of work).
+template <int PRO, int EPI, int TM, int WN, int NPL = 3, int ASLOTS = 2>
 __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_x3p_kernel(const GemmArgs a, const uint4* __restrict__ planes)
 {
+    static_assert(ASLOTS == 2 || (ASLOTS == 3 && TM == 2), "the three-slot weight ring exists for the 128-row tile");
     constexpr int XBM = 64 * TM, XBN = 64 * WN, NT = 128 * WN;
     constexpr int APL = XBM * 32, BPL = XBN * 32;              // bytes of one plane of one stage
     constexpr int ASTAGE = NPL * APL, BSTAGE = NPL * BPL;
@@ -166,13 +171,13 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr bool POOL = (PRO == PRO_BN_BWD_POOL);
     constexpr bool TWO = (PRO == PRO_BN_BWD) || POOL;
     constexpr int NCOEF = (PRO == PRO_NONE) ? 0 : (TWO ? 4 : 2);
-    constexpr int OPER_BYTES = 2 * (ASTAGE + BSTAGE);          // two stages of both operands
+    constexpr int OPER_BYTES = ASLOTS * ASTAGE + 2 * BSTAGE;   // two (three) stages of the weights, two of the streamed operand
     // widest contraction of the path: 640 inputs (mlp1) forward, 512 outputs backward; 4 x 512 floats keep two
     // workgroups of the 256 x 128 tile inside the CU's 160 KiB
     constexpr int KMAX = (NCOEF == 4) ? 512 : 640;
     __shared__ __attribute__((aligned(16))) unsigned char smem[OPER_BYTES + (NCOEF ? NCOEF : 1) * KMAX * 4];
     unsigned char* As = smem;                                  // [stage][plane][row][16 k]
-    unsigned char* Bs = smem + 2 * ASTAGE;
+    unsigned char* Bs = smem + ASLOTS * ASTAGE;
     float* cf = reinterpret_cast<float*>(smem + OPER_BYTES);   // [NCOEF][KMAX]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -357,12 +362,14 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int t = 0; t < 2; ++t) fb_off[t] = lds_off(wn * 64 + t * 32 + c, kh);
     constexpr int NXL = POOL ? 24 : (TWO ? 16 : 8);            // register loads of one stage of the streamed operand
     dma_stage(0, 0);
+    if (ASLOTS == 3) dma_stage(1, min(1, nk - 1));
     load_stage(0);
     __syncthreads();                                           // prologue coefficients are in LDS
     store_stage(0, 0);
     load_stage(min(1, nk - 1));
     __syncthreads();
     int cur = 0;
+    int sa = 0;                                                // ASLOTS == 3: the ring slot that holds stage kt's weights
     // the six plane pairs, smallest terms first; operands swapped: D'[position][channel], see gemm_epilogue
 #define USIP_X3_PRODUCT(PA_, PB_)                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                           \
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
         bf16x8 fa[NPL][TM], fb[NPL][2];                                                                            \
         _Pragma("unroll") for (int s = 0; s < NPL; ++s) {                                                          \
             _Pragma("unroll") for (int t = 0; t < TM; ++t)                                                         \
-                fa[s][t] = *reinterpret_cast<const bf16x8*>(As + cur * ASTAGE + s * APL + fa_off[t]);              \
+                fa[s][t] = *reinterpret_cast<const bf16x8*>(As + (ASLOTS == 3 ? sa : cur) * ASTAGE + s * APL + fa_off[t]); \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                          \
                 fb[s][t] = *reinterpret_cast<const bf16x8*>(Bs + cur * BSTAGE + s * BPL + fb_off[t]);              \
         }
@@ -389,7 +396,14 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
         if constexpr (NPL == 2) { USIP_X3_PRODUCT(0, 0) }                                                          \
         else { USIP_X3_PRODUCT(1, 0) USIP_X3_PRODUCT(0, 1) USIP_X3_PRODUCT(0, 0) }
     for (int kt = 0; kt + 1 < nk; ++kt) {
-        dma_stage(cur ^ 1, kt + 1);                            // A of stage kt+1: memory -> LDS (the other buffer is free)
+        // A of stage kt+1: memory -> LDS (the other buffer is free); three slots: stage kt+2 into the slot stage kt-1 left
+        // (in the last iterations a harmless repeat of the last stage, so that the counted wait below always has the same
+        // instructions in front of it)
+        // -- and it is issued BEHIND store_stage (below), not here: hipcc waits vmcnt(0) at the first use of the raw
+        // operand registers inside store_stage whenever an LDS-DMA is in flight, i.e. for every DMA issued before that
+        // point.  At the top of the stage that is a wait for a request made a few hundred cycles earlier (the two-slot
+        // form: one L2 round trip per stage, exposed); behind store_stage the same drain comes one whole stage later.
+        if (ASLOTS == 2) dma_stage(cur ^ 1, kt + 1);
         // no memory instruction may cross: the counted wait below relies on "DMA first, then the NXL register loads"
         // (ALU, MFMA and LDS instructions may still be scheduled across).  Measured and not kept (r03, f32x2 512 x 512
         // forward, same box): the DMA issued after store_stage, so that hipcc's vmcnt(0) at the first use of the
@@ -406,14 +420,21 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
         USIP_X3_READ_FRAGS()
         USIP_X3_FIRST_HALF()
         store_stage(cur ^ 1, kt + 1);                          // X of stage kt+1: registers -> LDS
+        if (ASLOTS == 3) {
+            __builtin_amdgcn_sched_barrier(0);                 // (the DMA stays behind the first use of the operand registers)
+            dma_stage(sa == 0 ? 2 : sa - 1, min(kt + 2, nk - 1));
+        }
         load_stage(min(kt + 2, nk - 1));                       // X of stage kt+2: memory -> registers (last: a harmless repeat)
         USIP_X3_SECOND_HALF()
         // The DMA (issued before the register loads of stage kt+2, loads retire in order) must have landed and this
         // wave's LDS writes must be done before anyone reads the other buffer; the register loads stay in flight
         // across the barrier -- __syncthreads() would drain them (it waits vmcnt(0) while an LDS-DMA is pending).
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NXL) : "memory");
+        // (three slots: what may stay in flight is this stage's DMA -- stage kt+2 -- AND its register loads; everything
+        // older, the DMA of stage kt+1 included, has then landed)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ASLOTS == 3 ? NPL * NA + NXL : NXL) : "memory");
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
+        sa = (sa == 2) ? 0 : sa + 1;
     }
     {
         USIP_X3_READ_FRAGS()
@@ -1240,8 +1261,20 @@ static int launch_x3p(const GemmArgs& a, const uint4* pl, int pro, hipStream_t s
     if (total > 0x7fffffffLL) return USIP_EINVAL;
     const int epi = a.stats ? EPI_STATS : EPI_NONE;
     dim3 grid((unsigned)total), block(128 * WN);
+    // three-slot weight ring: every 128-row-tile launch (knob r5_forms bit 5 = 32: never).  Same box, alternating
+    // (profiles/r05j_deep_ring_ab.txt): the six M-sized launches of the second stage and the head 258 -> 228 us together
+    // (512 x 640 forward 56 -> 49, 256 x 512 pooled data gradient 44 -> 37, ...), the chip-filling 128 x 256 data gradient
+    // 77 -> 70-75, the step 4.68-4.71 -> 4.65 ms
+    const bool deep = TM == 2 && !(usip_tuning_value(USIP_TUNE_R5_FORMS) & 32);
 #define USIP_X3P_CASE(P_, E_)                                                                 \
     if (pro == P_ && epi == E_) {                                                             \
+        if constexpr (TM == 2) {                                                              \
+            if (deep) {                                                                       \
+                USIP_LAUNCH((gemm_x3p_kernel<P_, E_, TM, WN, NPL, 3>), grid, block, 0, st, a, pl); \
+                USIP_LAUNCH_CHECK();                                                          \
+                return USIP_OK;                                                               \
+            }                                                                                 \
+        }                                                                                     \
         USIP_LAUNCH((gemm_x3p_kernel<P_, E_, TM, WN, NPL>), grid, block, 0, st, a, pl);       \
         USIP_LAUNCH_CHECK();                                                                  \
         return USIP_OK;                                                                       \
