@@ -575,8 +575,9 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                         pro, e, "true" if tail else "false", 1 if gen else depth,
                         "true" if red is not None else "false", "true" if gen else "false",
                         "true" if direct else "false", wg)
-            return "gemm_x3p_kernel<%d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3,
-                                                                   nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
+            slots = 3 if (bm == 128 and not (_lib.lib().usip_tuning_value(7) & 32)) else 2    # round 5: weight-ring slots
+            return "gemm_x3p_kernel<%d, %d, %d, %d, %d, %d> |wg=%d" % (pro, e, bm // 64, bn // 64, 2 if x2h else 3, slots,
+                                                                       nb * ((P + bn - 1) // bn) * ((M + bm - 1) // bm))
         if x3:
             return "gemm_bf16_kernel<2, 2, 16, %d, %d, 3> |wg=%d" % (pro, e, nb * ((P + 127) // 128) * ((M + 127) // 128))
         # csrc/shared_mlp.hip mlp_gemm_impl: 32 rows per wave when 128-row tiles would not fill the chip
