@@ -558,8 +558,12 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                 return "gemm_x2r_kernel<%d, %d, %s> |wg=%d" % (pro, e, "true" if rowbias is not None else "false",
                                                                min(512, nb * ((P + 63) // 64)))
             if x2h:
-                bn = 128
-                if bm == 256 and (_lib.lib().usip_tuning_value(6) & 15) != 1 and K * P * 4 < 2 ** 31:
+                # (tile_cols == 256 -- a measurement knob -- sends the launch to launch_x3p<4, 4, 2> in the C dispatcher
+                # before the direct kernel is considered: usip_mlp_gemm_x2h_f32; mirrored here)
+                wide = bm == 256 and bn == 256
+                if not wide:
+                    bn = 128
+                if bm == 256 and not wide and (_lib.lib().usip_tuning_value(6) & 15) != 1 and K * P * 4 < 2 ** 31:
                     # csrc/gemm_x2d.hip: <pro, stats, K % 16 != 0, stages of operand loads in flight>; persistent, two
                     # workgroups per CU once there are more tiles than that
                     tail = K % 16 != 0
