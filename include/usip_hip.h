@@ -36,7 +36,8 @@ const char* usip_version(void);
  * counterpart.  Returns USIP_EINVAL for an unknown name. */
 /* "x2_direct" (USIP_TUNE_X2_DIRECT), low four bits: 1 = the LDS-staged f32x2 GEMM of round 3 instead of csrc/gemm_x2d.hip,
  * 2 = one stage of operand loads in flight, 4 = one tile per workgroup, 8 = the LDS-transposing epilogue for data gradients
- * too, 10 = csrc/gemm_x2e.hip (both operands by LDS-DMA, 8-wave workgroups) for the forward launches that fit it; bits 4-5
+ * too, 10 = csrc/gemm_x2e.hip (both operands by LDS-DMA, 8-wave workgroups) for the forward launches that fit it, 12 = never
+ * csrc/gemm_x2f.hip (round 6: one wave per SIMD, 256 x 256 tiles -- the default wherever it fits); bits 4-5
  * skip the main loop / the epilogue (time splits: wrong results, tools/x2_knob_bench.py only).
  * "r5_forms" (USIP_TUNE_R5_FORMS), bit flags that bring back round 4's form of a kernel for same-box A/B runs: 1 = the f32x2
  * weight gradient with half-line loads (wgrad_x3_kernel<.., 2> instead of wgrad_x2l_kernel); and that switch ON forms round 5
@@ -321,6 +322,12 @@ int usip_mlp_gemm_x2h_f32(const void* planes, const float* X, const float* X2, c
  * d and of y.  usip_mlp_gemm_x2d_red_tiles() = tiles of such a launch, 0 when the shape does not take this path (M % 256,
  * P % 128, 256-row tiles): use usip_mlp_gemm_x2h_f32 + usip_bn_backward_reduce_f32 then. */
 int usip_mlp_gemm_x2d_red_tiles(int M, int K, int P, int nb, int red_group);
+/* Round 6 (profiling aid, no reference counterpart): 1 when usip_mlp_gemm_x2h_f32 runs a launch of this shape that reaches
+ * the direct kernel as csrc/gemm_x2f.hip -- one wave per SIMD, 256-channel x 256-position tiles, 64 positions per wave; the
+ * same products in the same order as csrc/gemm_x2d.hip (bit-identical outputs).  has_stats / has_bias: the pointer is given;
+ * rb_group 0: no row bias; y_rows 0: M. */
+int usip_mlp_gemm_x2f_used(int M, int K, int P, int nb, int pro, int has_stats, int has_bias, int rb_group,
+                           int pool_group, int y_rows);
 int usip_mlp_gemm_x2h_red_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
                               const float* pool_dp, const int32_t* pool_arg, int pool_group, float* Y,
                               const float* red_y, const float* red_coef, float* red_out, float* red_gsum,
@@ -400,8 +407,16 @@ int usip_mlp_wgrad_f32(const float* G, const float* G2, const float* coef, int p
  * entry point that ends in the fixed-order sum of its partial tiles (usip_mlp_wgrad_*, usip_mlp_narrow_backward_f32,
  * usip_mlp_layer_backward_x2h_f32) launches its tile kernel and RECORDS the sum instead of launching it; the flush issues all
  * recorded sums in at most two launches (same summation order: same bits) and returns how many it issued (>= 0; < 0 error).
- * The caller keeps every workspace alive until the flush.  usip_wgrad_defer(0) leaves the mode and drops what is recorded. */
+ * The caller keeps every workspace alive until the flush.  usip_wgrad_defer(0) leaves the mode and drops what is recorded.
+ * The flush issues ceil(jobs / 24) launches per reduction width (two widths): two launches for the detector's fifteen sums.
+ * usip_wgrad_defer_on(stream) enters the mode for ONE stream: entry points called with any other stream launch their sum at
+ * once (the job list is process-global; a second thread / device / stream must not find its sums on this stream's flush).
+ * usip_wgrad_defer_hold(1) .. (0) brackets calls whose sum must be launched at once although the mode is on: a dW that the
+ * caller returns to a consumer running before the flush (anything that is not a view of the step's gradient bucket);
+ * it returns the previous hold value. */
 int usip_wgrad_defer(int on);
+int usip_wgrad_defer_on(void* stream);
+int usip_wgrad_defer_hold(int hold);
 int usip_wgrad_flush(void* stream);
 
 /* Backward of a NARROW layer (64 inputs, 64 or 128 outputs) in one pass over its tensors: data gradient AND weight

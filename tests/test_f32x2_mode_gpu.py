@@ -715,6 +715,72 @@ def test_all_dma_forward_gemm_equals_the_direct_one_bit_for_bit(shape, stats, x2
         ops.PLANES_CACHE = None
 
 
+X2F_SHAPES = [(4, 256, 256, 8192), (16, 256, 512, 8192), (16, 512, 512, 4096), (2, 640, 512, 8192), (8, 128, 256, 8192)]
+
+
+@pytest.mark.parametrize("shape", X2F_SHAPES)
+def test_one_wave_per_simd_gemm_equals_the_direct_one_bit_for_bit(shape, x2_forced):
+    """Round 6, csrc/gemm_x2f.hip (one wave per SIMD, 256 x 256 tiles, a wave = 64 positions as even / odd blocks loaded with
+    dwordx2, next tile requested before the epilogue; the default wherever it fits) computes what csrc/gemm_x2d.hip computes
+    (knob x2_direct = 12), in the same order per accumulator: forward outputs bit-identical with bias, with and without a row
+    bias and statistics (statistics equal per 128-position slot up to fp32 summation order); data gradients (pro 2, and
+    pro 3 = the pooled form) bit-identical; persistent workgroups with 1..4 tiles each; repeated launches bit-stable."""
+    from usip_amd import _lib, ops
+    nb, K, M, P = shape
+    lib = _lib.lib()
+    assert lib.usip_mlp_x3p_tile_rows(M, P, nb) == 256
+    assert lib.usip_mlp_gemm_x2f_used(M, K, P, nb, 1, 1, 1, 0, 0, 0) == 1
+    g = torch.Generator().manual_seed(K * 5 + M + P + nb)
+    At = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+    X = (torch.randn(nb, K, P, generator=g) * 1.7 + 0.2).to(DEV)
+    bias = torch.randn(M, generator=g).to(DEV)
+    gamma = (1 + 0.3 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(K, generator=g)).to(DEV)
+    coef = _bn_coef(X, gamma, beta)
+    rowbias = torch.randn(nb, M, P // 16, generator=g).to(DEV)
+    ops.PLANES_CACHE = {}
+    try:
+        for rb in (None, rowbias):
+            for stats in (True, False):
+                kw = dict(want_stats=stats, pro=1, coef=coef, rowbias=rb, rb_group=16 if rb is not None else 1)
+                y1, s1 = ops.mlp_gemm(At, X, bias, **kw)
+                lib.usip_set_tuning(b"x2_direct", 12)
+                y0, s0 = ops.mlp_gemm(At, X, bias, **kw)
+                lib.usip_set_tuning(b"x2_direct", 0)
+                assert torch.equal(y0, y1), (rb is not None, stats, float((y0 - y1).abs().max()))
+                if stats:
+                    assert s0.shape == s1.shape
+                    assert _rel(s1[0], s0[0]) < 2e-6 and _rel(s1[1], s0[1]) < 2e-6
+                    assert _rel(s1.double().sum(-1)[0], y1.double().sum((0, 2))) < 1e-5
+                for _ in range(2):
+                    assert torch.equal(ops.mlp_gemm(At, X, bias, **kw)[0], y1)
+        if K <= 512:
+            W = (torch.randn(K, M, generator=g) * (2.0 / K) ** 0.5).to(DEV)
+            Yp = (torch.randn(nb, K, P, generator=g) * 2.0 + 0.5).to(DEV)
+            dZ = torch.randn(nb, K, P, generator=g).to(DEV)
+            cfy = _bn_coef(Yp, gamma, beta)
+            coef4 = ops.bn_backward_reduce(dZ, Yp, cfy, cfy[2].contiguous(), cfy[3].contiguous(), gamma, True)[2]
+            G = 16
+            dp = torch.randn(nb, K, P // G, generator=g).to(DEV)
+            arg = torch.randint(0, G, (nb, K, P // G), generator=g, dtype=torch.int32).to(DEV)
+            c4p = ops.bn_pool_backward_reduce(dp, arg, Yp.view(nb, K, P // G, G), cfy, cfy[2].contiguous(), cfy[3].contiguous(),
+                                              gamma, True)[2]
+            runs = (lambda: ops.mlp_gemm(W, dZ, pro=2, X2=Yp, coef=coef4, tag="dgrad")[0],
+                    lambda: ops.mlp_gemm(W, None, pro=3, X2=Yp, coef=c4p, tag="dgrad", pool=(dp, arg, G))[0])
+            for run in runs:
+                d1 = run()
+                lib.usip_set_tuning(b"x2_direct", 12)
+                d0 = run()
+                lib.usip_set_tuning(b"x2_direct", 0)
+                assert torch.equal(d0, d1), float((d0 - d1).abs().max())
+                assert bool(torch.isfinite(d1).all()) and float(d1.abs().max()) > 0
+                for _ in range(3):
+                    assert torch.equal(run(), d1)
+    finally:
+        lib.usip_set_tuning(b"x2_direct", 0)
+        ops.PLANES_CACHE = None
+
+
 @pytest.mark.parametrize("shape", [s for s in DIRECT_SHAPES if s[1] <= 512])
 @pytest.mark.parametrize("gscale", [1.0, 1e-6])
 def test_direct_gemm_backward_is_fp32_accurate(shape, gscale, x2_forced):

@@ -23,6 +23,8 @@ SIGNATURES = {
     "usip_set_tuning": ([ctypes.c_char_p, _int], _int),
     "usip_tuning_value": ([_int], _int),
     "usip_wgrad_defer": ([_int], _int),
+    "usip_wgrad_defer_on": ([_stream], _int),
+    "usip_wgrad_defer_hold": ([_int], _int),
     "usip_wgrad_flush": ([_stream], _int),
     "usip_index_max_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _stream], _int),
     "usip_index_max_f32_cpu": ([_f32p, _i32p, _i32p, _int, _int, _int, _int, _int], _int),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "usip_mlp_gemm_x2h_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _i32p, _int,
                                _f32p, _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_gemm_x2d_red_tiles": ([_int, _int, _int, _int, _int], _int),
+    "usip_mlp_gemm_x2f_used": ([_int] * 10, _int),
     "usip_mlp_gemm_x2h_red_f32": ([ctypes.c_void_p, _f32p, _f32p, _f32p, _int, _f32p, _i32p, _int, _f32p, _f32p, _f32p, _f32p,
                                    _f32p, _int, _int, _int, _int, _int, _stream], _int),
     "usip_mlp_wgrad_f32x3_used": ([_int, _int, _int, _int], _int),

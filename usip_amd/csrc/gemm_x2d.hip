@@ -537,10 +537,14 @@ __global__ __launch_bounds__(DNT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned ring_lds = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned char*)smem);
     auto dma_half = [&](int kt, int hf) {
         const unsigned dst = ring_lds + (unsigned)((kt & (DSLOTS - 1)) * DSTAGE) + (unsigned)(wave * 1024);
+        // m0 (the LDS base of an LDS-DMA) is saved and restored INSIDE the statement: hipcc treats "m0" in a clobber list as a
+        // reserved register it may ignore (344 -Winline-asm warnings); this form clobbers nothing
 #pragma unroll
-        for (int j = 2 * hf; j < 2 * hf + 2; ++j)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                         :: "s"(dst + j * 4096), "v"(a_voff), "s"(rAv), "s"(kt * DSTAGE + j * 4096) : "memory", "m0");
+        for (int j = 2 * hf; j < 2 * hf + 2; ++j) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst + j * 4096), "v"(a_voff), "s"(rAv), "s"(kt * DSTAGE + j * 4096) : "memory");
+        }
     };
     constexpr int NX = POOL ? 24 : (TWO ? 16 : 8);             // register loads of one stage of the streamed operand
     // Memory instructions issued AFTER the last DMA instruction of the previous stage (slot 5) when this stage's barrier
@@ -677,6 +681,7 @@ namespace usip_mlp {
 int launch_gemm_x2d(const GemmArgs& a_in, const uint4* pl, int pro, hipStream_t st)
 {
     if (!a_in.red_out && gemm_x2e_takes(a_in, pro)) return launch_gemm_x2e(a_in, pl, st);
+    if (gemm_x2f_takes(a_in, pro)) return launch_gemm_x2f(a_in, pl, pro, st);   // round 6: one wave per SIMD, 64-position wave tiles
     GemmArgs a = a_in;
     a.a_trans = usip_tuning_value(USIP_TUNE_X2_DIRECT) >> 4;   // measurement aid, see the kernel (0 in the product)
     const int tpc = (a.P + DBN - 1) / DBN, nmt = (a.M + DBM - 1) / DBM;

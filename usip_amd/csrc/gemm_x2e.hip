@@ -198,14 +198,16 @@ __global__ __launch_bounds__(ENT) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int rs = a.P * 4;
     auto dma_w = [&](int kt, int j) {
         const unsigned dst = wring_lds + (unsigned)((kt & (ESLOTS - 1)) * EWSTAGE) + (unsigned)(wave * 1024 + j * 8192);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(dst), "v"(a_voff), "s"(rAv), "s"(kt * EWSTAGE + j * 8192) : "memory", "m0");
+        unsigned keep;                                         // m0 saved and restored inside the statement (see gemm_x2d.hip)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(a_voff), "s"(rAv), "s"(kt * EWSTAGE + j * 8192) : "memory");
     };
     auto dma_x = [&](int kt, int j) {
         const int r = wave * 2 + j;
         const unsigned dst = xring_lds + (unsigned)((kt & (ESLOTS - 1)) * EXSTAGE) + (unsigned)(r * 1024);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     :: "s"(dst), "v"(x_voff), "s"(rXv), "s"((kt * EBK + r) * rs) : "memory", "m0");
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(x_voff), "s"(rXv), "s"((kt * EBK + r) * rs) : "memory");
     };
 
     // raw values of the NEXT stage (read from the ring behind the barrier that guarantees they landed), the lane's

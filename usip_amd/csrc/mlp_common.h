@@ -238,6 +238,9 @@ int launch_gemm_x2d(const GemmArgs& a, const uint4* pl, int pro, hipStream_t st)
 // gemm_x2e.hip: the forward launches of that family with both operands by LDS-DMA (one 8-wave workgroup per CU)
 bool gemm_x2e_takes(const GemmArgs& a, int pro);
 int launch_gemm_x2e(const GemmArgs& a, const uint4* pl, hipStream_t st);
+// gemm_x2f.hip (round 6): the launches of that family with whole 256 x 256 tiles as ONE wave per SIMD, 64 positions per wave
+bool gemm_x2f_takes(const GemmArgs& a, int pro);
+int launch_gemm_x2f(const GemmArgs& a, const uint4* pl, int pro, hipStream_t st);
 // the same from two fp16 planes per operand (pro 2 / 3 with the [5][M] coef4, xcoef = [4][N] batch statistics)
 int launch_wgrad_x2h_256(const WgradArgs& a, int pro, unsigned blocks, hipStream_t st);
 

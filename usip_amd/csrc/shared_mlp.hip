@@ -883,6 +883,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_rows_kernel(
 namespace {
 std::mutex g_defer_lock;
 bool g_defer_on = false;
+bool g_defer_any_stream = true;                               // usip_wgrad_defer(1): whatever stream; _on(stream): that stream only
+hipStream_t g_defer_stream = nullptr;
+int g_defer_hold = 0;                                         // > 0: reductions are launched at once although the mode is on
 std::vector<ReduceJob> g_defer_jobs;
 
 template <int Q>
@@ -913,8 +916,35 @@ extern "C" int usip_wgrad_defer(int on)
 {
     std::lock_guard<std::mutex> g(g_defer_lock);
     g_defer_on = on != 0;
+    g_defer_any_stream = true;
+    g_defer_stream = nullptr;
+    g_defer_hold = 0;
     g_defer_jobs.clear();                                     // entering or leaving the mode: nothing stale survives
     return USIP_OK;
+}
+
+// The mode for ONE stream: only reductions whose entry point was called with `stream` are recorded; a call on
+// any other stream (another thread, another device's step) launches its reduction at once, as outside the mode.
+extern "C" int usip_wgrad_defer_on(void* stream)
+{
+    std::lock_guard<std::mutex> g(g_defer_lock);
+    g_defer_on = true;
+    g_defer_any_stream = false;
+    g_defer_stream = (hipStream_t)stream;
+    g_defer_hold = 0;
+    g_defer_jobs.clear();
+    return USIP_OK;
+}
+
+// hold != 0: until usip_wgrad_defer_hold(0) every reduction is launched at once although the mode is on -- for a weight
+// gradient whose destination the caller hands straight to a consumer that runs BEFORE the flush (a dW that is not a view of
+// the step's gradient bucket).  Returns the previous value.
+extern "C" int usip_wgrad_defer_hold(int hold)
+{
+    std::lock_guard<std::mutex> g(g_defer_lock);
+    const int was = g_defer_hold;
+    g_defer_hold = hold != 0;
+    return was;
 }
 
 extern "C" int usip_wgrad_flush(void* stream)
@@ -938,7 +968,7 @@ int usip_mlp::launch_wgrad_reduce(const float* part, float* dW, long long elems,
 {
     {
         std::lock_guard<std::mutex> g(g_defer_lock);
-        if (g_defer_on) {                                     // the caller keeps `part` alive until usip_wgrad_flush
+        if (g_defer_on && !g_defer_hold && (g_defer_any_stream || st == g_defer_stream)) {   // the caller keeps `part` alive until usip_wgrad_flush
             g_defer_jobs.push_back(ReduceJob{part, dW, elems, slices, N, ldw, coloff, 0, 0});
             return USIP_OK;
         }

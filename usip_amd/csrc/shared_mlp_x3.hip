@@ -1382,6 +1382,20 @@ extern "C" int usip_mlp_gemm_x2d_red_tiles(int M, int K, int P, int nb, int red_
     return nb * (P / 128);
 }
 
+// Would usip_mlp_gemm_x2h_f32 hand a launch of this shape that reaches the direct kernel (256-row tiles, 128-position
+// tiles: see the dispatcher above) to the round-6 form csrc/gemm_x2f.hip (one wave per SIMD, 256 x 256 tiles)?  Profiling aid:
+// usip_amd/ops.py names the kernel a launch runs.  has_* = the pointer is given; rb_group 0 = no row bias; 16-B aligned
+// operands assumed (the entry point checks the real pointers).
+extern "C" int usip_mlp_gemm_x2f_used(int M, int K, int P, int nb, int pro, int has_stats, int has_bias, int rb_group,
+                                      int pool_group, int y_rows)
+{
+    static const float dummy[4] __attribute__((aligned(16))) = {0.f, 0.f, 0.f, 0.f};
+    GemmArgs a{nullptr, 0, dummy, dummy, dummy, has_bias ? dummy : nullptr, const_cast<float*>(dummy),
+               has_stats ? const_cast<float*>(dummy) : nullptr, M, K, P, nb, rb_group ? dummy : nullptr, rb_group ? rb_group : 1,
+               nullptr, nullptr, pool_group, 0, y_rows ? y_rows : M, (P % 4 == 0) ? 1 : 0};
+    return gemm_x2f_takes(a, pro) ? 1 : 0;
+}
+
 extern "C" int usip_mlp_gemm_x2h_red_f32(const void* planes, const float* X, const float* X2, const float* coef, int pro,
                                          const float* pool_dp, const int32_t* pool_arg, int pool_group, float* Y,
                                          const float* red_y, const float* red_coef, float* red_out, float* red_gsum,

@@ -566,6 +566,13 @@ def mlp_gemm(At: torch.Tensor, X: torch.Tensor, bias=None, want_stats: bool = Fa
                 if bm == 256 and not wide and (_lib.lib().usip_tuning_value(6) & 15) != 1 and K * P * 4 < 2 ** 31:
                     # csrc/gemm_x2d.hip: <pro, stats, K % 16 != 0, stages of operand loads in flight>; persistent, two
                     # workgroups per CU once there are more tiles than that
+                    if red is None and _lib.lib().usip_mlp_gemm_x2f_used(
+                            M, K, P, nb, int(pro), e, 1 if bias is not None else 0, int(rb_group) if rowbias is not None else 0,
+                            int(pool_group), int(y_rows)):
+                        # round 6, csrc/gemm_x2f.hip: <pro, stats, DIRECT>; one persistent workgroup per CU
+                        tiles_ = nb * (P // 256) * (M // 256)
+                        return "gemm_x2f_kernel<%d, %d, %s> |wg=%d" % (pro, e, "true" if pro >= 2 else "false",
+                                                                       tiles_ if (tiles_ <= 256 or tiles_ % 8) else 256)
                     tail = K % 16 != 0
                     depth = 2 if (not tail and (K // 16) % 2 == 0 and (_lib.lib().usip_tuning_value(6) & 15) != 2) else 1
                     tiles_ = nb * ((P + 127) // 128) * ((M + 255) // 256)
@@ -737,11 +744,36 @@ def _keep(ws):
     return ws
 
 
-def wgrad_defer(on: bool):
-    """Enter (True) or leave (False) the deferred mode; leaving drops whatever is recorded and not flushed."""
+def wgrad_defer(on: bool, device=None):
+    """Enter (True) or leave (False) the deferred mode; leaving drops whatever is recorded and not flushed.
+    device: record only what is launched on that device's CURRENT stream (the step's); anything another thread, device or
+    stream launches meanwhile runs its reduction at once (the library's job list is process-global)."""
     global _DEFER_KEEP
-    _lib.check(_lib.lib().usip_wgrad_defer(1 if on else 0), "usip_wgrad_defer")
+    if on and device is not None:
+        dev = torch.device(device)
+        _lib.check(_lib.lib().usip_wgrad_defer_on(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "usip_wgrad_defer_on")
+    else:
+        _lib.check(_lib.lib().usip_wgrad_defer(1 if on else 0), "usip_wgrad_defer")
     _DEFER_KEEP = [] if on else None
+
+
+class _reduce_now:
+    """`with _reduce_now(dest_is_private):` -- a weight gradient whose destination is NOT handed in by the caller (no view of
+    the step's gradient bucket: a frozen sibling parameter switched the layer's sink off, functional._sink) goes back to
+    autograd, whose AccumulateGrad reads it before any flush: its fixed-order sum must be launched at once."""
+
+    def __init__(self, private: bool):
+        self.on = bool(private) and _DEFER_KEEP is not None
+
+    def __enter__(self):
+        if self.on:
+            self.was = int(_lib.lib().usip_wgrad_defer_hold(1))
+
+    def __exit__(self, *exc):
+        if self.on:
+            _lib.lib().usip_wgrad_defer_hold(self.was)
+        return False
 
 
 def wgrad_flush(device) -> int:
@@ -819,9 +851,9 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
                                                     "true" if P % 4 == 0 else "false", planes,
                                                     _lib.lib().usip_mlp_wgrad_blocks(M, N, P, nb))
 
-    with torch.cuda.device(dev), prof.kernel("shared_mlp_wgrad %dx%d" % (M, N),
-                                             4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
-                                             rocprof_key=_key):
+    with torch.cuda.device(dev), _reduce_now(out is None), prof.kernel(
+            "shared_mlp_wgrad %dx%d" % (M, N), 4.0 * nb * P * (M * (2 if pro == 2 else 1) + N), 2.0 * M * N * nb * P,
+            rocprof_key=_key):
         _lib.check(getattr(_lib.lib(), fn_name)(_opt(G), _opt(G2), _opt(coef4), int(pro), _ptr(X), _opt(xcoef),
                                                 _opt(pool_dp), _opt(pool_arg), int(pool_group), _ptr(ws), _ptr(dW),
                                                 int(ldw), int(coloff), M, N, P, nb, _stream(X)), fn_name)
@@ -879,7 +911,7 @@ def mlp_narrow_backward(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, 
             raise RuntimeError("mlp_narrow_backward: want_red needs the producing layer's [4, Cin] coefficients")
         blocks = int(_lib.lib().usip_mlp_narrow_backward_blocks(Cout, P, nb))
         red = torch.empty(2 * blocks * Cin + blocks, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), prof.kernel("shared_mlp_narrow_bwd %dx%d" % (Cout, Cin),
+    with torch.cuda.device(dev), _reduce_now(dw_out is None), prof.kernel("shared_mlp_narrow_bwd %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * (2 * Cout + 2 * Cin), 4.0 * Cout * Cin * nb * P,
                                              rocprof_key="narrow_bwd_kernel<%d, %s, %s> |wg=%d" % (
                                                  Cout, "true" if xcoef is not None else "false",
@@ -948,7 +980,7 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     else:
         _need(dz, "dz", torch.float32)
     pg = pool is not None and group % 32 == 0
-    with torch.cuda.device(dev), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
+    with torch.cuda.device(dev), _reduce_now(dw_out is None), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin),
                                              4.0 * Cout * Cin * nb * P,
                                              rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s, %s, %s> |wg=%d" % (

@@ -253,7 +253,7 @@ class _GraphedStep:
             # partial tiles are recorded during backward and issued together behind it (USIP_DEFER_WGRAD=0: one by one)
             defer = self.device.type == "cuda" and os.environ.get("USIP_DEFER_WGRAD", "1") not in ("0", "off")
             if defer:
-                ops.wgrad_defer(True)
+                ops.wgrad_defer(True, self.device)
             try:
                 loss.backward()
                 if defer:
