@@ -10,9 +10,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# hand-built BatchNorm coefficients of the kernel tests carry no recorded sample count: take them as the launch's own
-# (the library's default is strict -- usip_amd/ops.py::bound_covers; the whole-step test switches this off again)
-os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")
+# The library's rule for BatchNorm bounds is STRICT (usip_amd/ops.py::bound_covers): a coefficient tensor without a recorded
+# sample count covers nothing.  Only the kernel-level tests below hand-build coefficients (no bn_finalize, no count) and take
+# them as the launch's own; every other test -- the module tests, the detector and descriptor steps, data parallel, the drop-in
+# surface -- runs under the shipped rule and must not meet an unknown count (round 5 set the opt-in for the
+# whole session, so only one whole-step test ran under the product's rule).
+_HAND_BUILT_COEFFICIENTS = ("test_f32x2_mode_gpu", "test_f32x3_mode_gpu", "test_shared_mlp_gpu", "test_bf16_mode_gpu")
+os.environ.pop("USIP_ASSUME_LAUNCH_SAMPLES", None)
 
 
 def pytest_configure(config):
@@ -31,6 +35,22 @@ def pytest_sessionstart(session):
         native.build()                                   # no-op when oracle/libusip_oracle.so is up to date
     except Exception as err:                             # the tests that need the artefact will say so
         print("conftest: could not build prerequisites: %s" % err, file=sys.stderr)
+
+
+@pytest.fixture(autouse=True)
+def _launch_samples_rule(request, monkeypatch):
+    mod = request.module.__name__.split(".")[-1]
+    if mod in _HAND_BUILT_COEFFICIENTS:
+        monkeypatch.setenv("USIP_ASSUME_LAUNCH_SAMPLES", "1")
+        yield
+        return
+    monkeypatch.delenv("USIP_ASSUME_LAUNCH_SAMPLES", raising=False)
+    ops = sys.modules.get("usip_amd.ops")
+    before = ops.UNKNOWN_SAMPLE_LOOKUPS if ops is not None else 0
+    yield
+    ops = sys.modules.get("usip_amd.ops")
+    if ops is not None:
+        assert ops.UNKNOWN_SAMPLE_LOOKUPS == before, "a BatchNorm bound was asked for coefficients with no recorded sample count"
 
 
 def load_golden(name):
@@ -53,6 +73,18 @@ def assert_close(actual, expected, rel=1e-5, name=""):
     err = float(np.abs(actual - expected).max()) / scale if expected.size else 0.0
     assert err <= rel, "%s: max err / scale = %.3e > %.1e" % (name, err, rel)
     return err
+
+
+def rel_by_channel(actual, expected, axis):
+    """Error of every slice along `axis` against THAT slice's own maximum (assert_close's bar is the
+    tensor's scale; for keypoints [B,3,M] of a slab cloud that lets the y row, ~N(0,1), sit 50x further from the oracle than
+    x and z, ~+-50).  -> (worst figure, per-slice array)."""
+    a = np.moveaxis(np.asarray(actual, dtype=np.float64), axis, 0)
+    e = np.moveaxis(np.asarray(expected, dtype=np.float64), axis, 0)
+    assert a.shape == e.shape
+    a, e = a.reshape(a.shape[0], -1), e.reshape(e.shape[0], -1)
+    per = np.abs(a - e).max(axis=1) / np.maximum(np.abs(e).max(axis=1), 1e-30)
+    return float(per.max()), per
 
 
 @pytest.fixture(params=["f32", "f32x3", "f32x2"])

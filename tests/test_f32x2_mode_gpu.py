@@ -724,7 +724,8 @@ def test_one_wave_per_simd_gemm_equals_the_direct_one_bit_for_bit(shape, x2_forc
     dwordx2, next tile requested before the epilogue; the default wherever it fits) computes what csrc/gemm_x2d.hip computes
     (knob x2_direct = 12), in the same order per accumulator: forward outputs bit-identical with bias, with and without a row
     bias and statistics (statistics equal per 128-position slot up to fp32 summation order); data gradients (pro 2, and
-    pro 3 = the pooled form) bit-identical; persistent workgroups with 1..4 tiles each; repeated launches bit-stable."""
+    pro 3 = the pooled form) bit-identical; persistent workgroups with 1..4 tiles each, whose software pipeline
+    runs across the tile boundary; repeated launches bit-stable."""
     from usip_amd import _lib, ops
     nb, K, M, P = shape
     lib = _lib.lib()

@@ -128,13 +128,19 @@ def test_lds_dma_statements_save_and_restore_m0(src, tmp_path):
     ins = [i for i in ins if i and not i.startswith(".") and not i.startswith("#")]
     dma = [n for n, i in enumerate(ins) if i.startswith("buffer_load_dwordx4") and i.endswith(" lds")]
     assert len(dma) >= 8, (src, len(dma))
-    for n in dma:
+    # a statement holds one DMA instruction or several back to back (gemm_x2f.hip: two, the second with an immediate offset)
+    runs = [[n] for n in dma if n - 1 not in dma]
+    for r in runs:
+        while r[-1] + 1 in dma:
+            r.append(r[-1] + 1)
+    for r in runs:
+        n, e = r[0], r[-1]
         save = re.match(r"s_mov_b32 (s\d+|vcc_lo|vcc_hi|ttmp\d+), m0$", ins[n - 3])
-        assert save, (src, ins[n - 4:n + 2])
-        assert re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", ins[n - 2]) and ins[n - 1] == "s_nop 0", (src, ins[n - 4:n + 2])
-        assert ins[n - 2] != "s_mov_b32 m0, %s" % save.group(1), (src, ins[n - 4:n + 2])      # (early clobber: another register)
-        assert ins[n + 1] == "s_mov_b32 m0, %s" % save.group(1), (src, ins[n - 4:n + 2])
-    assert sum(bool(re.search(r"\bm0\b", i)) for i in ins) == 3 * len(dma), src    # nobody else reads or writes m0
+        assert save, (src, ins[n - 4:e + 2])
+        assert re.match(r"s_mov_b32 m0, (s\d+|vcc_lo|vcc_hi)$", ins[n - 2]) and ins[n - 1] == "s_nop 0", (src, ins[n - 4:e + 2])
+        assert ins[n - 2] != "s_mov_b32 m0, %s" % save.group(1), (src, ins[n - 4:e + 2])      # (early clobber: another register)
+        assert ins[e + 1] == "s_mov_b32 m0, %s" % save.group(1), (src, ins[n - 4:e + 2])
+    assert sum(bool(re.search(r"\bm0\b", i)) for i in ins) == 3 * len(runs), src    # nobody else reads or writes m0
 
 
 def test_one_wave_per_simd_gemm_registers_and_counted_waits(tmp_path):
@@ -148,17 +154,25 @@ def test_one_wave_per_simd_gemm_registers_and_counted_waits(tmp_path):
     for name, ins in _functions(asm, "_ZN12_GLOBAL__N_115gemm_x2f_kernel"):
         pro = int(re.search(r"kernelILi(\d)E", name).group(1))
         nx = {1: 8, 2: 16, 3: 24}[pro]
-        loops = [b for b in _blocks(ins) if sum("v_mfma" in i for i in b) == 96 and any(i.startswith("s_cbranch") for i in b)]
-        assert len(loops) == 1, (name, len(loops))
-        body = loops[0]
-        assert not any("scratch_" in i for i in body), name
-        assert sum(i.startswith("buffer_load_dwordx4") and i.endswith(" lds") for i in body) == 8, name
-        assert sum(i.startswith("buffer_load_dword") and not i.endswith(" lds") for i in body) == 2 * nx, name
-        bars = [n for n, i in enumerate(body) if i.startswith("s_barrier")]
-        assert len(bars) == 2, name
-        for n in bars:
-            w = [i for i in body[max(0, n - 3):n] if i.startswith("s_waitcnt") and "vmcnt" in i]
-            assert w and re.search(r"vmcnt\((\d+)\)", w[-1]).group(1) == str(2 * nx + 4), (name, body[n - 3:n + 1])
+        # two stages per trip; the first trip of a tile is peeled (its stage 0 starts every accumulator with C = 0); hipcc may
+        # cut a trip into two blocks at a stage boundary (scalar selects of the next tile's offsets compiled to branches)
+        mblocks = [b for b in _blocks(ins) if any("v_mfma" in i for i in b)]
+        peeled = [i for b in mblocks if any(re.search(r"v_mfma.*\], 0$", i) for i in b) for i in b]
+        loop = [i for b in mblocks if not any(re.search(r"v_mfma.*\], 0$", i) for i in b) for i in b]
+        assert sum(bool(re.search(r"v_mfma.*\], 0$", i)) for i in peeled) == 16, name
+        for what, body in (("peeled", peeled), ("loop", loop)):
+            assert sum("v_mfma" in i for i in body) == 96, (name, what)
+            # (tile-level state the epilogue displaced may be reloaded once per tile in the peeled trip; the LOOP touches no scratch)
+            assert not any("scratch_store" in i for i in body), (name, what)
+            assert what == "peeled" or not any("scratch_" in i for i in body), name
+            assert sum(i.startswith("buffer_load_dwordx4") and i.endswith(" lds") for i in body) == 8, (name, what)
+            assert sum(i.startswith("buffer_load_dword") and not i.endswith(" lds") for i in body) == 2 * nx, (name, what)
+            bars = [n for n, i in enumerate(body) if i.startswith("s_barrier")]
+            assert len(bars) == 2, (name, what)
+            for n in bars:
+                w = [i for i in body[max(0, n - 3):n] if i.startswith("s_waitcnt") and "vmcnt" in i]
+                assert w and re.search(r"vmcnt\((\d+)\)", w[-1]).group(1) == str(2 * nx + 4), (name, body[n - 3:n + 1])
+        assert any(i.startswith("s_cbranch") for i in loop), name
         seen += 1
     for m in re.finditer(r"\.amdhsa_kernel (\S*gemm_x2f_kernel\S*)", asm):
         seg = asm[m.start():m.start() + 4000]

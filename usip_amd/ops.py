@@ -667,19 +667,26 @@ def bn_finalize(stats, count, gamma, beta, eps, momentum, running_mean, running_
     return mean, invstd, coef
 
 
-# data_ptr of a [4,C] forward-coefficient tensor -> the number of samples its statistics were taken over.  Keyed by
-# ADDRESS, not by a Python attribute: the tensor a backward pass gets back from ctx.saved_tensors, a detach() or a row
-# view is another Python object over the same memory, and an attribute would be gone.  bn_finalize
-# re-declares on every call, so an address that the allocator hands out again carries its newest producer's count.
-_SAMPLES = {}
+# data_ptr of a [4,C] forward-coefficient tensor -> (the number of samples its statistics were taken over, its element
+# count).  Keyed by ADDRESS, not by a Python attribute: the tensor a backward pass gets back from ctx.saved_tensors, a detach()
+# or a row view is another Python object over the same memory, and an attribute would be gone.  bn_finalize
+# re-declares on every call, so an address that the allocator hands out again carries its newest producer's count; a
+# hand-built tensor of ANOTHER size that lands on a recycled address does not inherit the old count (the element count is
+# checked: ADVICE r5), and the table sheds its OLDEST entries (a step declares a few dozen: nothing of a running step's
+# forward is dropped before its backward) instead of being cleared.
+import collections
+_SAMPLES = collections.OrderedDict()
+_SAMPLES_MAX = 8192
 UNKNOWN_SAMPLE_LOOKUPS = 0          # bound_covers calls that found no recorded count (a whole step must leave this at 0)
 
 
 def declare_samples(coef, count: int):
     """Record that the batch statistics in `coef` were taken over `count` samples per channel."""
-    if len(_SAMPLES) > 8192:
-        _SAMPLES.clear()            # addresses of long-dead tensors; live ones are re-declared by their next bn_finalize
-    _SAMPLES[coef.data_ptr()] = int(count)
+    key = coef.data_ptr()
+    _SAMPLES.pop(key, None)
+    _SAMPLES[key] = (int(count), int(coef.numel()))           # (re-)inserted at the young end
+    while len(_SAMPLES) > _SAMPLES_MAX:
+        _SAMPLES.popitem(last=False)
 
 
 def bound_covers(coef, samples: int) -> bool:
@@ -688,13 +695,16 @@ def bound_covers(coef, samples: int) -> bool:
     assumes n' = its own sample count under-estimates the bound when n' < n (a slice of the tensor, coefficients of
     another batch) and could overflow the fp16 planes.  Coefficients WITHOUT a recorded count do not cover anything
     (the launch takes the bound-free f32x3 path); hand-built coefficients in tests and tools either call
-    declare_samples or set USIP_ASSUME_LAUNCH_SAMPLES=1 (tests/conftest.py), which takes them as the launch's own."""
+    declare_samples or set USIP_ASSUME_LAUNCH_SAMPLES=1 (the `assume_launch_samples` fixture of tests/conftest.py), which takes
+    them as the launch's own."""
     global UNKNOWN_SAMPLE_LOOKUPS
-    n = _SAMPLES.get(coef.data_ptr())
-    if n is None:
+    rec = _SAMPLES.get(coef.data_ptr())
+    if rec is not None and rec[1] != int(coef.numel()) and coef._base is None:
+        rec = None                  # another tensor on a recycled address (a view of the declared one keeps its base's count)
+    if rec is None:
         UNKNOWN_SAMPLE_LOOKUPS += 1
         return os.environ.get("USIP_ASSUME_LAUNCH_SAMPLES") == "1"
-    return n <= samples
+    return rec[0] <= samples
 
 
 def bn_apply(Y, coef, relu: bool):

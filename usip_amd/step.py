@@ -279,6 +279,7 @@ class _GraphedStep:
         eager=True forces plain launches for this call (bench.py does so on the steps it instruments with
         HIP events, which a graph replay cannot carry)."""
         self._replay_this_call = True
+        self._prepare_group = group                           # the ranks this step's batch is sharded over (random point dropout)
         batch = self._prepare(batch)
         if self.use_graph and not eager and self._replay_this_call:
             return self._step_graph(batch, epoch, group)
@@ -547,16 +548,22 @@ class DetectorStep(_GraphedStep):
             n_in = int(getattr(self.opt, "input_pc_num", batch["src_pc"].shape[2]))
             # ONE draw per step for the whole batch, as in the reference (a single process behind nn.DataParallel):
             # rank 0 draws, every rank trains on the same keep ratio and index set -- equal cloud sizes per step
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-            if not multi or dist.get_rank() == 0:
+            # (the group handed to step(), not the world: a sub-group's ranks must not wait for ranks that never call; a solo
+            # step object -- bench.py's one-rank probe inside a multi-rank job -- draws for itself: ADVICE r5)
+            group = getattr(self, "_prepare_group", None)
+            multi = (not getattr(self, "solo", False) and dist.is_available() and dist.is_initialized()
+                     and dist.get_world_size(group) > 1)
+            first = multi and dist.get_rank(group) == 0
+            if not multi or first:
                 keep = round(random.uniform(limit, 1.0) * n_in)
                 idx = torch.from_numpy(np.random.choice(n_in, keep, replace=False)).to(self.device)
             if multi:
-                count = torch.tensor([keep if dist.get_rank() == 0 else 0], dtype=torch.int64, device=self.device)
-                dist.broadcast(count, src=0)
-                if dist.get_rank() != 0:
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                count = torch.tensor([keep if first else 0], dtype=torch.int64, device=self.device)
+                dist.broadcast(count, src=src, group=group)
+                if not first:
                     idx = torch.empty(int(count.item()), dtype=torch.int64, device=self.device)
-                dist.broadcast(idx, src=0)
+                dist.broadcast(idx, src=src, group=group)
             batch = dict(batch, keep_idx=idx)
         if "keep_idx" in batch:
             if self.use_graph and not getattr(self, "_warned_dropout", False):
