@@ -103,29 +103,49 @@ __device__ __forceinline__ void epilogue_x2f(const GemmArgs& a, f32x16 (&acc)[8]
     // position, odd position) on the packed fp32 VALU -- each half rounded exactly like its scalar twin; the two halves are two
     // running sums, added at the end.
     auto produce = [&](int i) {
+#if defined(USIP_X2F_EXP) && USIP_X2F_EXP == 2                 // measurement build: transposed reads + stores only
+        return;
+#endif
         const float bv = biasp ? biasp[i * 32] : 0.0f;
         float rb[4] = {0.f, 0.f, 0.f, 0.f};
         if (RB) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) rb[g] = rbp[(long long)i * 32 * ngrp + grp[g]];
         }
-        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+        // four independent running sums (one per run of positions): a lone wave has nobody to hide a dependent chain behind
+        f32x2 s2g[4], q2g[4];
         float* w = trw + (i & 1) * (32 * FTRS);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x2 u[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
+#if defined(USIP_X2F_EXP) && USIP_X2F_EXP == 3                 // measurement build: scalar fp32 instead of the packed forms
+#pragma unroll
+                for (int bk = 0; bk < 2; ++bk) {
+                    float t = __builtin_fmaf(f_aread(acc[i][bk], 4 * g + e), out_scale, bv);
+                    if (RB) t += rb[g];
+                    u[e][bk] = t;
+                }
+                if (EPI == EPI_STATS) {
+                    s2g[g] = (e == 0) ? u[e] : s2g[g] + u[e];
+                    q2g[g] = (e == 0) ? u[e] * u[e] : __builtin_elementwise_fma(u[e], u[e], q2g[g]);
+                }
+                continue;
+#endif
                 const f32x2 av = {f_aread(acc[i][0], 4 * g + e), f_aread(acc[i][1], 4 * g + e)};
                 u[e] = __builtin_elementwise_fma(av, os2, (f32x2){bv, bv});               // out_scale = 2^n: exact
                 if (RB) u[e] = u[e] + (f32x2){rb[g], rb[g]};
-                if (EPI == EPI_STATS) { s2 = s2 + u[e]; q2 = __builtin_elementwise_fma(u[e], u[e], q2); }
+                if (EPI == EPI_STATS) {
+                    s2g[g] = (e == 0) ? u[e] : s2g[g] + u[e];
+                    q2g[g] = (e == 0) ? u[e] * u[e] : __builtin_elementwise_fma(u[e], u[e], q2g[g]);
+                }
             }
             *reinterpret_cast<float4*>(w + 16 * g) = make_float4(u[0][0], u[0][1], u[1][0], u[1][1]);
             *reinterpret_cast<float4*>(w + 16 * g + 4) = make_float4(u[2][0], u[2][1], u[3][0], u[3][1]);
-            __builtin_amdgcn_sched_barrier(0);                 // one run of positions at a time (register pressure)
         }
         if (EPI != EPI_NONE) {
+            const f32x2 s2 = (s2g[0] + s2g[1]) + (s2g[2] + s2g[3]), q2 = (q2g[0] + q2g[1]) + (q2g[2] + q2g[3]);
             float s = s2[0] + s2[1], q = q2[0] + q2[1];
             s += __shfl_xor(s, 32);
             q += __shfl_xor(q, 32);
@@ -151,7 +171,11 @@ __device__ __forceinline__ void epilogue_x2f(const GemmArgs& a, f32x16 (&acc)[8]
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const u32x4 d = {__float_as_uint(w[k].x), __float_as_uint(w[k].y), __float_as_uint(w[k].z), __float_as_uint(w[k].w)};
+#if defined(USIP_X2F_EXP) && USIP_X2F_EXP == 1                 // measurement build: the epilogue without its stores
+            asm volatile("" ::"v"(d));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 4 * k) * a.P * 4, 0);
+#endif
         }
         // buffer_store_dwordx4 with an SGPR soffset reads its data registers late (gemm_x2d.hip): eight wait states
         // behind the last store before anything may overwrite them
