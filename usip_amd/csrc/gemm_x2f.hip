@@ -77,10 +77,40 @@ __device__ __forceinline__ float f_aread(const f32x16& t, int r)
 // values (block 0, r), (block 1, r) for e = 0..3 are EIGHT consecutive positions 16 g + 8 half + 0..7.  They go to the wave's
 // transposition area (row = channel, 64 positions + 4 pad), and come back in the store role: lane = (rr = l >> 4, cc = l & 15)
 // reads 16 B of row rr + 4 k -- a buffer_store_dwordx4 writes 4 rows x 256 B.
+// (Measured and NOT kept, profiles/r06t_deferred_pieces_ab.txt: the last two channel tiles left in the wave's LDS buffers and
+// stored from inside the NEXT tile's K loop, one 1-KB piece per stage -- the epilogue drops 17 -> 14.5 k cycles, the loop gains
+// 1.5 k (40 cycles per stage that carries a store) and the workgroup's last tile has to flush 16 pieces behind its epilogue:
+// 512 x 512 202 against 210 us, 256 x 256 72 against 67.)
+// The tile's BatchNorm partials leave LDS one tile LATE: four scattered 4-B stores per thread at the end of an epilogue are
+// the youngest memory operations when the next tile's first counted wait comes (1-2 k cycles of exposed store latency per
+// tile, profiles/r06j_x2f_tile_trace_512.txt: first trip 3.4 k cycles after nothing, 5.1 k after an epilogue).  The sums of
+// tile t stay in `red` through tile t + 1's K loop and are stored at the top of ITS epilogue (or behind the last tile).
+__device__ __forceinline__ void stats_flush_x2f(const GemmArgs& a, const float* scratch, int m0, int tn128, int tpc128)
+{
+    const float* red = scratch + 4 * 2 * 32 * FTRS;
+    const int tid = threadIdx.x;
+    // the caller allocated one statistics slot per 128 positions (usip_mlp_gemm_tiles): waves 0-1 / 2-3 fill the two slots
+    const long long ntn = (long long)a.nb * tpc128;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const float s = red[(2 * hf) * FBM + tid] + red[(2 * hf + 1) * FBM + tid];
+        const float q = red[4 * FBM + (2 * hf) * FBM + tid] + red[4 * FBM + (2 * hf + 1) * FBM + tid];
+        a.stats[(long long)(m0 + tid) * ntn + tn128 + hf] = s;
+        a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn128 + hf] = q;
+    }
+}
+
 template <int EPI, bool RB>
 __device__ __forceinline__ void epilogue_x2f(const GemmArgs& a, f32x16 (&acc)[8][2], float out_scale, float* scratch,
-                                             int b, int m0, int p0, int tn128, int tpc128)
+                                             int b, int m0, int p0, int prev_m0, int prev_tn128, int tpc128)
 {
+    if (EPI != EPI_NONE && prev_tn128 >= 0) {
+        // the previous tile's sums (every wave wrote its part a whole K loop ago); nobody may overwrite `red` before all have read
+        stats_flush_x2f(a, scratch, prev_m0, prev_tn128, tpc128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* tr = scratch + wave * (2 * 32 * FTRS);              // two transposition buffers per wave
@@ -181,22 +211,6 @@ __device__ __forceinline__ void epilogue_x2f(const GemmArgs& a, f32x16 (&acc)[8]
         // behind the last store before anything may overwrite them
         asm volatile("s_nop 7" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-    }
-    if (EPI != EPI_NONE) {
-        // LDS-only exchange: a raw barrier (__syncthreads() would also wait for the tile's stores and for the next tile's
-        // requests, which are in flight by design); the next write of `red` is a whole K loop (and its barriers) away
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        // the caller allocated one statistics slot per 128 positions (usip_mlp_gemm_tiles): waves 0-1 / 2-3 fill the two slots
-        const long long ntn = (long long)a.nb * tpc128;
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            const float s = red[(2 * hf) * FBM + tid] + red[(2 * hf + 1) * FBM + tid];
-            const float q = red[4 * FBM + (2 * hf) * FBM + tid] + red[4 * FBM + (2 * hf + 1) * FBM + tid];
-            a.stats[(long long)(m0 + tid) * ntn + tn128 + hf] = s;
-            a.stats[ntn * a.M + (long long)(m0 + tid) * ntn + tn128 + hf] = q;
-        }
     }
 }
 
@@ -554,6 +568,7 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_s_barrier();
         read_frag(0, 0, 0, FA); read_frag(0, 0, 1, FA);
     }
+    int prev_m0 = 0, prev_tn128 = -1;                          // the tile whose BatchNorm partials are still in LDS
     for (;;) {
         const int vn = v + (int)gridDim.x;
         const bool more = vn < total;
@@ -590,8 +605,10 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __builtin_amdgcn_sched_barrier(0);
         X2F_TP(trp, tix * 8 + 5)                               // 5: accumulators readable
         if constexpr (DIRECT) epilogue_x2f_direct(a, acc, out_scale, T.b, T.m0, T.p0);
-        else if (a.rowbias) epilogue_x2f<EPI, true>(a, acc, out_scale, scr, T.b, T.m0, T.p0, T.tn128, tpc * 2);
-        else epilogue_x2f<EPI, false>(a, acc, out_scale, scr, T.b, T.m0, T.p0, T.tn128, tpc * 2);
+        else if (a.rowbias) epilogue_x2f<EPI, true>(a, acc, out_scale, scr, T.b, T.m0, T.p0, prev_m0, prev_tn128, tpc * 2);
+        else epilogue_x2f<EPI, false>(a, acc, out_scale, scr, T.b, T.m0, T.p0, prev_m0, prev_tn128, tpc * 2);
+        prev_m0 = T.m0;
+        prev_tn128 = T.tn128;
         X2F_TP(trp, tix * 8 + 6)                               // 6: epilogue issued
 #ifdef USIP_X2F_TRACE
         ++tix;
@@ -599,6 +616,12 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (!more) break;
         v = vn;
         T = Tn;
+    }
+    if constexpr (!DIRECT && EPI != EPI_NONE) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the last tile's sums: every wave's part is in LDS
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stats_flush_x2f(a, scr, prev_m0, prev_tn128, tpc * 2);
     }
     // the last tile's repeats of its first stages: no LDS-DMA may be in flight when the workgroup's LDS is handed on
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
