@@ -546,6 +546,52 @@ def gen_detectors(networks, losses, som):
          **{"idx/" + k: v for k, v in rec.items()}, **out)
 
 
+def gen_detectors_options(networks, losses, som):
+    """Round 6: the non-default values of --activation / --normalization (models/layers.py:181-193, :262-272; every
+    options file of the reference defaults to relu / batch): RPN_Detector_Ball with ELU + instance normalisation and
+    RPN_Detector with Swish + batch normalisation, through the same optimize() step."""
+    opt = Opt(surface_normal_len=4, node_knn_k_1=8, loss_sigma_lower_bound=1e-3, activation="elu",
+              normalization="instance")
+    batch = synth.make_pair_batch(seed=6161, pairs=1, n=1024, m=32, cs=4, kind="slab:14")
+    net = networks.RPN_Detector_Ball(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=0.01)
+    restore()
+    rec = {k: v for k, v in rec.items() if not k.startswith("relu_")}
+    save("detector_ball_elu_instance.npz", cfg_model="ball", cfg_knn=np.int32(8), cfg_sigma_lb=np.float32(1e-3),
+         cfg_alpha=np.float32(0.01), cfg_activation="elu", cfg_normalization="instance",
+         **{"in/" + k: v for k, v in batch.items()}, **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+    opt = Opt(surface_normal_len=3, node_knn_k_1=8, loss_sigma_lower_bound=1e-4, activation="swish",
+              normalization="batch")
+    batch = synth.make_pair_batch(seed=6262, pairs=1, n=1024, m=32, cs=3, kind="sphere")
+    net = networks.RPN_Detector(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=1.0)
+    restore()
+    rec = {k: v for k, v in rec.items() if not k.startswith("relu_")}
+    save("detector_som_swish.npz", cfg_model="som", cfg_knn=np.int32(8), cfg_sigma_lb=np.float32(1e-4),
+         cfg_alpha=np.float32(1.0), cfg_activation="swish", cfg_normalization="batch",
+         **{"in/" + k: v for k, v in batch.items()}, **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+    # --k 2 (util/som.py:49-50, networks.py:85-92): every point goes to its TWO nearest nodes, the cloud is stacked twice.
+    # torch.topk(sorted=False) leaves the order of a point's picks unspecified: idx/min_idx is compared as per-point SETS
+    # and the index_max positions (positions in the stacked cloud) are not stored.
+    opt = Opt(surface_normal_len=3, node_knn_k_1=8, loss_sigma_lower_bound=1e-4, k=2)
+    batch = synth.make_pair_batch(seed=6363, pairs=1, n=1024, m=32, cs=3, kind="sphere")
+    net = networks.RPN_Detector(opt)
+    load_filled(net)
+    rec, restore = capture_indices(networks, som)
+    out = run_step(net, losses, opt, batch, alpha=1.0)
+    restore()
+    rec = {k: v for k, v in rec.items() if k in ("min_idx", "knn_I")}
+    save("detector_som_k2.npz", cfg_model="som", cfg_knn=np.int32(8), cfg_sigma_lb=np.float32(1e-4),
+         cfg_alpha=np.float32(1.0), cfg_k=np.int32(2),
+         **{"in/" + k: v for k, v in batch.items()}, **{"idx/" + k: v for k, v in rec.items()}, **out)
+
+
 def gen_descriptor(networks, losses):
     """DescriptorLiteOld + DescPairScanLoss as ModelDescriptor.optimize drives them
     (models/keypoint_descriptor.py:126-159), with the random point permutation of
@@ -669,6 +715,9 @@ if __name__ == "__main__":
     if "--only-detectors" in sys.argv:
         gen_detectors(networks, losses, som)
         sys.exit(0)
+    if "--only-detectors-options" in sys.argv:
+        gen_detectors_options(networks, losses, som)
+        sys.exit(0)
     if "--only-detectors-r3" in sys.argv:
         gen_detectors_r3(networks, losses, som)
         sys.exit(0)
@@ -687,5 +736,6 @@ if __name__ == "__main__":
     gen_point_to_plane(losses)
     gen_detectors(networks, losses, som)
     gen_detectors_r3(networks, losses, som)
+    gen_detectors_options(networks, losses, som)
     gen_descriptor(networks, losses)
     gen_pre_post(networks)

@@ -1,6 +1,7 @@
 """Streaming narrow forward kernel vs the generic tile kernel (same launch through ops.mlp_gemm), ring of inputs
 larger than the Infinity Cache."""
 import os
+import sys
 os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers), sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

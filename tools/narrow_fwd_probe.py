@@ -1,5 +1,6 @@
 """The narrow forward GEMMs of the ball front end alone (64 -> 64 and 64 -> 128 at 524288 positions), for counters."""
 import os
+import sys
 os.environ.setdefault("USIP_ASSUME_LAUNCH_SAMPLES", "1")   # hand-built BatchNorm coefficients: the launch's own samples (usip_amd/ops.py::bound_covers), sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

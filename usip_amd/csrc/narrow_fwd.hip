@@ -221,7 +221,8 @@ extern "C" int usip_mlp_narrow_forward_blocks(int M, int K, int P, int nb)
 {
     if (K != NF_K || (M != 64 && M != 128) || P < 4 || P % 4 != 0 || nb < 1) return 0;
     const long long total = (long long)nb * ((P + NF_BN - 1) / NF_BN);
-    const int G = (M == 64) ? 768 : 512;                     // three / two workgroups per CU
+    int G = (M == 64) ? 768 : 512;                           // three / two workgroups per CU
+    if (usip_tuning_value(USIP_TUNE_R5_FORMS) & 64) G = (M == 64) ? 1024 : 768;   // measurement: one more per CU (round 6)
     if (total < 4 * G) return 0;                             // too few tiles to keep the persistent workgroups busy
     return G;
 }

@@ -553,6 +553,21 @@ class _SharedMLPLayer(torch.autograd.Function):
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
         x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
+        if not ctx.relu:
+            # BatchNorm with no ReLU behind it: only the generic form of a layer built with a non-default activation
+            # (layers._generic_forward).  The GEMM prologues rebuild dY WITH the ReLU decision (mlp_common.h::pro_apply),
+            # so dY = a1*dZ + q1*y + q0 is written out here and the plain gradient GEMMs run on it.
+            C = dz.shape[1]
+            dy = torch.addcmul(torch.addcmul(coef4[3].view(1, C, 1), y, coef4[2].view(1, C, 1)),
+                               dz, coef4[0].view(1, C, 1))
+            dx = _dgrad(x, w2.contiguous(), dy, pro=0) if need_x else None
+            dw = None
+            if need_w:
+                dw = ops.mlp_wgrad(dy, x, xcoef=xcoef, out=sink[0].view(w2.shape) if sink else None)
+            db = torch.zeros_like(gamma) if (ctx.needs_input_grad[3] and not sink) else None
+            if sink:
+                dw = db = dgamma = dbeta = None
+            return (dx, None, dw, db, dgamma, dbeta) + tail
         x2 = (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0
               and ops.layer_backward_x2_supported(x.shape[1], w2.shape[0], x.shape[2], (dz, y, x), coef4, xcoef))
         if x2 or (FUSED_NARROW_BWD and need_x and need_w and ctx.relu and ctx.nograd_prefix == 0

@@ -3,9 +3,13 @@ state_dict keys as the reference's models/layers.py, for the classes its detecto
 (SURVEY 8 a-5, a-6, a-7, a-13), so released checkpoints load and models/networks.py builds on
 them unchanged.  The arithmetic lives in usip_amd.functional / the HIP library.
 
-Only what the detector path uses is provided: 1x1 kernels, 'batch' or no normalisation,
-'relu' or no activation.  Anything else raises NotImplementedError instead of silently
-taking another code path.
+1x1 kernels only.  The options every train_detector.py of the reference defaults to ('batch' or no normalisation,
+'relu' or no activation) run the fused kernels (lazy BatchNorm + ReLU, layer + max nodes, row-bias GEMMs).  The
+other values models/layers.py accepts -- activation 'elu' | 'swish' | 'leakyrelu' | 'selu', normalization
+'instance' -- run a GENERIC form (round 6): the convolution on the HIP GEMM, BatchNorm through the HIP
+statistics kernels, instance normalisation and the activation as plain device-tensor operations, the
+expand + cat + max sequences literally as the reference writes them -- same results as the reference (fixtures
+detector_ball_elu_instance / detector_som_swish), none of the fusions.  Unknown strings raise NotImplementedError.
 """
 import math
 
@@ -65,12 +69,57 @@ class MyBatchNorm2d(_EpochDecayBatchNorm):
     _dims = (4,)
 
 
+class Swish(nn.Module):
+    """models/layers.py:15-20."""
+
+    def forward(self, x):
+        return 1.78718727865 * (x * torch.sigmoid(x) - 0.20662096414)
+
+
+_ACTIVATIONS = {"relu": nn.ReLU, "elu": lambda: nn.ELU(alpha=1.0), "swish": Swish,
+                "leakyrelu": lambda: nn.LeakyReLU(0.01), "selu": nn.SELU}          # layers.py:181-191, :262-272
+
+
 def _check_supported(activation, normalization):
-    if activation not in (None, "relu"):
-        raise NotImplementedError("usip_amd: activation %r is outside the detector path (relu only)" % activation)
-    if normalization not in (None, "batch"):
-        raise NotImplementedError("usip_amd: normalization %r is outside the detector path (batch only)"
-                                  % normalization)
+    """-> True when the layer takes the GENERIC (unfused) form: any activation but ReLU, or instance normalisation."""
+    if activation is not None and activation not in _ACTIVATIONS:
+        raise NotImplementedError("usip_amd: unknown activation %r" % (activation,))
+    if normalization not in (None, "batch", "instance"):
+        raise NotImplementedError("usip_amd: unknown normalization %r" % (normalization,))
+    return activation not in (None, "relu") or normalization == "instance"
+
+
+def _generic_forward(layer, x, epoch):
+    """conv -> norm -> act of a layer built with non-default options (models/layers.py:208-216, :293-303): the 1x1
+    convolution (and a 'batch' normalisation's statistics) on the HIP kernels, the rest as device-tensor operations."""
+    x = Fh.as_tensor(x)
+    bn = layer.norm if layer.normalization == "batch" else None
+    if bn is not None:
+        bn.decay_momentum(epoch)
+    y = Fh.conv1x1_bn_act(x, layer.conv.weight, layer.conv.bias, bn, False)
+    if layer.normalization == "instance":
+        y = layer.norm(y)
+    if layer.activation is not None:
+        y = layer.act(y)
+    return y
+
+
+def is_generic(layer) -> bool:
+    return bool(getattr(layer, "_generic", False))
+
+
+def pooled_concat_layer(layer, h, pooled, pooled_first: bool, epoch=None, defer: bool = True):
+    """layer(cat(expand(pooled), h) or cat(h, expand(pooled))) -- models/layers.py:433-435, networks.py:706-709: the fused
+    row-bias form for a BatchNorm + ReLU (or plain) layer, the literal expand + cat for a generic one."""
+    if is_generic(layer):
+        ht = Fh.as_tensor(h)
+        e = pooled.unsqueeze(3).expand(-1, -1, -1, ht.shape[3])
+        return layer(torch.cat((e, ht) if pooled_first else (ht, e), dim=1), epoch)
+    bn = getattr(layer, "norm", None)
+    if bn is not None:
+        bn.decay_momentum(epoch)
+    return Fh.conv1x1_bn_act_pooled(h, pooled, layer.conv.weight, layer.conv.bias, bn, layer.activation == "relu",
+                                    pooled_first=pooled_first, defer=defer)
 
 
 def _init_conv(conv, fan_in):
@@ -87,7 +136,7 @@ class MyConv2d(nn.Module):
                  activation=None, normalization=None, momentum=0.1, bn_momentum_decay_step=None,
                  bn_momentum_decay=1):
         super().__init__()
-        _check_supported(activation, normalization)
+        self._generic = _check_supported(activation, normalization)
         ks = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size, kernel_size)
         if tuple(ks) != (1, 1) or stride not in (1, (1, 1)) or padding not in (0, (0, 0)):
             raise NotImplementedError("usip_amd: the shared MLP is a 1x1 convolution (stride 1, no padding)")
@@ -98,13 +147,17 @@ class MyConv2d(nn.Module):
             self.norm = MyBatchNorm2d(out_channels, momentum=momentum, affine=True,
                                       momentum_decay_step=bn_momentum_decay_step,
                                       momentum_decay=bn_momentum_decay)
-        if activation == "relu":
-            self.act = nn.ReLU()
+        elif normalization == "instance":
+            self.norm = nn.InstanceNorm2d(out_channels, momentum=momentum, affine=True)       # layers.py:189-190
+        if activation is not None:
+            self.act = _ACTIVATIONS[activation]()
         _init_conv(self.conv, in_channels)
 
     def forward(self, x, epoch=None, defer=False, nograd_prefix=0):
         """defer=True (internal use by the fused networks): return a functional.LazyAct.
         nograd_prefix: leading input channels that need no gradient (see functional.conv1x1_bn_act)."""
+        if self._generic:
+            return _generic_forward(self, x, epoch)
         bn = getattr(self, "norm", None)
         if bn is not None:
             bn.decay_momentum(epoch)
@@ -119,7 +172,7 @@ class EquivariantLayer(nn.Module):
     def __init__(self, num_in_channels, num_out_channels, activation="relu", normalization=None,
                  momentum=0.1, bn_momentum_decay_step=None, bn_momentum_decay=1):
         super().__init__()
-        _check_supported(activation, normalization)
+        self._generic = _check_supported(activation, normalization)
         self.num_in_channels = num_in_channels
         self.num_out_channels = num_out_channels
         self.activation = activation
@@ -129,11 +182,15 @@ class EquivariantLayer(nn.Module):
             self.norm = MyBatchNorm1d(num_out_channels, momentum=momentum, affine=True,
                                       momentum_decay_step=bn_momentum_decay_step,
                                       momentum_decay=bn_momentum_decay)
-        if activation == "relu":
-            self.act = nn.ReLU()
+        elif normalization == "instance":
+            self.norm = nn.InstanceNorm1d(num_out_channels, momentum=momentum, affine=True)   # layers.py:265-266
+        if activation is not None:
+            self.act = _ACTIVATIONS[activation]()
         _init_conv(self.conv, num_in_channels)
 
     def forward(self, x, epoch=None, defer=False):
+        if self._generic:
+            return _generic_forward(self, x, epoch)
         bn = getattr(self, "norm", None)
         if bn is not None:
             bn.decay_momentum(epoch)
@@ -211,14 +268,11 @@ class GeneralKNNFusionModule(nn.Module):
             h = layer(h, epoch, defer=True, nograd_prefix=3 if n == 0 else 0)
         pooled, h = Fh.group_max_fork(h)                                 # :433 (BN+ReLU+max in one pass)
         first, rest = self.layers_after[0], list(self.layers_after)[1:]
-        bn = getattr(first, "norm", None)
-        if bn is not None:
-            bn.decay_momentum(epoch)
-        y = Fh.conv1x1_bn_act_pooled(h, pooled, first.conv.weight, first.conv.bias, bn,
-                                     first.activation == "relu", pooled_first=True, defer=True)   # :435
+        y = pooled_concat_layer(first, h, pooled, True, epoch)           # :435
         for layer in rest[:-1]:
             y = layer(y, epoch, defer=True)
-        if rest and getattr(rest[-1], "norm", None) is not None and rest[-1].activation == "relu":
+        if rest and isinstance(getattr(rest[-1], "norm", None), _BatchNorm) and rest[-1].activation == "relu" \
+                and not is_generic(rest[-1]):
             last = rest[-1]                                              # last layer + max over K fused
             last.norm.decay_momentum(epoch)
             return Fh.conv1x1_bn_relu_max(y, last.conv.weight, last.conv.bias, last.norm)   # :436-438

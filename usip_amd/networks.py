@@ -12,7 +12,9 @@ import torch.nn as nn
 
 from . import functional as Fh
 from . import ops
-from .layers import EquivariantLayer, GeneralKNNFusionModule, MyConv2d, PointNet
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from .layers import EquivariantLayer, GeneralKNNFusionModule, MyConv2d, PointNet, pooled_concat_layer
 
 
 def _bn_kw(opt):
@@ -59,8 +61,6 @@ class RPN_Detector(_DetectorTail):
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
-        if opt.k != 1:
-            raise NotImplementedError("usip_amd: %s is implemented for opt.k == 1" % type(self).__name__)
         self.C1 = self.C1_WIDTH
         h = self.C1 // 2
         self.first_pointnet = PointNet(3 + opt.surface_normal_len, [h, h, h], activation=opt.activation,
@@ -74,7 +74,17 @@ class RPN_Detector(_DetectorTail):
         B, _, N = x.shape
         M = node.shape[2]
         x = x.contiguous()
-        min_idx32 = ops.som_assign(x, node.contiguous())                  # som.py:31-39
+        k = int(getattr(self.opt, "k", 1))
+        if k == 1:
+            min_idx32 = ops.som_assign(x, node.contiguous())              # som.py:31-39
+        else:
+            # --k > 1 (networks.py:85-92): every point is assigned to its k nearest nodes and the cloud is stacked k times;
+            # from here on that is the k = 1 computation over k*N points with a GIVEN assignment
+            from . import som
+            min_idx32 = som.topk_assign(x, node.contiguous(), k).int().contiguous()
+            x = x.repeat(1, 1, k).contiguous()
+            sn = sn.repeat(1, 1, k)
+            N = k * N
         # the assignment sorted by node, once: cluster sums, and every "sum over a node's points" of the backward
         csr = ops.csr_by_index(min_idx32, M) if (Fh.SEGMENT_BACKWARD and ops.segment_sum_supported(M, N)) else None
         cluster_mean, count, x_dec = ops.som_cluster(x, min_idx32, M, csr=csr)   # networks.py:87-107
@@ -146,10 +156,8 @@ class RPN_Detector_Ball(_DetectorTail):
         # activations stay lazy between the layers: BN+ReLU is applied by the consumer's prologue
         h = self.conv3(self.conv2(self.conv1(g, defer=True), defer=True), defer=True)   # no epoch: networks.py:705
         pooled, h = Fh.group_max_fork(h)                                  # :706
-        h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
-                                     getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
-                                     pooled_first=False, defer=True)      # cat(h, expand(max)) :708-709
-        if getattr(self.conv5, "norm", None) is not None and self.conv5.activation == "relu":
+        h = pooled_concat_layer(self.conv4, h, pooled, False)             # cat(h, expand(max)) :708-709 (no epoch: :709)
+        if isinstance(getattr(self.conv5, "norm", None), _BatchNorm) and self.conv5.activation == "relu":
             second_max = Fh.conv1x1_bn_relu_max(h, self.conv5.conv.weight, self.conv5.conv.bias,
                                                 self.conv5.norm)          # conv5 + max over K fused :709-710
         else:
@@ -210,9 +218,7 @@ class DescriptorLiteOld(nn.Module):
         x_features = ops.group_gather(x_aug.contiguous(), ball_idx32, sub=keypoints)          # :358-370
         h = self.conv3(self.conv2(self.conv1(x_features, defer=True), defer=True), defer=True)   # :373
         pooled, h = Fh.group_max_fork(h)                                                       # :374
-        h = Fh.conv1x1_bn_act_pooled(h, pooled, self.conv4.conv.weight, self.conv4.conv.bias,
-                                     getattr(self.conv4, "norm", None), self.conv4.activation == "relu",
-                                     pooled_first=False, defer=True)                           # :375-377
+        h = pooled_concat_layer(self.conv4, h, pooled, False)                                  # :375-377
         y = self.conv5(h)                                                                      # plain conv
         descriptor = Fh.group_max(y)                                                           # :379
         descriptor = descriptor / (torch.norm(descriptor, dim=1, keepdim=True) + 1e-5)         # :380
