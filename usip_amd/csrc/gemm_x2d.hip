@@ -249,7 +249,7 @@ __device__ __forceinline__ void epilogue_x2d_fast(const GemmArgs& a, f32x16 (&ac
         for (int k = 0; k < 4; ++k) {
             const float4 w = *reinterpret_cast<const float4*>(trr + 8 * k * TRS);
             const u32x4 d = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 8 * k) * a.P * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 8 * k) * a.P * 4, st_aux<ST_X2D>());
             if (RED) {
                 const int row_l = i * 32 + rr + 8 * k;
                 const float4 c4 = *reinterpret_cast<const float4*>(cfr + row_l * 4);
@@ -350,7 +350,7 @@ __device__ __forceinline__ void epilogue_x2d_direct(const GemmArgs& a, f32x16 (&
             for (int e = 0; e < 4; ++e) v[e] = acc[i][0][4 * g + e] * out_scale;          // 2^n: exact
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), rY, voff, (i * 32 + 8 * g + e) * rowb, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[e]), rY, voff, (i * 32 + 8 * g + e) * rowb, st_aux<ST_X2D>());
             // the stores read their data registers late (see epilogue_x2d_fast): nothing may overwrite v[] at once
             asm volatile("s_nop 7" ::: "memory");
         }

@@ -105,7 +105,7 @@ __device__ __forceinline__ void epilogue_x2e(const GemmArgs& a, f32x16 (&acc)[8]
         for (int k = 0; k < 4; ++k) {
             const float4 w = *reinterpret_cast<const float4*>(trr + 8 * k * ETRS);
             const e_u32x4 d = {__float_as_uint(w.x), __float_as_uint(w.y), __float_as_uint(w.z), __float_as_uint(w.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 8 * k) * a.P * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 8 * k) * a.P * 4, st_aux<ST_X2D>());
         }
         // gfx950 / ROCm 7.2: the stores read their data registers late (gemm_x2d.hip): eight wait states behind the last one
         asm volatile("s_nop 7" ::: "memory");

@@ -204,7 +204,7 @@ __device__ __forceinline__ void epilogue_x2f(const GemmArgs& a, f32x16 (&acc)[8]
 #if defined(USIP_X2F_EXP) && USIP_X2F_EXP == 1                 // measurement build: the epilogue without its stores
             asm volatile("" ::"v"(d));
 #else
-            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 4 * k) * a.P * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rY, st_voff, (i * 32 + 4 * k) * a.P * 4, st_aux<ST_X2F_FWD>());
 #endif
         }
         // buffer_store_dwordx4 with an SGPR soffset reads its data registers late (gemm_x2d.hip): eight wait states
@@ -235,7 +235,7 @@ __device__ __forceinline__ void epilogue_x2f_direct(const GemmArgs& a, f32x16 (&
                              __float_as_uint(f_aread(acc[i][1], 4 * g + e) * out_scale)};
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                __builtin_amdgcn_raw_buffer_store_b64(v[e], rY, voff, (i * 32 + 8 * g + e) * rowb, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v[e], rY, voff, (i * 32 + 8 * g + e) * rowb, st_aux<ST_X2F_DGRAD>());
             asm volatile("s_nop 7" ::: "memory");              // the stores read their data registers late (see above)
             __builtin_amdgcn_sched_barrier(0);                 // one group of rows at a time (the scheduler otherwise reads dozens of
         }                                                      // accumulators ahead and spills the state that lives across the epilogue)
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(FNT) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             S.rd[POOL ? i : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, gv[POOL ? i : 0], sg, 0));
             S.rarg[POOL ? i : 0] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, gv[POOL ? i : 0], sg, 0);
         } else {
-            S.rx[POOL ? 0 : i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rX, xv[i], so, 0));
+            S.rx[POOL ? 0 : i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rX, xv[i], so, st_aux<(PRO >= PRO_BN_BWD) ? LD_X2F_DGRAD : LD_X2F_FWD>()));
         }
-        if (TWO) S.ry[TWO ? i : 0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rX2, xv[i], so, 0));
+        if (TWO) S.ry[TWO ? i : 0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rX2, xv[i], so, st_aux<LD_X2F_DGRAD>()));
     };
 
     // prologue of row i (both positions) of the stage in S; cq: coefficients of the stage for this half-wave, TWO: one float4

@@ -169,11 +169,11 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         } else {
 #pragma unroll
             for (int i = 0; i < GC; ++i)
-                rz[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, voff, i * a.P * 4, 0));
+                rz[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, voff, i * a.P * 4, st_aux<LD_LAYER_BWD_G>()));
         }
 #pragma unroll
         for (int i = 0; i < GC; ++i)
-            ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, voff, i * a.P * 4, 0));
+            ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rY, voff, i * a.P * 4, st_aux<LD_LAYER_BWD_G>()));
     };
     auto load_x = [&](int t) {
         int p0;
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         const float* xbase = a.X + ((long long)bb * a.x_rows + xr0) * a.P + p0 + xq * 8;
 #pragma unroll
         for (int q = 0; q < NPX; ++q) {
-            const float4* src = reinterpret_cast<const float4*>(xbase + (long long)q * XRP * a.P);
-            const float4 u = src[0], v = src[1];
+            const float* src = xbase + (long long)q * XRP * a.P;
+            const float4 u = ld_in4<LD_LAYER_BWD_X>(src), v = ld_in4<LD_LAYER_BWD_X>(src + 4);
             rx[q][0] = u.x; rx[q][1] = u.y; rx[q][2] = u.z; rx[q][3] = u.w;
             rx[q][4] = v.x; rx[q][5] = v.y; rx[q][6] = v.z; rx[q][7] = v.w;
         }
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         for (int r = 0; r < 16; ++r) {
             const int ci = dx_ci * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
             const float v = acc[r] * dx_scale;
-            orow[(long long)ci * a.P] = v;
+            st_out<ST_LAYER_BWD_DX>(orow + (long long)ci * a.P, v);
             if (RED) DX[((RED && DB) ? (t & 1) * CIN * XRS : 0) + ci * XRS + pos] = v;
         }
     };
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (T / NCI) * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                out[row * CIN + (T % NCI) * 32 + c] = acc_dw[u][r] * dw_scale;
+                st_out<ST_WGRAD_PART>(out + row * CIN + (T % NCI) * 32 + c, acc_dw[u][r] * dw_scale);
             }
         }
     }

@@ -7,6 +7,50 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace usip_mlp {
 
+// Cache policy of the big streams (round 6).  A store or load of the shared-MLP kernels can be marked non-temporal
+// (`... nt`; buffer instructions: aux = 2): the line is not kept in L2 / the Infinity Cache in preference to other data.
+// Whether that helps is a property of the STEP, not of the kernel (stand-alone the kernels time the same): it was measured
+// site by site, one variant build per bit, whole step, same box, alternating (profiles/r06z_nt_cache_policy_ab.txt).
+// USIP_ST_NT is the bit mask of the sites that are nt; the default is the set that gained:
+//   ST_X2F_DGRAD    the 8-byte stores of the data gradient of the 256/512-wide layers          -0.08 ms per step
+//   ST_WGRAD_PART   partial weight-gradient tiles (read once, by the reduction behind backward) -0.01
+//   LD_WGRAD_G      (dZ, Y) in the weight gradient: their last use in the step                  -0.02
+//   LD_LAYER_BWD_G  (dZ, Y) in the fused backward of the 64/128-wide layers: their last use     -0.02 ... -0.06
+//   LD_X2F_FWD      the streamed operand of the 256/512-wide forward GEMMs (next use: backward)  -0.04
+// together 4.60 -> 4.42 ms on one box.  Measured and NOT taken (neutral within 0.01 ms unless a figure is given):
+// ST_NARROW_FWD, ST_X2R, ST_X2F_FWD, ST_X2D, ST_LAYER_BWD_DX, LD_NARROW_FWD, LD_X3P_FWD, LD_WGRAD3_G; ST_TILE_EPI (+0.24:
+// conv1's output is read at once by conv2), ST_TILE_EPI_PLAIN (+0.06), LD_X2F_DGRAD (+0.03: the weight gradient re-reads
+// them), LD_X2R (+0.02), LD_WGRAD_X (+0.03: the previous layer's backward re-reads it), LD_LAYER_BWD_X (+0.03).
+enum { ST_NARROW_FWD = 1, ST_X2R = 2, ST_TILE_EPI = 4, ST_X2F_FWD = 8, ST_X2F_DGRAD = 16, ST_X2D = 32, ST_LAYER_BWD_DX = 64,
+       ST_WGRAD_PART = 128, LD_WGRAD_G = 256, ST_TILE_EPI_PLAIN = 512, LD_LAYER_BWD_G = 1024, LD_X2F_FWD = 2048,
+       LD_X2F_DGRAD = 4096, LD_NARROW_FWD = 8192, LD_X2R = 16384, LD_WGRAD_X = 32768, LD_WGRAD3_G = 65536,
+       LD_X3P_FWD = 131072, LD_LAYER_BWD_X = 262144 };
+#ifndef USIP_ST_NT
+#define USIP_ST_NT (ST_X2F_DGRAD | ST_WGRAD_PART | LD_WGRAD_G | LD_LAYER_BWD_G | LD_X2F_FWD)
+#endif
+template <int SITE> constexpr int st_aux() { return (USIP_ST_NT & SITE) ? 2 : 0; }
+typedef float st_f4v __attribute__((ext_vector_type(4)));
+template <int SITE>
+__device__ __forceinline__ void st_out(float* p, float v)
+{
+    if (USIP_ST_NT & SITE) __builtin_nontemporal_store(v, p); else *p = v;
+}
+template <int SITE>
+__device__ __forceinline__ float4 ld_in4(const float* p)
+{
+    if (USIP_ST_NT & SITE) {
+        const st_f4v q = __builtin_nontemporal_load(reinterpret_cast<const st_f4v*>(p));
+        return make_float4(q.x, q.y, q.z, q.w);
+    }
+    return *reinterpret_cast<const float4*>(p);
+}
+template <int SITE>
+__device__ __forceinline__ void st_out4(float* p, float x, float y, float z, float w)
+{
+    if (USIP_ST_NT & SITE) { st_f4v q = {x, y, z, w}; __builtin_nontemporal_store(q, reinterpret_cast<st_f4v*>(p)); }
+    else *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w);
+}
+
 enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2, PRO_BN_BWD_POOL = 3 };
 // PRO_BN_BWD_POOL: the layer's output went ONLY into a max over K neighbours, so its incoming gradient is
 // dZ[c][m][k] = (k == arg[c][m]) ? dpooled[c][m] : 0.  It is synthesised from the two small [C][M] arrays
@@ -123,7 +167,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[T
                 }
                 if (rok) {
                     if (a.y_vec && pb + 3 < a.P) {
-                        *reinterpret_cast<float4*>(yrow + pb) = make_float4(v[0], v[1], v[2], v[3]);
+                        st_out4<(EPI == EPI_STATS) ? ST_TILE_EPI : ST_TILE_EPI_PLAIN>(yrow + pb, v[0], v[1], v[2], v[3]);
                         if (EPI == EPI_STATS) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { s += v[e]; q = __builtin_fmaf(v[e], v[e], q); }
@@ -217,7 +261,7 @@ __device__ __forceinline__ void wgrad_store_partial(const WgradArgs& a, f32x16 (
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int col = n0 + (wn * TN + j) * 32 + c;
-                if (row < a.M && col < a.N) out[(long long)row * a.N + col] = acc[i][j][r];
+                if (row < a.M && col < a.N) st_out<ST_WGRAD_PART>(out + (long long)row * a.N + col, acc[i][j][r]);
             }
 }
 

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(NF_T, OTW == 1 ? 3 : 2) void narrow_fwd_kernel(cons
             const int r4 = (j * 4 + wave) * 4;                // first of the instruction's four rows
             const float* src = xb + (long long)(r4 + (lane >> 4)) * a.P + min(p0 + (lane & 15) * 4, a.P - 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)&Xs[buf][r4][0], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)&Xs[buf][r4][0], 16, 0, st_aux<LD_NARROW_FWD>());
         }
     };
     auto wait_newer = [&](bool ragged, bool stores, bool dma) {   // at most the named newer operations stay in flight
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NF_T, OTW == 1 ? 3 : 2) void narrow_fwd_kernel(cons
                 for (int q = 0; q < 16; ++q) {
                     const float v = acc[t][q];
                     float* rowbase = a.Y + (size_t)(t * 32 + 8 * (q >> 2) + (q & 3)) * a.P;       // wave-uniform
-                    rowbase[yo] = v;
+                    st_out<ST_NARROW_FWD>(rowbase + yo, v);
                     if (STATS) { s1[t][q] += v; s2[t][q] = __builtin_fmaf(v, v, s2[t][q]); }
                 }
         } else {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(NF_T, OTW == 1 ? 3 : 2) void narrow_fwd_kernel(cons
                     const float v = acc[t][q];
                     float* rowbase = a.Y + (size_t)(t * 32 + 8 * (q >> 2) + (q & 3)) * a.P;
                     if (pok) {
-                        rowbase[yo] = v;
+                        st_out<ST_NARROW_FWD>(rowbase + yo, v);
                         if (STATS) { s1[t][q] += v; s2[t][q] = __builtin_fmaf(v, v, s2[t][q]); }
                     }
                 }

@@ -283,7 +283,7 @@ __global__ __launch_bounds__(128 * WN) __attribute__((amdgpu_waves_per_eu(2, 2))
                 rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, goff, kc * pgrp * 4, 0));
                 rarg[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, goff, kc * pgrp * 4, 0);
             } else {
-                rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, kc * a.P * 4, 0));
+                rx[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, kc * a.P * 4, st_aux<(PRO >= PRO_BN_BWD) ? 0 : LD_X3P_FWD>()));
             }
             if (TWO) ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX2, xoff, kc * a.P * 4, 0));
         }
@@ -564,9 +564,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int g = pc / a.pool_group;
                 rg[i] = make_float4(pdp[i][g], __int_as_float(pap[i][g]), __int_as_float(pc % a.pool_group), 0.f);
             } else {
-                rg[i] = *reinterpret_cast<const float4*>(gp[i] + pc);
+                rg[i] = ld_in4<LD_WGRAD3_G>(gp[i] + pc);
             }
-            if (TWO) rg2[i] = *reinterpret_cast<const float4*>(g2p[i] + pc);
+            if (TWO) rg2[i] = ld_in4<LD_WGRAD3_G>(g2p[i] + pc);
             rx[i] = *reinterpret_cast<const float4*>(xp[i] + pc);
         }
     };
@@ -808,10 +808,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 rg[i] = make_float4(Pdb[pgoff[H][i] + g], __int_as_float(Pab[pgoff[H][i] + g]),
                                     __int_as_float(pc % a.pool_group), 0.f);
             } else {
-                rg[i] = *reinterpret_cast<const float4*>(Gb + goff[H][i] + pc);
+                rg[i] = ld_in4<LD_WGRAD_G>(Gb + goff[H][i] + pc);
             }
-            rg2[i] = *reinterpret_cast<const float4*>(G2b + goff[H][i] + pc);
-            rx[i] = *reinterpret_cast<const float4*>(Xb + xoff[H][i] + pc);
+            rg2[i] = ld_in4<LD_WGRAD_G>(G2b + goff[H][i] + pc);
+            rx[i] = ld_in4<LD_WGRAD_X>(Xb + xoff[H][i] + pc);
         }
     };
     auto store_event = [&](auto hc, int pbuf, int pair) {
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 r.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rPd, goff, kc * pgrp * 4, 0));
                 r.arg[POOL ? i : 0] = (int)__builtin_amdgcn_raw_buffer_load_b32(rPa, goff, kc * pgrp * 4, 0);
             } else {
-                r.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, kc * a.P * 4, 0));
+                r.x[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, xoff, kc * a.P * 4, st_aux<LD_X2R>()));
             }
             if (TWO) r.y[TWO ? i : 0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX2, xoff, kc * a.P * 4, 0));
         }
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float v = __builtin_fmaf(acc[j][r], out_scale, bsh[ch]);
                     if (RB) v += rbs[RB ? (q / nslab) & 1 : 0][RB ? ch : 0][j];
                     if (pok && ch < a.M) {
-                        yb[(long long)ch * a.P + pp] = v;
+                        st_out<ST_X2R>(yb + (long long)ch * a.P + pp, v);
                         if (EPI == EPI_STATS) { s1[EPI == EPI_STATS ? r : 0] += v; s2[EPI == EPI_STATS ? r : 0] = __builtin_fmaf(v, v, s2[EPI == EPI_STATS ? r : 0]); }
                     }
                 }
