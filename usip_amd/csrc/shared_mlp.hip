@@ -617,8 +617,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int p = min(p0 + u * 1024, P - 4);         // clamped: branch-free loads (P % 4 == 0)
-                yq[u] = *reinterpret_cast<const float4*>(y + p);
-                dq[u] = *reinterpret_cast<const float4*>(dz + p);
+                yq[u] = ld_in4<LD_BN_REDUCE_Y>(y + p);
+                dq[u] = ld_in4<LD_BN_REDUCE_Z>(dz + p);
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
@@ -659,8 +659,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int p = min(p0 + u * 1024, P - 4);     // clamped: branch-free loads
-                    yq[u] = *reinterpret_cast<const float4*>(y + p);
-                    dq[u] = *reinterpret_cast<const float4*>(dz + p);
+                    yq[u] = ld_in4<LD_BN_REDUCE_Y>(y + p);
+                    dq[u] = ld_in4<LD_BN_REDUCE_Z>(dz + p);
                 }
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
