@@ -123,7 +123,10 @@ def load_traffic_db(precision):
             cands.append((m.group(1), f))
     if not cands:
         return {}, None
-    tag = max(t for t, _ in cands)
+    def order(t):                                    # r06ac is newer than r06m: session tags run a..z, then aa..az
+        m = re.match(r"r(\d+)([a-z]*)", t)
+        return (int(m.group(1)), len(m.group(2)), m.group(2))
+    tag = max((t for t, _ in cands), key=order)
     db, src = {}, []
     for t, f in sorted(cands):
         if t != tag:
