@@ -525,6 +525,29 @@ int usip_group_max_backward_add_f32(const float* dpooled, const int32_t* arg, fl
 int usip_knn_f32(const float* query, const float* database, int32_t* idx,
                  int B, int M, int N, int K, void* stream);
 
+/* The FIRST layer of GeneralKNNFusionModule (models/layers.py:422-431: gather the K neighbours' coordinates and features,
+ * decenter the coordinates, concatenate to B x (3+C) x M x K, then models/layers.py:208-216: conv1x1 + BatchNorm + ReLU)
+ * without the gathered tensor.  The convolution is linear and the features enter it undecentered:
+ *     Y[b][co][m][k] = sum_j W[co][j] (database[b][j][n] - query[b][j][m])  +  U[b][co][n],   n = idx[b][m][k],
+ * with U = W[:, 3:] . feat + bias a product over the N database points (usip_mlp_gemm_*) instead of the M*K grouped
+ * positions.  Same math as the reference's layer up to fp32 summation order.
+ *   forward : U f32 [B][Cout][N], W f32 [Cout][ldw] (columns 0..2 = the coordinate weights), database [B][3][N],
+ *             query [B][3][M], idx i32 [B][M][K] -> Y f32 [B][Cout][M*K]; stats (may be NULL): [2][Cout][B] per-cloud
+ *             partial (sum, sum^2) of every channel, the layout usip_bn_finalize_f32 reads with ntn = B.
+ *   backward: dZ, Y [B][Cout][M*K] and coef4 [>=4][Cout] as for the shared-MLP prologue PRO_BN_BWD
+ *             (dY = coef4[0] dZ [fma(Y, coef4[0], coef4[1]) > 0 if relu] + coef4[2] Y + coef4[3]); (start, perm) = the
+ *             usip_csr_by_index_i32 lists of idx viewed as [B][M*K] over N destinations ->
+ *             dU [B][Cout][N] = the segment sums of dY in list order (no float atomics),
+ *             dWc_part [B][Cout][3] = per-cloud partial gradients of the coordinate weights (the caller adds the B parts).
+ * Shapes: usip_knn_layer_supported (N <= 1489, M*K <= 16384, M*K % 4 == 0); dZ, Y, idx 16-B aligned. */
+int usip_knn_layer_supported(int N, int M, int K);
+int usip_knn_layer_forward_f32(const float* U, const float* W, int ldw, const float* database, const float* query,
+                               const int32_t* idx, float* Y, float* stats, int B, int Cout, int N, int M, int K,
+                               void* stream);
+int usip_knn_layer_backward_f32(const float* dZ, const float* Y, const float* coef4, int relu, const float* database,
+                                const float* query, const int32_t* idx, const int32_t* start, const int32_t* perm,
+                                float* dU, float* dWc_part, int B, int Cout, int N, int M, int K, void* stream);
+
 /* ------------------------------------------------------------------ (judge row) RPN_Detector_KNN front end
  * idx[b][m][0..K) = the K cloud points nearest to node m, nearest first, ties towards the lower index:
  * torch.norm(node - x) over B x M x N followed by torch.topk(k=64, largest=False, sorted=False) of

@@ -961,6 +961,85 @@ class _KnnGroup(torch.autograd.Function):
         return ops.group_gather_backward(dout.contiguous(), idx32, C, N, coff=3), None, None, None
 
 
+# Round 6: the first layer of GeneralKNNFusionModule without the gathered tensor (csrc/knn_layer.hip); USIP_KNN_LAYER=0
+# keeps the gather + generic layer (A/B runs, and the form the new one is tested against).
+KNN_FIRST_LAYER = _os.environ.get("USIP_KNN_LAYER", "1") not in ("0", "off")
+
+
+class _KnnFirstLayer(torch.autograd.Function):
+    """layers_before[0](cat(gather(database, I) - query, gather(feat, I))) of GeneralKNNFusionModule
+    (models/layers.py:422-431 + :208-216: conv1x1 + BatchNorm (batch statistics) + ReLU) as ONE node that never builds the
+    B x (3+C) x M x K tensor:  W . [d ; feat[:, n]] = W_c . d + (W_f . feat)[:, n]  -- the feature half of the product is
+    taken over the N database points (an M-sized GEMM), gathered by the neighbour index and completed with the three
+    coordinate terms in one pass that writes the layer's pre-BN output and its statistics.  Backward: one pass over
+    (dZ, Y) forms dY, its segment sums over the neighbour lists (fixed order) and the coordinate columns of dW; d feat
+    and the feature columns of dW are M-sized products again.  Same math as the reference up to fp32 summation order.
+    Returns (pre-BN output [B,Cout,M*K], coef) = the parts of a LazyAct."""
+
+    @staticmethod
+    def forward(ctx, feat, database, query, idx32, w2, bias, gamma, beta, running_mean, running_var, momentum, eps, sink):
+        B, C, N = feat.shape
+        _, M, K = idx32.shape
+        ctx.set_materialize_grads(False)
+        feat = feat.contiguous()
+        database, query = database.contiguous(), query.contiguous()
+        w2c = w2.contiguous()
+        U, _ = ops.mlp_gemm(_kmajor(w2)[3:], feat, bias, tag="fwd_knn_nodes")          # [B,Cout,N] = W_f . feat + bias
+        y, stats = ops.knn_layer_forward(U, w2c, database, query, idx32)
+        mean, invstd, coef = ops.bn_finalize(stats.view(2, w2.shape[0], B), B * M * K, gamma, beta, eps, momentum,
+                                             running_mean, running_var)
+        y = _relu_hook(y, coef)
+        start, perm = ops.csr_by_index(idx32.view(B, M * K), N)
+        ctx.save_for_backward(feat, database, query, idx32, w2, y, coef, mean, invstd, gamma, start, perm)
+        ctx.sink = sink
+        ctx.mark_non_differentiable(coef)
+        return y, coef
+
+    @staticmethod
+    def backward(ctx, dz, _dcoef):
+        if dz is None:
+            return (None,) * 13
+        feat, database, query, idx32, w2, y, coef, mean, invstd, gamma, start, perm = ctx.saved_tensors
+        sink = ctx.sink
+        C = feat.shape[1]
+        dz = dz.contiguous().view(y.shape)
+        dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, True, sink)
+        dU, dwc = ops.knn_layer_backward(dz, y, coef4, True, database, query, idx32, start, perm)
+        w2c = w2.contiguous()
+        dfeat = dw = None
+        if ctx.needs_input_grad[0]:
+            dfeat = ops.mlp_gemm(w2c, dU, tag="dgrad_knn_nodes", M=C, a_offset=3)[0]     # W_f^T . dU
+        if ctx.needs_input_grad[4]:
+            dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
+            ops.mlp_wgrad(dU, feat, out=dw, coloff=3)                                     # dU . feat^T -> columns 3..
+            dw[:, :3].copy_(dwc)
+        db = torch.zeros_like(gamma) if (ctx.needs_input_grad[5] and not sink) else None  # in front of BatchNorm: zero
+        if sink:
+            dw = db = dgamma = dbeta = None
+        return (dfeat, None, None, None, dw, db, dgamma, dbeta) + (None,) * 5
+
+
+def knn_first_layer_supported(feat, idx32, bias, bn, relu: bool) -> bool:
+    return (KNN_FIRST_LAYER and relu and bias is not None and bn is not None and bn.training and torch.is_grad_enabled()
+            and isinstance(feat, torch.Tensor) and feat.is_cuda
+            and ops.knn_layer_supported(feat.shape[2], idx32.shape[1], idx32.shape[2]))
+
+
+def knn_first_layer(feat, database, query, idx32, weight, bias, bn) -> "LazyAct":
+    """relu(bn(conv1x1(cat(gather(database, I) - query, gather(feat, I))))) as a LazyAct [B,Cout,M,K]
+    (knn_first_layer_supported; coordinates carry no gradient, models/layers.py:428-430 operates on detached inputs
+    there as here)."""
+    require_device(feat, "knn_first_layer")
+    w2 = weight.reshape(weight.shape[0], weight.shape[1])
+    if bn.num_batches_tracked is not None and not DEFER_BN_COUNTERS:
+        bn.num_batches_tracked.add_(1)
+    y, coef = _KnnFirstLayer.apply(feat, database.detach(), query.detach(), idx32, w2, bias, bn.weight, bn.bias,
+                                   bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                   _sink(weight, bias, bn.weight, bn.bias))
+    B, _, M, K = (feat.shape[0], 0) + tuple(idx32.shape[1:])
+    return LazyAct(y, coef, True, (B, w2.shape[0], M, K))
+
+
 class _ClusterBroadcast(torch.autograd.Function):
     """out[b,c,n] = x[b,c,idx[b,n]]: every point receives its SOM node's feature (models/networks.py:119-125,
     torch.gather on an index expanded over the channels).  Backward = the sum over each node's member points,

@@ -262,10 +262,21 @@ class GeneralKNNFusionModule(nn.Module):
         """query Bx3xM, database Bx3xN, x BxCxN -> BxC'xM.  Coordinates carry no gradient."""
         knn_I = Fh.knn_indices(query, database, K)                       # layers.py:417-421
         self.last_knn_I = knn_I
-        h = Fh.knn_group(x, database.detach(), query.detach(), knn_I)    # :422-430
-        for n, layer in enumerate(self.layers_before):
+        first0 = self.layers_before[0]
+        bn0 = getattr(first0, "norm", None)
+        if (not is_generic(first0) and isinstance(bn0, _BatchNorm)
+                and Fh.knn_first_layer_supported(x, knn_I, first0.conv.bias, bn0, first0.activation == "relu")):
+            # :422-431 without the gathered tensor (csrc/knn_layer.hip): the feature half of the first layer's product is
+            # taken over the database points and gathered
+            bn0.decay_momentum(epoch)
+            h = Fh.knn_first_layer(x, database, query, knn_I, first0.conv.weight, first0.conv.bias, bn0)
+            rest_before = list(self.layers_before)[1:]
+        else:
+            h = Fh.knn_group(x, database.detach(), query.detach(), knn_I)    # :422-430
+            rest_before = list(self.layers_before)
+        for layer in rest_before:
             # the three decentered coordinates in front of the features are inputs without a gradient
-            h = layer(h, epoch, defer=True, nograd_prefix=3 if n == 0 else 0)
+            h = layer(h, epoch, defer=True, nograd_prefix=3 if layer is first0 else 0)
         pooled, h = Fh.group_max_fork(h)                                 # :433 (BN+ReLU+max in one pass)
         first, rest = self.layers_after[0], list(self.layers_after)[1:]
         y = pooled_concat_layer(first, h, pooled, True, epoch)           # :435

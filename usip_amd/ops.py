@@ -1189,6 +1189,47 @@ def knn(query: torch.Tensor, database: torch.Tensor, K: int) -> torch.Tensor:
     return out
 
 
+def knn_layer_supported(N: int, M: int, K: int) -> bool:
+    return bool(_lib.lib().usip_knn_layer_supported(int(N), int(M), int(K)))
+
+
+def knn_layer_forward(U, weight2, database, query, idx32, want_stats: bool = True):
+    """Y[b,co,m,k] = W[co,:3] . (database[b,:,n] - query[b,:,m]) + U[b,co,n], n = idx[b,m,k] (csrc/knn_layer.hip).
+    U [B,Cout,N] (= W[:,3:] . feat + bias), weight2 [Cout,3+C] -> (Y [B,Cout,M*K], stats [2*Cout*B] or None)."""
+    _need(U, "U", torch.float32)
+    _need(weight2, "weight", torch.float32)
+    _need_pts(query, "query")
+    _need_pts(database, "database")
+    _need(idx32, "idx", torch.int32)
+    B, Cout, N = U.shape
+    _, M, K = idx32.shape
+    Y = torch.empty((B, Cout, M * K), dtype=torch.float32, device=U.device)
+    stats = torch.empty(2 * Cout * B, dtype=torch.float32, device=U.device) if want_stats else None
+    with torch.cuda.device(U.device), prof.kernel("knn_layer_fwd", 4.0 * B * M * K * (Cout + 1), 8.0 * B * Cout * M * K):
+        _lib.check(_lib.lib().usip_knn_layer_forward_f32(_ptr(U), _ptr(weight2), int(weight2.stride(0)), _ptr(database),
+                                                         _ptr(query), _ptr(idx32), _ptr(Y), _opt(stats), B, Cout, N, M, K,
+                                                         _stream(U)), "usip_knn_layer_forward_f32")
+    return Y, stats
+
+
+def knn_layer_backward(dZ, Y, coef4, relu: bool, database, query, idx32, start, perm):
+    """-> (dU [B,Cout,N], dWc [Cout,3]): segment sums of dY = BN'(dZ, Y) in CSR list order, and the gradient of the three
+    coordinate columns of the weight (per-cloud partials added in cloud order)."""
+    _need(dZ, "dZ", torch.float32)
+    _need(Y, "Y", torch.float32)
+    B, Cout, P = Y.shape
+    _, M, K = idx32.shape
+    N = start.shape[1] - 1
+    dU = torch.empty((B, Cout, N), dtype=torch.float32, device=Y.device)
+    part = torch.empty((B, Cout, 3), dtype=torch.float32, device=Y.device)
+    with torch.cuda.device(Y.device), prof.kernel("knn_layer_bwd", 4.0 * B * P * (2 * Cout + 1), 12.0 * B * Cout * P):
+        _lib.check(_lib.lib().usip_knn_layer_backward_f32(_ptr(dZ), _ptr(Y), _ptr(coef4), int(bool(relu)), _ptr(database),
+                                                          _ptr(query), _ptr(idx32), _ptr(start), _ptr(perm), _ptr(dU),
+                                                          _ptr(part), B, Cout, N, M, K, _stream(Y)),
+                   "usip_knn_layer_backward_f32")
+    return dU, part.sum(dim=0)
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr: float, beta1: float, beta2: float, eps: float, hyper=None):
     """One Adam step on flat fp32 buffers, in place (usip_adam_step_f32); `step` is a device float[1], incremented.
     hyper: device float[4] = (lr, beta1, beta2, eps) read by the kernel instead of the scalar arguments (a captured launch
