@@ -43,7 +43,8 @@ const char* usip_version(void);
  * weight gradient with half-line loads (wgrad_x3_kernel<.., 2> instead of wgrad_x2l_kernel); and that switch ON forms round 5
  * measured and did not keep: 2 / 4 = two / four loop iterations' loads in flight in the BatchNorm-backward reduction (default
  * one), 8 = several batches of rows per workgroup with prefetch in group_max4 (default one); 32 = the 128-row-tile split GEMM with
- * round 4's two-slot weight ring (DMA one stage ahead, issued at the top of the stage) instead of the three-slot one. */
+ * round 4's two-slot weight ring (DMA one stage ahead, issued at the top of the stage) instead of the three-slot one;
+ * 64 = narrow_fwd with 1024 / 768 workgroups; 128 = usip_knn_layer_backward_f32 with one row and 256 threads per workgroup (default: two rows, 512 threads). */
 enum { USIP_TUNE_INDEX_MAX_CH = 0, USIP_TUNE_INDEX_MAX_UNROLL, USIP_TUNE_X3_WGRAD_TILE, USIP_TUNE_X3_GEMM_TILE,
        USIP_TUNE_GEMM_SPLIT3, USIP_TUNE_INDEX_MAX_THREADS, USIP_TUNE_X2_DIRECT, USIP_TUNE_R5_FORMS, USIP_TUNE_COUNT };
 int usip_set_tuning(const char* name, int value);
@@ -535,18 +536,19 @@ int usip_knn_f32(const float* query, const float* database, int32_t* idx,
  *             query [B][3][M], idx i32 [B][M][K] -> Y f32 [B][Cout][M*K]; stats (may be NULL): [2][Cout][B] per-cloud
  *             partial (sum, sum^2) of every channel, the layout usip_bn_finalize_f32 reads with ntn = B.
  *   backward: dZ, Y [B][Cout][M*K] and coef4 [>=4][Cout] as for the shared-MLP prologue PRO_BN_BWD
- *             (dY = coef4[0] dZ [fma(Y, coef4[0], coef4[1]) > 0 if relu] + coef4[2] Y + coef4[3]); (start, perm) = the
+ *             (dY = coef4[0] dZ [fma(Y, coef4[0], coef4[1]) > 0 if relu] + coef4[2] Y + coef4[3]); dcoord f32 [B][3][M*K] =
+ *             database[b][j][idx] - query[b][j][m] (usip_group_gather_f32 with sub = query); (start, perm) = the
  *             usip_csr_by_index_i32 lists of idx viewed as [B][M*K] over N destinations ->
  *             dU [B][Cout][N] = the segment sums of dY in list order (no float atomics),
  *             dWc_part [B][Cout][3] = per-cloud partial gradients of the coordinate weights (the caller adds the B parts).
- * Shapes: usip_knn_layer_supported (N <= 1489, M*K <= 16384, M*K % 4 == 0); dZ, Y, idx 16-B aligned. */
+ * Shapes: usip_knn_layer_supported (N <= 1489, M*K <= 16384, M*K % 4 == 0); dZ, Y, dcoord 16-B aligned. */
 int usip_knn_layer_supported(int N, int M, int K);
 int usip_knn_layer_forward_f32(const float* U, const float* W, int ldw, const float* database, const float* query,
                                const int32_t* idx, float* Y, float* stats, int B, int Cout, int N, int M, int K,
                                void* stream);
-int usip_knn_layer_backward_f32(const float* dZ, const float* Y, const float* coef4, int relu, const float* database,
-                                const float* query, const int32_t* idx, const int32_t* start, const int32_t* perm,
-                                float* dU, float* dWc_part, int B, int Cout, int N, int M, int K, void* stream);
+int usip_knn_layer_backward_f32(const float* dZ, const float* Y, const float* coef4, int relu, const float* dcoord,
+                                const int32_t* start, const int32_t* perm, float* dU, float* dWc_part,
+                                int B, int Cout, int N, int M, int K, void* stream);
 
 /* ------------------------------------------------------------------ (judge row) RPN_Detector_KNN front end
  * idx[b][m][0..K) = the K cloud points nearest to node m, nearest first, ties towards the lower index:

@@ -65,7 +65,8 @@ def test_knn_layer_backward_matches_segment_sums_of_the_batchnorm_gradient(shape
     dZ = torch.randn(B, Cout, P, generator=g).to(DEV)
     coef4 = (torch.randn(4, Cout, generator=g) * 0.5).to(DEV).contiguous()
     start, perm = ops.csr_by_index(idx.view(B, P), N)
-    dU, dwc = ops.knn_layer_backward(dZ, Y, coef4, True, database, query, idx, start, perm)
+    dcoord = ops.group_gather(database, idx, sub=query).view(B, 3, P)
+    dU, dwc = ops.knn_layer_backward(dZ, Y, coef4, True, dcoord, start, perm, M, K)
     z = ops.bn_apply(Y, coef4[:2].contiguous(), False)     # the kernels' own fma(y, a1, a0): the same ReLU decisions
     c = coef4.double().view(4, 1, Cout, 1)
     dY = c[0] * torch.where(z > 0, dZ, torch.zeros_like(dZ)).double() + c[2] * Y.double() + c[3]
@@ -75,7 +76,15 @@ def test_knn_layer_backward_matches_segment_sums_of_the_batchnorm_gradient(shape
     ref_dwc = torch.einsum("bop,bjp->oj", dY, X[:, :3])
     assert_close(dU.cpu().numpy(), ref_dU.cpu().numpy(), name="dU")
     assert_close(dwc.cpu().numpy(), ref_dwc.cpu().numpy(), name="dW[:, :3]")
-    dU2, dwc2 = ops.knn_layer_backward(dZ, Y, coef4, True, database, query, idx, start, perm)
+    dU2, dwc2 = ops.knn_layer_backward(dZ, Y, coef4, True, dcoord, start, perm, M, K)
+    from usip_amd import _lib
+    _lib.lib().usip_set_tuning(b"r5_forms", 128)        # the one-row-per-workgroup form: the same sums in the same order
+    try:
+        dU3, dwc3 = ops.knn_layer_backward(dZ, Y, coef4, True, dcoord, start, perm, M, K)
+    finally:
+        _lib.lib().usip_set_tuning(b"r5_forms", 0)
+    assert torch.equal(dU, dU3)
+    assert_close(dwc3.cpu().numpy(), ref_dwc.cpu().numpy(), name="dW[:, :3], one row per workgroup")
     assert torch.equal(dU, dU2) and torch.equal(dwc, dwc2)          # fixed summation order: the same bits
 
 
@@ -139,6 +148,6 @@ def test_knn_first_layer_is_what_the_training_module_runs():
     finally:
         prof.enable(False)
         prof.reset()
-    assert "knn_layer_fwd" in names and "knn_layer_bwd" in names and "group_gather" not in names, names
+    assert "knn_layer_fwd" in names and "knn_layer_bwd" in names and "segment_sum" not in names, names
     with torch.no_grad():                                  # inference keeps the gather + layer form
         assert not Fh.knn_first_layer_supported(feat, idx, mod.layers_before[0].conv.bias, mod.layers_before[0].norm, True)

@@ -135,8 +135,8 @@ SIGNATURES = {
     "usip_knn_layer_supported": ([_int, _int, _int], _int),
     "usip_knn_layer_forward_f32": ([_f32p, _f32p, _int, _f32p, _f32p, _i32p, _f32p, _f32p, _int, _int, _int, _int, _int,
                                     _stream], _int),
-    "usip_knn_layer_backward_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _f32p, _i32p, _i32p, _i32p, _f32p, _f32p, _int, _int,
-                                     _int, _int, _int, _stream], _int),
+    "usip_knn_layer_backward_f32": ([_f32p, _f32p, _f32p, _int, _f32p, _i32p, _i32p, _f32p, _f32p, _int, _int, _int, _int,
+                                     _int, _stream], _int),
     "usip_fps_f32": ([_f32p, _i32p, _i32p, _int, _int, _int, _stream], _int),
     "usip_nms_f32": ([_f32p, _f32p, _flt, _i32p, _i32p, _int, _int, _stream], _int),
     "usip_ball_query_coords_f32": ([_f32p, _f32p, _i32p, _flt, _int, _int, _int, _int, _stream], _int),

@@ -16,7 +16,8 @@
 //   backward: dY = BatchNorm-backward of (dZ, Y) (the shared library's prologue, mlp_common.h::pro_apply<PRO_BN_BWD>)
 //             dU[b, c, n]  = sum over the grouped positions that picked n, in the fixed order of the CSR lists
 //                            (usip_csr_by_index_i32: no float atomics)
-//             dW_c[c, j]   = sum_p dY[c, p] d[j, p]   (one partial per cloud; the caller adds the B partials)
+//             dW_c[c, j]   = sum_p dY[c, p] d[j, p]   (one partial per cloud; the caller adds the B partials; d = the
+//                            decentered neighbour coordinates [B][3][M*K], gathered once: usip_group_gather_f32)
 //           d feat = W_f^T . dU and dW_f = dU . feat^T are M-sized products of the shared-MLP library again.
 //   Replaces, per step of the Ball detector: two group_gather launches + the 69 MB gathered tensor, the 256 x 131 forward
 //   GEMM, its data gradient, its weight gradient and the gathered tensor's segment sum.
@@ -24,6 +25,9 @@
 
 namespace {
 
+#ifndef KL_EXP
+#define KL_EXP 0                      // measurement builds (tools/build_variant.py): 1 no pass 2, 2 no coordinate gradient, 4 no dZ/Y loads
+#endif
 constexpr int KL_FCH = 8;             // forward: channels per workgroup
 constexpr int KL_FT = 256;            // forward: threads
 
@@ -105,21 +109,38 @@ __global__ __launch_bounds__(KL_FT) void knn_layer_fwd_kernel(
     }
 }
 
-constexpr int KL_BT = 512;            // backward: threads
-
-// grid (ceil(Cout / CPB), B).  LDS: dY rows of the chunk [CPB][P] (the 6 KB of database coordinates come from L1 / L2).
-template <int CPB>
-__global__ __launch_bounds__(KL_BT) void knn_layer_bwd_kernel(
+// Backward.  grid (ceil(Cout / CPB), B), NT threads.  LDS: dY rows of the chunk [CPB][P].  `dcoord` [B][3][P] = the
+// decentered neighbour coordinates (usip_group_gather_f32 with sub = query: formed once per step, exactly as
+// models/layers.py:428-430 does), read in whole 16-B pieces.
+template <int CPB, int NT>
+__global__ __launch_bounds__(NT) void knn_layer_bwd_kernel(
     const float* __restrict__ dZ, const float* __restrict__ Yp, const float* __restrict__ coef4, int relu,
-    const float* __restrict__ database, const float* __restrict__ query, const int32_t* __restrict__ idx,
-    const int32_t* __restrict__ start, const int32_t* __restrict__ perm, float* __restrict__ dU,
-    float* __restrict__ dWc_part, int Cout, int N, int M, int K)
+    const float* __restrict__ dcoord, const int32_t* __restrict__ start, const int32_t* __restrict__ perm,
+    float* __restrict__ dU, float* __restrict__ dWc_part, int Cout, int N, int P)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];         // [CPB][P]
-    __shared__ float red[CPB][3][KL_BT / 64];
-    const int P = M * K;
-    const int b = blockIdx.y, c0 = blockIdx.x * CPB, tid = threadIdx.x;
-    const float* ds = database + (long long)b * 3 * N;
+    __shared__ float red[CPB][3][NT / 64];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    // the neighbour list of this thread's first destination (pass 2) is requested first: its two dependent round trips
+    // hide behind pass 1
+    const int32_t* st = start + (long long)b * (N + 1);
+    const int32_t* pm = perm + (long long)b * P;
+    constexpr int PF = 32;                                                 // the K = 16 lists have up to ~3 K entries
+    int seg0 = 0, seg1 = 0, pre[PF];
+    if (!(KL_EXP & 1)) {
+        if (tid < N) { seg0 = st[tid]; seg1 = st[tid + 1]; }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) pre[i] = pm[min(seg0 + i, P - 1)];
+    } else {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) pre[i] = 0;
+    }
+    // pass 1: dY of the chunk's rows into LDS (whole 16-B pieces: P % 4 == 0), the coordinate weight gradient on the way.
+    // UN pieces per thread and trip, every load of a trip issued before the first use (clamped addresses: no branches)
+    constexpr int UN = 4;
+    const float* db = dcoord + (long long)b * 3 * P;
+    // the workgroup's channel chunks: blockIdx.x, + gridDim.x, ... (its neighbour list is fetched once for all of them)
+    for (int c0 = blockIdx.x * CPB; c0 < Cout; c0 += gridDim.x * CPB) {
     float a1[CPB], a0[CPB], q1[CPB], q0[CPB];
 #pragma unroll
     for (int c = 0; c < CPB; ++c) {
@@ -129,35 +150,45 @@ __global__ __launch_bounds__(KL_BT) void knn_layer_bwd_kernel(
     float sw[CPB][3];
 #pragma unroll
     for (int c = 0; c < CPB; ++c) { sw[c][0] = 0.f; sw[c][1] = 0.f; sw[c][2] = 0.f; }
-    const int32_t* ib = idx + (long long)b * P;
-    const float* qb = query + (long long)b * 3 * M;
-    // pass 1: dY of the chunk's rows into LDS (whole 16-B pieces: P % 4 == 0), the coordinate weight gradient on the way
-    for (int p = tid * 4; p < P; p += KL_BT * 4) {
-        const int4 nn = *reinterpret_cast<const int4*>(ib + p);
-        const int n4[4] = {nn.x, nn.y, nn.z, nn.w};
-        float d[3][4];
+    for (int pb = tid * 4; pb < P; pb += NT * 4 * UN) {
+        float4 d4[UN][3], z4[UN][CPB], y4[UN][CPB];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = min(max(n4[e], 0), N - 1), m = (p + e) / K;
-            d[0][e] = ds[n] - qb[m]; d[1][e] = ds[N + n] - qb[M + m]; d[2][e] = ds[2 * N + n] - qb[2 * M + m];
-        }
+        for (int u = 0; u < UN; ++u) {
+            const int p = min(pb + u * NT * 4, P - 4);
 #pragma unroll
-        for (int c = 0; c < CPB; ++c) {
-            const long long off = ((long long)b * Cout + min(c0 + c, Cout - 1)) * P + p;
-            const float4 z4 = usip_load_stream4(dZ + off), y4 = usip_load_stream4(Yp + off);   // last use of both
-            const float zv[4] = {z4.x, z4.y, z4.z, z4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
-            float g[4];
+            for (int j = 0; j < 3; ++j) d4[u][j] = (KL_EXP & 2) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(db + (long long)j * P + p);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float dyh = (!relu || __builtin_fmaf(yv[e], a1[c], a0[c]) > 0.0f) ? zv[e] : 0.0f;
-                g[e] = __builtin_fmaf(a1[c], dyh, __builtin_fmaf(q1[c], yv[e], q0[c]));   // pro_apply<PRO_BN_BWD>
-#pragma unroll
-                for (int j = 0; j < 3; ++j) sw[c][j] = __builtin_fmaf(g[e], d[j][e], sw[c][j]);
+            for (int c = 0; c < CPB; ++c) {
+                const long long off = ((long long)b * Cout + min(c0 + c, Cout - 1)) * P + p;
+                z4[u][c] = (KL_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)p) : usip_load_stream4(dZ + off);   // last use of both in the step
+                y4[u][c] = (KL_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)p) : usip_load_stream4(Yp + off);
             }
-            *reinterpret_cast<float4*>(rows + c * P + p) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                                 // all of the trip's loads in flight before the first use
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = pb + u * NT * 4;
+            if (p >= P) break;
+            const float d[3][4] = {{d4[u][0].x, d4[u][0].y, d4[u][0].z, d4[u][0].w},
+                                   {d4[u][1].x, d4[u][1].y, d4[u][1].z, d4[u][1].w},
+                                   {d4[u][2].x, d4[u][2].y, d4[u][2].z, d4[u][2].w}};
+#pragma unroll
+            for (int c = 0; c < CPB; ++c) {
+                const float zv[4] = {z4[u][c].x, z4[u][c].y, z4[u][c].z, z4[u][c].w};
+                const float yv[4] = {y4[u][c].x, y4[u][c].y, y4[u][c].z, y4[u][c].w};
+                float g[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dyh = (!relu || __builtin_fmaf(yv[e], a1[c], a0[c]) > 0.0f) ? zv[e] : 0.0f;
+                    g[e] = __builtin_fmaf(a1[c], dyh, __builtin_fmaf(q1[c], yv[e], q0[c]));   // pro_apply<PRO_BN_BWD>
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) sw[c][j] = __builtin_fmaf(g[e], d[j][e], sw[c][j]);
+                }
+                *reinterpret_cast<float4*>(rows + c * P + p) = make_float4(g[0], g[1], g[2], g[3]);
+            }
         }
     }
-    // coordinate weight gradient: lanes (fixed tree), then the eight waves in order
+    // coordinate weight gradient: lanes (fixed tree), then the waves in order
 #pragma unroll
     for (int c = 0; c < CPB; ++c)
 #pragma unroll
@@ -171,21 +202,32 @@ __global__ __launch_bounds__(KL_BT) void knn_layer_bwd_kernel(
     if (tid < CPB * 3) {
         const int c = tid / 3, j = tid % 3;
         if (c0 + c < Cout) {
-            const float* r = red[c][j];
-            dWc_part[((long long)b * Cout + c0 + c) * 3 + j] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) t += red[c][j][w];
+            dWc_part[((long long)b * Cout + c0 + c) * 3 + j] = t;
         }
     }
-    // pass 2: segment sums in list order (usip_segment_sum_f32's loop)
-    const int32_t* st = start + (long long)b * (N + 1);
-    const int32_t* pm = perm + (long long)b * P;
+    // pass 2: segment sums in list order (the summation order of usip_segment_sum_f32: one position after the other)
     float* ub = dU + ((long long)b * Cout + c0) * N;
-    for (int n = tid; n < N; n += KL_BT) {
-        const int s0 = st[n], s1 = st[n + 1];
+    for (int n = tid; n < ((KL_EXP & 1) ? 0 : N); n += NT) {
+        const bool mine = n == tid;                                        // the prefetched list
+        const int s0 = mine ? seg0 : st[n], s1 = mine ? seg1 : st[n + 1];
         float acc[CPB];
 #pragma unroll
         for (int c = 0; c < CPB; ++c) acc[c] = 0.f;
         int j = s0;
-        for (; j + 3 < s1; j += 4) {
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) {
+                if (s0 + i < s1) {
+#pragma unroll
+                    for (int c = 0; c < CPB; ++c) acc[c] += rows[c * P + pre[i]];
+                }
+            }
+            j = min(s0 + PF, s1);
+        }
+        for (; j + 3 < s1; j += 4) {                                       // four list entries in flight
             const int p0 = pm[j], p1 = pm[j + 1], p2 = pm[j + 2], p3 = pm[j + 3];
 #pragma unroll
             for (int c = 0; c < CPB; ++c) {
@@ -202,6 +244,8 @@ __global__ __launch_bounds__(KL_BT) void knn_layer_bwd_kernel(
         for (int c = 0; c < CPB; ++c)
             if (c0 + c < Cout) ub[(long long)c * N + n] = acc[c];
     }
+    __syncthreads();                                                       // the next chunk overwrites rows and red
+    }   // channel chunks
 }
 
 }  // namespace
@@ -232,26 +276,34 @@ extern "C" int usip_knn_layer_forward_f32(const float* U, const float* W, int ld
 }
 
 extern "C" int usip_knn_layer_backward_f32(const float* dZ, const float* Y, const float* coef4, int relu,
-                                           const float* database, const float* query, const int32_t* idx,
-                                           const int32_t* start, const int32_t* perm, float* dU, float* dWc_part,
-                                           int B, int Cout, int N, int M, int K, void* stream)
+                                           const float* dcoord, const int32_t* start, const int32_t* perm, float* dU,
+                                           float* dWc_part, int B, int Cout, int N, int M, int K, void* stream)
 {
     if (B < 0 || Cout < 1 || !usip_knn_layer_supported(N, M, K)) return USIP_EINVAL;
     if (B == 0) return USIP_OK;
-    if (!dZ || !Y || !coef4 || !database || !query || !idx || !start || !perm || !dU || !dWc_part || B > 65535)
+    if (!dZ || !Y || !coef4 || !dcoord || !start || !perm || !dU || !dWc_part || B > 65535) return USIP_EINVAL;
+    if (((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dcoord)) & 15u) != 0)
         return USIP_EINVAL;
-    if (((reinterpret_cast<uintptr_t>(dZ) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(idx)) & 15u) != 0)
-        return USIP_EINVAL;
-    const long long P = (long long)M * K;
+    const int P = M * K;
     hipStream_t st = (hipStream_t)stream;
-    // two rows per workgroup when they fit 64 KiB of LDS
-    const bool two = 2 * P * 4 <= 65536 && Cout % 2 == 0;
+    // two rows and 512 threads per workgroup where they fit 64 KiB of LDS (two workgroups per CU); knob r5_forms bit 7
+    // (128): one row and 256 threads (five per CU by LDS) -- measured slower, 94 against 72 us at the step's shape
+    // (profiles/r06aj_knn_layer_kernels.txt)
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    // channel chunks per workgroup (they share the cloud's neighbour lists): as many as leave >= 2 workgroups per CU
+    int tpw = 1;
+    { const long long chunks = (long long)B * Cout / 2; while (tpw < 8 && chunks / (tpw * 2) >= 2LL * cus) tpw *= 2; }
+    const bool two = !(usip_tuning_value(USIP_TUNE_R5_FORMS) & 128) && 2LL * P * 4 <= 65536 && Cout % 2 == 0;
     if (two)
-        USIP_LAUNCH((knn_layer_bwd_kernel<2>), dim3(Cout / 2, B), dim3(KL_BT), (size_t)(2 * P) * sizeof(float), st,
-                    dZ, Y, coef4, relu, database, query, idx, start, perm, dU, dWc_part, Cout, N, M, K);
+        USIP_LAUNCH((knn_layer_bwd_kernel<2, 512>), dim3(usip_ceil_div(Cout / 2, tpw), B), dim3(512), (size_t)2 * P * sizeof(float), st,
+                    dZ, Y, coef4, relu, dcoord, start, perm, dU, dWc_part, Cout, N, P);
     else
-        USIP_LAUNCH((knn_layer_bwd_kernel<1>), dim3(Cout, B), dim3(KL_BT), (size_t)P * sizeof(float), st,
-                    dZ, Y, coef4, relu, database, query, idx, start, perm, dU, dWc_part, Cout, N, M, K);
+        USIP_LAUNCH((knn_layer_bwd_kernel<1, 256>), dim3(usip_ceil_div(Cout, tpw), B), dim3(256), (size_t)P * sizeof(float), st,
+                    dZ, Y, coef4, relu, dcoord, start, perm, dU, dWc_part, Cout, N, P);
     USIP_LAUNCH_CHECK();
     return USIP_OK;
 }

@@ -990,7 +990,8 @@ class _KnnFirstLayer(torch.autograd.Function):
                                              running_mean, running_var)
         y = _relu_hook(y, coef)
         start, perm = ops.csr_by_index(idx32.view(B, M * K), N)
-        ctx.save_for_backward(feat, database, query, idx32, w2, y, coef, mean, invstd, gamma, start, perm)
+        dcoord = ops.group_gather(database, idx32, sub=query)                      # [B,3,M,K], layers.py:428-430
+        ctx.save_for_backward(feat, dcoord, w2, y, coef, mean, invstd, gamma, start, perm)
         ctx.sink = sink
         ctx.mark_non_differentiable(coef)
         return y, coef
@@ -999,12 +1000,13 @@ class _KnnFirstLayer(torch.autograd.Function):
     def backward(ctx, dz, _dcoef):
         if dz is None:
             return (None,) * 13
-        feat, database, query, idx32, w2, y, coef, mean, invstd, gamma, start, perm = ctx.saved_tensors
+        feat, dcoord, w2, y, coef, mean, invstd, gamma, start, perm = ctx.saved_tensors
         sink = ctx.sink
         C = feat.shape[1]
         dz = dz.contiguous().view(y.shape)
         dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, True, sink)
-        dU, dwc = ops.knn_layer_backward(dz, y, coef4, True, database, query, idx32, start, perm)
+        dU, dwc = ops.knn_layer_backward(dz, y, coef4, True, dcoord.view(dcoord.shape[0], 3, -1), start, perm,
+                                         dcoord.shape[2], dcoord.shape[3])
         w2c = w2.contiguous()
         dfeat = dw = None
         if ctx.needs_input_grad[0]:

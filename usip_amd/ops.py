@@ -1205,28 +1205,28 @@ def knn_layer_forward(U, weight2, database, query, idx32, want_stats: bool = Tru
     _, M, K = idx32.shape
     Y = torch.empty((B, Cout, M * K), dtype=torch.float32, device=U.device)
     stats = torch.empty(2 * Cout * B, dtype=torch.float32, device=U.device) if want_stats else None
-    with torch.cuda.device(U.device), prof.kernel("knn_layer_fwd", 4.0 * B * M * K * (Cout + 1), 8.0 * B * Cout * M * K):
+    with torch.cuda.device(U.device), prof.kernel("knn_layer_fwd", 4.0 * B * (M * K * (Cout + 1) + Cout * N)):
         _lib.check(_lib.lib().usip_knn_layer_forward_f32(_ptr(U), _ptr(weight2), int(weight2.stride(0)), _ptr(database),
                                                          _ptr(query), _ptr(idx32), _ptr(Y), _opt(stats), B, Cout, N, M, K,
                                                          _stream(U)), "usip_knn_layer_forward_f32")
     return Y, stats
 
 
-def knn_layer_backward(dZ, Y, coef4, relu: bool, database, query, idx32, start, perm):
+def knn_layer_backward(dZ, Y, coef4, relu: bool, dcoord, start, perm, M: int, K: int):
     """-> (dU [B,Cout,N], dWc [Cout,3]): segment sums of dY = BN'(dZ, Y) in CSR list order, and the gradient of the three
-    coordinate columns of the weight (per-cloud partials added in cloud order)."""
+    coordinate columns of the weight (per-cloud partials added in cloud order).  dcoord [B,3,M*K] = the decentered
+    neighbour coordinates (group_gather(database, idx, sub=query))."""
     _need(dZ, "dZ", torch.float32)
     _need(Y, "Y", torch.float32)
+    _need(dcoord, "dcoord", torch.float32)
     B, Cout, P = Y.shape
-    _, M, K = idx32.shape
     N = start.shape[1] - 1
     dU = torch.empty((B, Cout, N), dtype=torch.float32, device=Y.device)
     part = torch.empty((B, Cout, 3), dtype=torch.float32, device=Y.device)
-    with torch.cuda.device(Y.device), prof.kernel("knn_layer_bwd", 4.0 * B * P * (2 * Cout + 1), 12.0 * B * Cout * P):
-        _lib.check(_lib.lib().usip_knn_layer_backward_f32(_ptr(dZ), _ptr(Y), _ptr(coef4), int(bool(relu)), _ptr(database),
-                                                          _ptr(query), _ptr(idx32), _ptr(start), _ptr(perm), _ptr(dU),
-                                                          _ptr(part), B, Cout, N, M, K, _stream(Y)),
-                   "usip_knn_layer_backward_f32")
+    with torch.cuda.device(Y.device), prof.kernel("knn_layer_bwd", 4.0 * B * (P * (2 * Cout + 3) + Cout * N)):
+        _lib.check(_lib.lib().usip_knn_layer_backward_f32(_ptr(dZ), _ptr(Y), _ptr(coef4), int(bool(relu)), _ptr(dcoord),
+                                                          _ptr(start), _ptr(perm), _ptr(dU), _ptr(part), B, Cout, N,
+                                                          int(M), int(K), _stream(Y)), "usip_knn_layer_backward_f32")
     return dU, part.sum(dim=0)
 
 
