@@ -971,7 +971,8 @@ def test_deferred_reductions_with_a_frozen_batchnorm_weight(monkeypatch):
     deferred mode that tensor was still unwritten (silent garbage) and the flush then wrote into freed memory.  Now such a
     weight gradient's fixed-order sum is launched at once (ops._reduce_now / usip_wgrad_defer_hold): every gradient of a
     step with one frozen BatchNorm weight in a wide layer and one in a narrow layer is the SAME BITS with and without the
-    deferred mode, the frozen layers' convolution weights included."""
+    deferred mode, the frozen layers' convolution weights included (round 6: also a pooled-concat layer of each kind and the
+    gathered first layer of the KNN fusion module, whose dW are assembled from two launches)."""
     from usip_amd import ops, synth
     from usip_amd.networks import DetectorOptions
     from usip_amd.step import DetectorStep, batch_to_device
@@ -982,7 +983,10 @@ def test_deferred_reductions_with_a_frozen_batchnorm_weight(monkeypatch):
         monkeypatch.setenv("USIP_DEFER_WGRAD", "1" if defer else "0")
         torch.manual_seed(17)
         st = DetectorStep("ball", opt, DEV)
-        frozen = [st.detector.knnlayer_1.layers_before[1].norm.weight, st.detector.conv2.norm.weight]
+        frozen = [st.detector.knnlayer_1.layers_before[1].norm.weight, st.detector.conv2.norm.weight,
+                  st.detector.conv4.norm.weight,                           # a pooled-concat layer (row-bias form)
+                  st.detector.knnlayer_1.layers_after[0].norm.weight,      # the same in the KNN fusion module
+                  st.detector.knnlayer_1.layers_before[0].norm.weight]     # the gathered first layer (csrc/knn_layer.hip)
         for p in frozen:                                    # after the bucket was built: these layers lose their sink
             p.requires_grad_(False)
             p.grad = None

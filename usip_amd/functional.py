@@ -757,21 +757,24 @@ class _SharedMLPLayerPooled(torch.autograd.Function):
         want = FUSED_NARROW_BWD and ctx.needs_input_grad[0] and ctx.needs_input_grad[4] and ctx.relu
         x2 = want and ops.layer_backward_x2_supported(Ch, Cout, M * K, (dz, y, h3), coef4, hcoef)
         fused = x2 or (want and ops.narrow_backward_supported(Ch, Cout, M * K, (dz, y, h3)))
+        # (a dW that is not a view of the step's gradient bucket goes back to autograd: its sums are launched at once)
         if fused:                                           # data and weight gradient of the feature half in one pass
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
             red = FUSED_NARROW_RED and hcoef is not None and hcoef.shape[0] >= 4
             back = ops.mlp_layer_backward_x2 if x2 else ops.mlp_narrow_backward      # f32x2 (csrc/layer_bwd_x2.hip) / fp32 MFMA
-            res = back(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch, want_red=red)
+            with ops.reduce_now(not sink):
+                res = back(dz, y, coef4, h3, hcoef, w2c, wcol=hoff, dw_out=dw, Cin=Ch, want_red=red)
+                ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
             if red:
                 _register_pre_bn_sums(res[0], [res[2]])
             dh = res[0].view(ctx.h_shape)
-            ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
         if ctx.needs_input_grad[0] and not fused:
             dh = _dgrad(h3, w2c, dz, pro=2, X2=y, coef=coef4, M=Ch, a_offset=hoff, xcoef=hcoef).view(ctx.h_shape)
         if ctx.needs_input_grad[4] and not fused:
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
-            ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff, xcoef=hcoef)
-            ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
+            with ops.reduce_now(not sink):
+                ops.mlp_wgrad(dz, h3, pro=2, G2=y, coef4=coef4, out=dw, coloff=hoff, xcoef=hcoef)
+                ops.mlp_wgrad(sdy, pooled, out=dw, coloff=poff)
         db = torch.zeros_like(gamma) if (ctx.needs_input_grad[5] and not sink) else None
         if sink:
             dw = db = dgamma = dbeta = None
@@ -1013,7 +1016,8 @@ class _KnnFirstLayer(torch.autograd.Function):
             dfeat = ops.mlp_gemm(w2c, dU, tag="dgrad_knn_nodes", M=C, a_offset=3)[0]     # W_f^T . dU
         if ctx.needs_input_grad[4]:
             dw = sink[0].view(w2c.shape) if sink else torch.empty_like(w2c)
-            ops.mlp_wgrad(dU, feat, out=dw, coloff=3)                                     # dU . feat^T -> columns 3..
+            with ops.reduce_now(not sink):                                                # (private dW: summed at once)
+                ops.mlp_wgrad(dU, feat, out=dw, coloff=3)                                 # dU . feat^T -> columns 3..
             dw[:, :3].copy_(dwc)
         db = torch.zeros_like(gamma) if (ctx.needs_input_grad[5] and not sink) else None  # in front of BatchNorm: zero
         if sink:
@@ -1038,8 +1042,7 @@ def knn_first_layer(feat, database, query, idx32, weight, bias, bn) -> "LazyAct"
     y, coef = _KnnFirstLayer.apply(feat, database.detach(), query.detach(), idx32, w2, bias, bn.weight, bn.bias,
                                    bn.running_mean, bn.running_var, bn.momentum, bn.eps,
                                    _sink(weight, bias, bn.weight, bn.bias))
-    B, _, M, K = (feat.shape[0], 0) + tuple(idx32.shape[1:])
-    return LazyAct(y, coef, True, (B, w2.shape[0], M, K))
+    return LazyAct(y, coef, True, (feat.shape[0], w2.shape[0], idx32.shape[1], idx32.shape[2]))
 
 
 class _ClusterBroadcast(torch.autograd.Function):

@@ -870,6 +870,9 @@ def mlp_wgrad(G, X, pro: int = 0, G2=None, coef4=None, out=None, coloff: int = 0
     return dW
 
 
+reduce_now = _reduce_now          # for callers that hand a PRIVATE destination through `out` / `dw_out` (functional.py)
+
+
 class RedSums:
     """What a fused layer backward leaves for the layer that produced its input: `sums` [2, blocks, C] partial
     BatchNorm-backward sums and `maxima` [blocks] of |dX [relu on]| -- views of one flat buffer."""
