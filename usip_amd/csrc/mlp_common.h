@@ -21,11 +21,11 @@ namespace usip_mlp {
 // ST_NARROW_FWD, ST_X2R, ST_X2F_FWD, ST_X2D, ST_LAYER_BWD_DX, LD_NARROW_FWD, LD_X3P_FWD, LD_WGRAD3_G; ST_TILE_EPI (+0.24:
 // conv1's output is read at once by conv2), ST_TILE_EPI_PLAIN (+0.06), LD_X2F_DGRAD (+0.03: the weight gradient re-reads
 // them), LD_X2R (+0.02), LD_WGRAD_X (+0.03: the previous layer's backward re-reads it), LD_LAYER_BWD_X (+0.03),
-// LD_BN_REDUCE_Z / _Y (the stand-alone BatchNorm-backward reduction: +0.00 / +0.01, both +0.03), LD_WGRAD_GEN_G (+0.02).
+// LD_BN_REDUCE_Z / _Y (the stand-alone BatchNorm-backward reduction: +0.00 / +0.01, both +0.03), LD_WGRAD_GEN_G (+0.02); ST_X2R split by launch (conv4's / conv5's output): -0.01 / 0.00.
 enum { ST_NARROW_FWD = 1, ST_X2R = 2, ST_TILE_EPI = 4, ST_X2F_FWD = 8, ST_X2F_DGRAD = 16, ST_X2D = 32, ST_LAYER_BWD_DX = 64,
        ST_WGRAD_PART = 128, LD_WGRAD_G = 256, ST_TILE_EPI_PLAIN = 512, LD_LAYER_BWD_G = 1024, LD_X2F_FWD = 2048,
        LD_X2F_DGRAD = 4096, LD_NARROW_FWD = 8192, LD_X2R = 16384, LD_WGRAD_X = 32768, LD_WGRAD3_G = 65536,
-       LD_X3P_FWD = 131072, LD_LAYER_BWD_X = 262144, LD_BN_REDUCE_Z = 524288, LD_BN_REDUCE_Y = 1048576, LD_WGRAD_GEN_G = 2097152 };
+       LD_X3P_FWD = 131072, LD_LAYER_BWD_X = 262144, LD_BN_REDUCE_Z = 524288, LD_BN_REDUCE_Y = 1048576, LD_WGRAD_GEN_G = 2097152, ST_X2R_PLAIN = 4194304 };
 #ifndef USIP_ST_NT
 #define USIP_ST_NT (ST_X2F_DGRAD | ST_WGRAD_PART | LD_WGRAD_G | LD_LAYER_BWD_G | LD_X2F_FWD)
 #endif

@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float v = __builtin_fmaf(acc[j][r], out_scale, bsh[ch]);
                     if (RB) v += rbs[RB ? (q / nslab) & 1 : 0][RB ? ch : 0][j];
                     if (pok && ch < a.M) {
-                        st_out<ST_X2R>(yb + (long long)ch * a.P + pp, v);
+                        st_out<RB ? ST_X2R : ST_X2R_PLAIN>(yb + (long long)ch * a.P + pp, v);
                         if (EPI == EPI_STATS) { s1[EPI == EPI_STATS ? r : 0] += v; s2[EPI == EPI_STATS ? r : 0] = __builtin_fmaf(v, v, s2[EPI == EPI_STATS ? r : 0]); }
                     }
                 }
