@@ -194,6 +194,23 @@ def test_fused_layer_backward_has_no_scratch(tmp_path):
     assert seen == 7
 
 
+def test_gathered_knn_layer_kernels_registers_and_streaming_loads(tmp_path):
+    """csrc/knn_layer.hip (round 6): no scratch; the backward reads (dZ, Y) -- their last use in the step -- with
+    non-temporal 16-byte loads and stays at two workgroups of eight waves per CU (<= 128 registers: the form with every
+    piece's loads ahead of the first use needed 210 and ran slower)."""
+    asm = _asm("knn_layer.hip", tmp_path)
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S*knn_layer_(?:fwd|bwd)_kernel\S*)", asm):
+        seg = asm[m.start():m.start() + 4000]
+        assert int(re.search(r"amdhsa_private_segment_fixed_size (\d+)", seg).group(1)) == 0, m.group(1)
+        assert int(re.search(r"amdhsa_next_free_vgpr (\d+)", seg).group(1)) <= 128, m.group(1)
+        seen += 1
+    assert seen == 3
+    for name, body in _functions(asm, "_ZN12_GLOBAL__N_120knn_layer_bwd_kernel"):
+        nt = sum(1 for ln in body if re.search(r"global_load_dwordx4 .* nt", ln))
+        assert nt >= 2, (name, nt)
+
+
 @pytest.mark.parametrize("src", sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "usip_amd", "csrc", "*.hip"))))
 def test_no_packed_fp32_instruction_selects_halves(src, tmp_path):
     """Packed fp32 arithmetic whose operands pick their halves with op_sel is what hipcc's SLP vectoriser emits when it

@@ -164,7 +164,10 @@ __global__ __launch_bounds__(NT) void knn_layer_bwd_kernel(
                 y4[u][c] = (KL_EXP & 4) ? make_float4(1.f, 2.f, 3.f, (float)p) : usip_load_stream4(Yp + off);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);                                 // all of the trip's loads in flight before the first use
+        __builtin_amdgcn_sched_barrier(0);
+        // (hipcc sinks the loads of pieces 1.. behind the `break` tests below, i.e. it keeps ONE piece's seven loads in flight
+        // and 64 registers.  Forcing all four pieces' 28 loads ahead of the first use -- branch-free clamped pieces -- was
+        // measured slower: 210 registers = one workgroup per CU, 84 us against 70; with two pieces 85 us.)
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int p = pb + u * NT * 4;
