@@ -28,6 +28,9 @@ namespace {
 #ifndef KL_EXP
 #define KL_EXP 0                      // measurement builds (tools/build_variant.py): 1 no pass 2, 2 no coordinate gradient, 4 no dZ/Y loads
 #endif
+#ifndef KL_ST_NT
+#define KL_ST_NT 0                    // 1: the forward's output stored non-temporal (measured: see profiles/r06z_nt_cache_policy_ab.txt)
+#endif
 constexpr int KL_FCH = 8;             // forward: channels per workgroup
 constexpr int KL_FT = 256;            // forward: threads
 
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(KL_FT) void knn_layer_fwd_kernel(
                 if (c0 + c >= Cout) break;
                 const float t = __builtin_fmaf(wz[c], dz[u], __builtin_fmaf(wy[c], dy[u], wx[c] * dx[u]));
                 const float y = us[c * N + n[u]] + t;
-                yb[(long long)c * P + p] = y;
+                if (KL_ST_NT) __builtin_nontemporal_store(y, yb + (long long)c * P + p); else yb[(long long)c * P + p] = y;
                 s1[c] += y;
                 s2[c] = __builtin_fmaf(y, y, s2[c]);
             }
