@@ -463,6 +463,20 @@ int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float
                                     const float* xcoef, const void* planes, float* dX, int dx_rows, float* workspace,
                                     float* dW, int lddw, float* red_partial, float* group_sums, int Cin, int Cout,
                                     int P, int nb, void* stream);
+/* The (Cin, Cout) = (64, 64) form with red_partial that ALSO takes, on the way, the sums from which the PRODUCING layer's
+ * weight gradient follows -- for a producing layer whose input S f32 [nb][ws_rows <= 8][P] needs no gradient (conv1 of
+ * RPN_Detector_Ball, models/networks.py:705; the first PointNet layer of RPN_Detector, layers.py:524-544): that layer's
+ * dW' = dY' . S^T with dY' = a1' dYhat' + q1' y' + q0' is linear in  S1 = sum_p dYhat' S_j,  S2 = sum_p (y' - mean') S_j,
+ * S3 = sum_p S_j, and this pass holds dYhat' = dX [relu on] and y' = X in LDS anyway.  wsum f32 [blocks][64][16]
+ * (S1 | S2, j < 8), wsum3 f32 [blocks][8], blocks = usip_mlp_layer_backward_x2h_blocks.  usip_mlp_wsum_finalize_f32
+ * combines them (fp64, fixed order) into dW'[c * lddw + j], j < ws_rows, once coef4' = usip_bn_backward_finalize_*_f32 of
+ * the same call's red_partial is known: the producing layer needs no pass of its own over its (dZ, Y). */
+int usip_mlp_layer_backward_x2h_ws_f32(const float* dZ, const float* Y, const float* coef4, const float* X, int x_rows,
+                                       const float* xcoef, const void* planes, float* dX, int dx_rows, float* workspace,
+                                       float* dW, int lddw, float* red_partial, const float* wsrc, int ws_rows,
+                                       float* wsum, float* wsum3, int Cin, int Cout, int P, int nb, void* stream);
+int usip_mlp_wsum_finalize_f32(const float* wsum, const float* wsum3, int blocks, int C, const float* coef4,
+                               const float* mean, int ws_rows, float* dW, int lddw, void* stream);
 int usip_bn_backward_finalize_f32(const float* partial, int rows, int C, long long count, const float* coef_fwd,
                                   const float* mean, const float* invstd, float* dgamma, float* dbeta, float* coef4,
                                   void* stream);

@@ -1283,3 +1283,45 @@ def test_bench_two_ranks_graph_replay_on_one_gpu(tmp_path):
     # (RCCL's collectives can be captured, and then the whole step is ONE graph: usip_amd/step.py.  That form needs one
     # device per rank and cannot run on this 1-GPU box; a gloo all-reduce inside a capture aborts the process, so the
     # attempt is made with backend "nccl" only, and a refused capture falls back to this two-graph form.)
+
+
+@pytest.mark.parametrize("model,first", [("ball", "conv1.conv.weight"), ("som", "first_pointnet.layers.0.conv.weight")])
+def test_first_layer_weight_gradient_from_the_next_layers_fused_backward(model, first, monkeypatch):
+    """Round 6: the detector's first layer (7 -> 64, input without a gradient) no longer makes a pass over its own (dZ, Y):
+    dW = dY . S^T with dY = a1 dYhat + q1 (y - mu) + (q1 mu + q0) is linear in three sums which the fused backward of the
+    SECOND layer takes while it holds (dYhat, y) of the first in LDS (csrc/layer_bwd_x2.hip, WS; ops.wsum_finalize).  Same
+    forward, so every other gradient is the same bits with and without it, and the first layer's weight gradient agrees to
+    fp32 summation order."""
+    from usip_amd import ops, prof, synth
+    from usip_amd.networks import DetectorOptions
+    from usip_amd.step import DetectorStep, batch_to_device
+    prev_mode = ops.set_matmul_mode("f32x2")
+    opt = DetectorOptions(surface_normal_len=4, node_knn_k_1=8)
+    batch = batch_to_device(synth.make_pair_batch(31, 2, 2048, 64, 4, "sphere"), DEV)
+
+    def run(on):
+        monkeypatch.setattr(ops, "WSUM", on)
+        torch.manual_seed(11)
+        st = DetectorStep(model, opt, DEV)
+        prof.reset()
+        prof.enable(True)
+        try:
+            st.step(batch)
+            names = set(prof.summary())
+        finally:
+            prof.enable(False)
+            prof.reset()
+        return {k: p.grad.detach().clone() for k, p in st.detector.named_parameters()}, names
+
+    try:
+        g1, n1 = run(True)
+        g0, n0 = run(False)
+    finally:
+        ops.set_matmul_mode(prev_mode)
+    assert "wsum_finalize" in n1 and "wsum_finalize" not in n0
+    assert "shared_mlp_wgrad 64x7" in n0 and "shared_mlp_wgrad 64x7" not in n1
+    for k in g0:
+        if k == first:
+            assert_close(g1[k].cpu().numpy(), g0[k].cpu().numpy(), rel=2e-6, name=k)
+        else:
+            assert torch.equal(g1[k], g0[k]), k

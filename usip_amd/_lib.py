@@ -114,6 +114,10 @@ SIGNATURES = {
     "usip_mlp_layer_backward_x2h_f32": ([_f32p, _f32p, _f32p, _f32p, _i32p, _int, _f32p, _int, _f32p, ctypes.c_void_p,
                                          _f32p, _int, _f32p, _f32p, _int, _f32p, _f32p, _int, _int, _int, _int, _stream],
                                         _int),
+    "usip_mlp_layer_backward_x2h_ws_f32": ([_f32p, _f32p, _f32p, _f32p, _int, _f32p, ctypes.c_void_p, _f32p, _int, _f32p,
+                                            _f32p, _int, _f32p, _f32p, _int, _f32p, _f32p, _int, _int, _int, _int, _stream],
+                                           _int),
+    "usip_mlp_wsum_finalize_f32": ([_f32p, _f32p, _int, _int, _f32p, _f32p, _int, _f32p, _int, _stream], _int),
     "usip_mlp_narrow_backward_f32": ([_f32p, _f32p, _f32p, _f32p, _int, _f32p, _f32p, _int, _f32p, _int, _f32p, _f32p,
                                       _int, _f32p, _int, _int, _int, _int, _stream], _int),
     "usip_bn_backward_finalize_f32": ([_f32p, _int, _int, ctypes.c_longlong, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p,

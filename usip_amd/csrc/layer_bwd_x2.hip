@@ -44,6 +44,12 @@ struct LayerBwdArgs {
     float* red;                                                // RED: [2][workgroups][CIN] sums, then [workgroups] maxima
     float* gsum;                                               // RED + POOL, may be null: [2][nb * CIN][P / pool_group] per-neighbourhood sums
     int P, nb;
+    // WS (round 6): the PRODUCING layer's weight gradient on the way.  That layer's input S [nb][ws_rows <= 8][P] needs no
+    // gradient (the detector's first layer), so all its backward still has to do is dW' = dY' . S^T with
+    // dY' = a1' dYhat' + q1' (x - mu') + (q1' mu' + q0') -- linear in three sums this pass can take while it holds
+    // dYhat' = dX [relu on] and x in LDS anyway:  wsum [workgroups][CIN][16] = sum_p dYhat' S_j | sum_p (x - mu') S_j
+    // (j < 8), wsum3 [workgroups][8] = sum_p S_j.  usip_mlp_wsum_finalize_f32 combines them once that layer's coef4 is known.
+    const float* wsrc; int ws_rows; float* wsum; float* wsum3;
 };
 
 // byte offset of (row, position) in a [rows][BP positions] fp16 image: rows of BP * 2 + 16 bytes
@@ -59,9 +65,10 @@ __device__ __forceinline__ int rows_off(int row, int pos) { return row * (BP * 2
 // changed nothing in time but frees 15 registers).
 // SPLIT: the first half of the waves does the data gradient (and holds the weight fragments), the second half the weight
 // gradient (and holds its accumulators) -- the two register-hungry roles no longer add up in every wave.
-template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwdArgs a)
+template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG, bool SPLIT, bool WS>
+__device__ __forceinline__ void layer_bwd_x2_body(const LayerBwdArgs& a)
 {
+    static_assert(!WS || (RED && !DB && !POOL && BP == 32 && CIN * BP / 8 == 64 * NW), "WS: the single-buffer RED form, 8 threads per source piece row");
     constexpr int NT = 64 * NW;
     constexpr int GC = COUT * BP / NT;                         // output channels per (dZ, Y) loader thread: 8 or 16
     constexpr bool EARLY = (GC == 8) && !(RED && DB);          // next tile's loads re-issued inside write_tile (else: register pressure)
@@ -82,6 +89,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     __shared__ float cfX[2][CIN];
     __shared__ float redm[2][NW];
     __shared__ unsigned poolv[PG ? 2 : 1][2][PG ? COUT : 1];    // PG: [tile parity][dpooled | arg][channel]
+    __shared__ __attribute__((aligned(16))) float GS[WS ? 2 : 1][WS ? 8 : 1][WS ? BP : 4];   // WS: [tile parity][source row][position]
     static_assert(!PG || (POOL && 2 * COUT <= NT), "PG");
     // RED: the tile of dX for the sums' pass -- one buffer behind an fp32 copy of the X tile (XR), or, with two LDS buffers
     // per tile (DB), two dX buffers and the raw X tile kept in registers instead
@@ -136,6 +144,13 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
     float s1 = 0.f, s2 = 0.f, mx = 0.f;                        // RED: the thread's channel (its X row), its 8 positions of every tile
     float rxk[(RED && DB) ? 2 : 1][8];                         // RED + DB: the raw X of the tiles in the two LDS buffers
     float gd = 0.f, gy = 0.f;                                  // per-neighbourhood sums of the current run (a.gsum)
+    typedef float ws_f32x2 __attribute__((ext_vector_type(2)));
+    ws_f32x2 wSa[WS ? 8 : 1], wSb[WS ? 8 : 1];                 // WS: S1_j, S2_j of this thread's channel, each as (even, odd) positions: packed FMAs on
+                                                               // natural register pairs (no half is selected or swapped: tests/test_kernel_isa.py)
+    float wS3 = 0.f;
+    float4 rgs = make_float4(0.f, 0.f, 0.f, 0.f);              // WS: threads [0, 64): 4 positions of one source row of the next tile
+#pragma unroll
+    for (int j = 0; j < (WS ? 8 : 1); ++j) { wSa[j] = ws_f32x2{0.f, 0.f}; wSb[j] = ws_f32x2{0.f, 0.f}; }
 
     // loaders.  (dZ, Y): thread -> position gp of the tile, the GC output channels [GC gg, GC gg + GC); buffer loads with
     // the row as a scalar offset.  X: thread -> 8 consecutive positions (piece xq) of row xr0 (+ XRP per pass).
@@ -186,6 +201,11 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             rx[q][0] = u.x; rx[q][1] = u.y; rx[q][2] = u.z; rx[q][3] = u.w;
             rx[q][4] = v.x; rx[q][5] = v.y; rx[q][6] = v.z; rx[q][7] = v.w;
         }
+        if (WS && tid < 64) {                                  // row tid / 8, positions 4 (tid % 8) .. + 3 (rows beyond ws_rows: zeros)
+            const int j = tid >> 3;
+            rgs = (j < a.ws_rows) ? *reinterpret_cast<const float4*>(a.wsrc + ((long long)bb * a.ws_rows + j) * a.P + p0 + 4 * (tid & 7))
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     };
     // One tile from the prefetched registers into LDS.  The loads of the NEXT tile (the last tile: a harmless repeat) are re-issued as soon as
     // a register group has been consumed -- in front of the splits and the LDS writes, not behind them: with the loads
@@ -205,6 +225,7 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
         unsigned char* G1 = smem + buf * BUF;
         unsigned char* G2 = G1 + 2 * PL1;
         unsigned char* X2 = G2 + 2 * PL2;
+        if (WS && tid < 64) *reinterpret_cast<float4*>(&GS[WS ? tcur & 1 : 0][WS ? tid >> 3 : 0][WS ? 4 * (tid & 7) : 0]) = rgs;
         // act(X) first: its temporaries are dead before the 2 GC values of dY come to life
         if (RED && DB) {
 #pragma unroll
@@ -287,13 +308,30 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
                 x4 = reinterpret_cast<const float4*>(xbase_l)[h];
             }
             const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+            float dm[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float d = (__builtin_fmaf(xv[i], rsc, rsh) > 0.f) ? dv[i] : 0.f;
+                dm[i] = d;
                 s1 += d;
                 s2 = __builtin_fmaf(d, (xv[i] - rmu) * ris, s2);
                 mx = fmaxf(mx, fabsf(d));
                 if (POOL) { gd += d; gy += xv[i]; }
+            }
+            if (WS && tp >= 0) {                               // (tp < 0: the zero tile in front of the first one)
+                const ws_f32x2 d01 = {dm[0], dm[1]}, d23 = {dm[2], dm[3]};
+                const ws_f32x2 x01 = {xv[0] - rmu, xv[1] - rmu}, x23 = {xv[2] - rmu, xv[3] - rmu};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(&GS[WS ? tp & 1 : 0][WS ? j : 0][WS ? xq * 8 + 4 * h : 0]);
+                    const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
+                    const ws_f32x2 g01 = {g4.x, g4.y}, g23 = {g4.z, g4.w};
+                    wSa[WS ? j : 0] = __builtin_elementwise_fma(d01, g01, wSa[WS ? j : 0]);        // v_pk_fma_f32
+                    wSa[WS ? j : 0] = __builtin_elementwise_fma(d23, g23, wSa[WS ? j : 0]);
+                    wSb[WS ? j : 0] = __builtin_elementwise_fma(x01, g01, wSb[WS ? j : 0]);
+                    wSb[WS ? j : 0] = __builtin_elementwise_fma(x23, g23, wSb[WS ? j : 0]);
+                    if (xr0 == j) wS3 += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+                }
             }
         }
         if (POOL && a.gsum && tp >= 0 && (tp % tpg) == tpg - 1) {
@@ -465,6 +503,26 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             a.red[(long long)blockIdx.x * CIN + xr0] = s1;
             a.red[(nblk + blockIdx.x) * CIN + xr0] = s2;
         }
+        if (WS) {
+            float wS1[8], wS2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wS1[j] = wSa[WS ? j : 0].x + wSa[WS ? j : 0].y; wS2[j] = wSb[WS ? j : 0].x + wSb[WS ? j : 0].y;
+#pragma unroll
+                for (int off = 1; off < XPC; off <<= 1) {
+                    wS1[j] += __shfl_xor(wS1[j], off);
+                    wS2[j] += __shfl_xor(wS2[j], off);
+                }
+            }
+#pragma unroll
+            for (int off = 1; off < XPC; off <<= 1) wS3 += __shfl_xor(wS3, off);
+            if (xq == 0) {
+                float* o = a.wsum + ((long long)blockIdx.x * CIN + xr0) * 16;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = wS1[j]; o[8 + j] = wS2[j]; }
+                if (xr0 < 8) a.wsum3[(long long)blockIdx.x * 8 + xr0] = wS3;
+            }
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
         __syncthreads();
@@ -477,6 +535,55 @@ __global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwd
             for (int w = 0; w < NW; ++w) m = fmaxf(m, rs[w]);
             a.red[2 * nblk * CIN + blockIdx.x] = m;
         }
+    }
+}
+
+template <int CIN, int COUT, bool POOL, bool RED, int NW, int BP, bool DB, bool PG = false, bool SPLIT = false>
+__global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2_kernel(const LayerBwdArgs a)
+{
+    layer_bwd_x2_body<CIN, COUT, POOL, RED, NW, BP, DB, PG, SPLIT, false>(a);
+}
+
+// ... and with the producing layer's weight-gradient sums taken on the way (LayerBwdArgs::wsrc)
+template <int CIN, int COUT, int NW, int BP>
+__global__ __launch_bounds__(64 * NW, 2) void layer_bwd_x2ws_kernel(const LayerBwdArgs a)
+{
+    layer_bwd_x2_body<CIN, COUT, false, true, NW, BP, false, false, false, true>(a);
+}
+
+// WS: dW'[c][j] = a1' S1 + q1' S2 + (q1' mu' + q0') S3 from the per-workgroup sums (see LayerBwdArgs).  One workgroup per
+// channel; thread -> (source row j = tid % 8, slice tid / 8 of the workgroups); fp64, fixed order.
+__global__ __launch_bounds__(256) void wsum_finalize_kernel(
+    const float* __restrict__ wsum, const float* __restrict__ wsum3, int blocks, int C, const float* __restrict__ coef4,
+    const float* __restrict__ mean, int ws_rows, float* __restrict__ dW, int lddw)
+{
+    __shared__ double red[3][32][8];
+    const int c = blockIdx.x, j = threadIdx.x & 7, sl = threadIdx.x >> 3;
+    const int per = (blocks + 31) / 32, b0 = sl * per, b1 = min(blocks, b0 + per);
+    double s1 = 0, s2 = 0, s3 = 0;
+    int b = b0;
+    for (; b + 7 < b1; b += 8) {                               // 24 loads in flight (one at a time: a chain of L2 round trips, 10 us)
+        float u[8], v[8], w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float* o = wsum + ((long long)(b + i) * C + c) * 16;
+            u[i] = o[j]; v[i] = o[8 + j]; w[i] = wsum3[(long long)(b + i) * 8 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1 += (double)u[i]; s2 += (double)v[i]; s3 += (double)w[i]; }
+    }
+    for (; b < b1; ++b) {
+        const float* o = wsum + ((long long)b * C + c) * 16;
+        s1 += (double)o[j]; s2 += (double)o[8 + j]; s3 += (double)wsum3[(long long)b * 8 + j];
+    }
+    red[0][sl][j] = s1; red[1][sl][j] = s2; red[2][sl][j] = s3;
+    __syncthreads();
+    if (threadIdx.x < 8 && j < ws_rows) {
+        double t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) { t1 += red[0][g][j]; t2 += red[1][g][j]; t3 += red[2][g][j]; }
+        const float a1 = coef4[c], q1 = coef4[2 * C + c], q0 = coef4[3 * C + c], mu = mean[c];
+        dW[(long long)c * lddw + j] = (float)((double)a1 * t1 + (double)q1 * t2 + (double)__builtin_fmaf(q1, mu, q0) * t3);
     }
 }
 
@@ -528,11 +635,12 @@ extern "C" long long usip_mlp_layer_backward_x2h_workspace(int Cin, int Cout, in
 // usip_mlp_layer_backward_x2h_workspace floats.  red_partial (may be NULL): receives [2][blocks][Cin] partial sums of the
 // producing layer's BatchNorm backward against dX, then [blocks] maxima of |dX [relu on]|
 // (usip_bn_backward_finalize_f32 with a maxima pointer turns them into that layer's [5][Cin] coef4).
-extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
-                                               const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
-                                               const float* xcoef, const void* planes, float* dX, int dx_rows,
-                                               float* workspace, float* dW, int lddw, float* red_partial,
-                                               float* group_sums, int Cin, int Cout, int P, int nb, void* stream)
+static int layer_backward_x2h(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
+                              const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
+                              const float* xcoef, const void* planes, float* dX, int dx_rows,
+                              float* workspace, float* dW, int lddw, float* red_partial,
+                              float* group_sums, int Cin, int Cout, int P, int nb, const float* wsrc, int ws_rows,
+                              float* wsum, float* wsum3, void* stream)
 {
     const bool pooled = pool_dp != nullptr;
     if (!usip_mlp_layer_backward_x2h_supported(Cin, Cout, P, pooled ? 1 : 0) || nb < 1 || x_rows < Cin || dx_rows < Cin ||
@@ -545,8 +653,11 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
          reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(planes)) & 15u)
         return USIP_EINVAL;
     const int blocks = layer_bwd_blocks(Cin, Cout, P, nb);
+    if (wsrc && (!wsum || !wsum3 || !red_partial || pooled || Cin != 64 || Cout != 64 || ws_rows < 1 || ws_rows > 8 ||
+                 (reinterpret_cast<uintptr_t>(wsrc) & 15u)))
+        return USIP_EINVAL;
     LayerBwdArgs a{dZ, Y, coef4, pool_dp, pool_arg, pool_group, X, x_rows, xcoef, reinterpret_cast<const uint4*>(planes),
-                   dX, dx_rows, workspace, red_partial, group_sums, P, nb};
+                   dX, dx_rows, workspace, red_partial, group_sums, P, nb, wsrc, ws_rows, wsum, wsum3};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks);
     const bool red = red_partial != nullptr;
@@ -556,7 +667,8 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
         if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 128, false, true, 4, 32, false, false, true>), grid, dim3(256), 0, st, a);
         else USIP_LAUNCH((layer_bwd_x2_kernel<64, 128, false, false, 4, 32, false, false, true>), grid, dim3(256), 0, st, a);
     } else if (Cin == 64) {
-        if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
+        if (red && wsrc) USIP_LAUNCH((layer_bwd_x2ws_kernel<64, 64, 4, 32>), grid, dim3(256), 0, st, a);
+        else if (red) USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, true, 4, 32, false>), grid, dim3(256), 0, st, a);
         else USIP_LAUNCH((layer_bwd_x2_kernel<64, 64, false, false, 4, 32, false>), grid, dim3(256), 0, st, a);
     } else {
         // (the single-buffer form with 64-position tiles measured the same, 224-230 us at 16 x 32768 positions, and
@@ -571,4 +683,45 @@ extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, 
     }
     USIP_LAUNCH_CHECK();
     return usip_mlp::launch_wgrad_reduce(workspace, dW, (long long)Cout * Cin, blocks, Cin, lddw, 0, st);
+}
+
+extern "C" int usip_mlp_layer_backward_x2h_f32(const float* dZ, const float* Y, const float* coef4, const float* pool_dp,
+                                               const int32_t* pool_arg, int pool_group, const float* X, int x_rows,
+                                               const float* xcoef, const void* planes, float* dX, int dx_rows,
+                                               float* workspace, float* dW, int lddw, float* red_partial,
+                                               float* group_sums, int Cin, int Cout, int P, int nb, void* stream)
+{
+    return layer_backward_x2h(dZ, Y, coef4, pool_dp, pool_arg, pool_group, X, x_rows, xcoef, planes, dX, dx_rows, workspace, dW,
+                              lddw, red_partial, group_sums, Cin, Cout, P, nb, nullptr, 0, nullptr, nullptr, stream);
+}
+
+// The (64, 64) form with red_partial that ALSO takes the sums from which the PRODUCING layer's weight gradient follows,
+// for a producing layer whose input S [nb][ws_rows <= 8][P] needs no gradient (conv1 of RPN_Detector_Ball, the first
+// PointNet layer of RPN_Detector: models/networks.py:705, layers.py:524-544): wsum [blocks][64][16], wsum3 [blocks][8]
+// (blocks = usip_mlp_layer_backward_x2h_blocks) -- see usip_mlp_wsum_finalize_f32.  That layer then needs no pass of its
+// own over its (dZ, Y).
+extern "C" int usip_mlp_layer_backward_x2h_ws_f32(const float* dZ, const float* Y, const float* coef4, const float* X,
+                                                  int x_rows, const float* xcoef, const void* planes, float* dX,
+                                                  int dx_rows, float* workspace, float* dW, int lddw, float* red_partial,
+                                                  const float* wsrc, int ws_rows, float* wsum, float* wsum3,
+                                                  int Cin, int Cout, int P, int nb, void* stream)
+{
+    if (!wsrc) return USIP_EINVAL;
+    return layer_backward_x2h(dZ, Y, coef4, nullptr, nullptr, 0, X, x_rows, xcoef, planes, dX, dx_rows, workspace, dW, lddw,
+                              red_partial, nullptr, Cin, Cout, P, nb, wsrc, ws_rows, wsum, wsum3, stream);
+}
+
+// dW[c * lddw + j] (j < ws_rows) = coef4[0][c] S1[c][j] + coef4[2][c] S2[c][j] + (coef4[2][c] mean[c] + coef4[3][c]) S3[j]
+// with S* = the sums of usip_mlp_layer_backward_x2h_ws_f32 over its `blocks` workgroups (fp64, fixed order): the weight
+// gradient dY . S^T of a training-mode BatchNorm layer with C = 64 channels whose dY = coef4[0] dYhat + coef4[2] y +
+// coef4[3] (coef4 = what usip_bn_backward_finalize_*_f32 made of the same call's red_partial; mean = its batch mean).
+extern "C" int usip_mlp_wsum_finalize_f32(const float* wsum, const float* wsum3, int blocks, int C, const float* coef4,
+                                          const float* mean, int ws_rows, float* dW, int lddw, void* stream)
+{
+    if (!wsum || !wsum3 || !coef4 || !mean || !dW || blocks < 1 || C < 1 || ws_rows < 1 || ws_rows > 8 || lddw < ws_rows)
+        return USIP_EINVAL;
+    USIP_LAUNCH(wsum_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, wsum, wsum3, blocks, C, coef4, mean,
+                ws_rows, dW, lddw);
+    USIP_LAUNCH_CHECK();
+    return USIP_OK;
 }

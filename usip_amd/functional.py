@@ -382,8 +382,11 @@ class LazyAct:
     to or read back from HBM.  `y` is the autograd-tracked tensor and STANDS FOR the activated output:
     gradients flowing into it are gradients w.r.t. the activated output."""
 
-    def __init__(self, y: torch.Tensor, coef: torch.Tensor, relu: bool, shape):
+    def __init__(self, y: torch.Tensor, coef: torch.Tensor, relu: bool, shape, wsrc=None):
         self.y, self.coef, self.relu, self.shape = y, coef, relu, tuple(shape)
+        # the gradient-free INPUT [nb, <= 8, P] of the layer that produced y (the detector's first layer), when the
+        # consumer's fused backward may take that layer's weight-gradient sums on its way (ops.wsum_supported)
+        self.wsrc = wsrc
 
     def materialize(self) -> torch.Tensor:
         return _Materialize.apply(self.y, self.coef, self.relu).view(self.shape)
@@ -430,7 +433,7 @@ def _take_pre_bn_sums(dz, shape=None):
     return pre
 
 
-def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
+def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0, took=None):
     """(dgamma, dbeta, coef4[, gsum]) of this layer: from partial sums its gradient's producer already took
     (PRE_BN_SUMS), else by the stand-alone reduction pass over (dZ, y).
     (Folding these sums into the consuming layer's data-gradient GEMM epilogue for the MFMA-bound layers was
@@ -438,6 +441,8 @@ def _own_bn_backward(dz, y, coef, mean, invstd, gamma, relu, sink, group=0):
     go, bo = (sink[2], sink[3]) if sink else (None, None)
     pre = _take_pre_bn_sums(dz)                  # removed even when this layer cannot use them
     if pre is not None and group == 0 and relu:
+        if took is not None:
+            took.extend(pre[1])                  # (the caller looks for RedSums.wsum)
         return ops.bn_backward_from_partials(pre[1], dz.shape[0] * dz.shape[2], coef, mean, invstd, go, bo)
     if pre is not None and group and relu and len(pre[1]) == 1:
         # a pooled-concat layer: the producer (the fused backward of a max-pooled layer) also took the
@@ -490,9 +495,10 @@ class _SharedMLPLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, xcoef, w2, bias, gamma, beta, running_mean, running_var, training, momentum, eps,
-                relu, defer, sink, nograd_prefix=0):
+                relu, defer, sink, nograd_prefix=0, wsrc=None):
         ctx.sink = sink
         ctx.nograd_prefix = int(nograd_prefix)
+        ctx.wsrc = wsrc                      # (an input tensor of the step: alive for its whole duration)
         ctx.set_materialize_grads(False)     # no zero-filled gradient for the (non-differentiable) coef output
         x = x.contiguous()
         # K-major copy of the weight [Cin][Cout]: the GEMM can also read W transposed in place (negative lda),
@@ -530,10 +536,10 @@ class _SharedMLPLayer(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz, _dcoef):
         if dz is None:
-            return (None,) * 15
+            return (None,) * 16
         dz = dz.contiguous()
         need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
-        tail = (None,) * 9
+        tail = (None,) * 10
         sink = ctx.sink                      # (w.grad, b.grad[, gamma.grad, beta.grad]) or None
         if not ctx.has_bn:
             x, xcoef, w2 = ctx.saved_tensors
@@ -552,7 +558,8 @@ class _SharedMLPLayer(torch.autograd.Function):
         if not ctx.train_stats:
             raise NotImplementedError("usip_amd: backward through eval-mode BatchNorm is outside the path")
         x, xcoef, w2, y, coef, mean, invstd, gamma = ctx.saved_tensors
-        dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink)
+        took = []
+        dgamma, dbeta, coef4 = _own_bn_backward(dz, y, coef, mean, invstd, gamma, ctx.relu, sink, took=took)
         if not ctx.relu:
             # BatchNorm with no ReLU behind it: only the generic form of a layer built with a non-default activation
             # (layers._generic_forward).  The GEMM prologues rebuild dY WITH the ReLU decision (mlp_common.h::pro_apply),
@@ -575,7 +582,8 @@ class _SharedMLPLayer(torch.autograd.Function):
             red = FUSED_NARROW_RED and xcoef is not None and xcoef.shape[0] >= 4   # input = lazy activation of a train-mode BN layer
             if x2:                                           # f32x2 with the operand bounds at hand: csrc/layer_bwd_x2.hip
                 res = ops.mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2.contiguous(), Cin=x.shape[1],
-                                                dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
+                                                dw_out=sink[0].view(w2.shape) if sink else None, want_red=red,
+                                                wsrc=ctx.wsrc if red else None)
             else:
                 res = ops.mlp_narrow_backward(dz, y, coef4, x, xcoef, w2.contiguous(),
                                               dw_out=sink[0].view(w2.shape) if sink else None, want_red=red)
@@ -601,8 +609,16 @@ class _SharedMLPLayer(torch.autograd.Function):
                 dx = _dgrad(x, w2.contiguous(), dz, pro=2, X2=y, coef=coef4, xcoef=xcoef)
         dw = None
         if need_w:
-            dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef,
-                               out=sink[0].view(w2.shape) if sink else None)
+            # the detector's first layer (gradient-free input of <= 8 rows): the fused backward of the NEXT layer took the
+            # sums dW follows from while it had (dYhat, y) of this one in LDS (csrc/layer_bwd_x2.hip, WS) -- no pass over
+            # this layer's (dZ, Y) at all
+            pack = took[0].wsum if (len(took) == 1 and getattr(took[0], "wsum", None) is not None) else None
+            if (pack is not None and not need_x and xcoef is None and pack[2].data_ptr() == x.data_ptr()
+                    and tuple(pack[2].shape) == tuple(x.shape) and w2.shape[1] == x.shape[1] and w2.is_contiguous()):
+                dw = ops.wsum_finalize(pack, coef4, mean, sink[0].view(w2.shape) if sink else torch.empty_like(w2))
+            else:
+                dw = ops.mlp_wgrad(dz, x, pro=2, G2=y, coef4=coef4, xcoef=xcoef,
+                                   out=sink[0].view(w2.shape) if sink else None)
         db = torch.zeros_like(gamma) if (ctx.needs_input_grad[3] and not sink) else None
         if sink:
             dw = db = dgamma = dbeta = None  # written in place; the bias gradient is the zero already there
@@ -820,12 +836,12 @@ def conv1x1_bn_act(x, weight: torch.Tensor, bias: Optional[torch.Tensor],
     defer=True (BatchNorm layers only) returns a LazyAct instead of the activated tensor.
     nograd_prefix: the first so many input channels need no gradient (their rows of dX are zeros, not computed)."""
     shape = x.shape
-    xcoef = None
+    xcoef = wsrc_in = None
     if isinstance(x, LazyAct):
         if not x.relu:
             x = x.materialize()
         else:
-            x, xcoef = x.y, x.coef
+            x, xcoef, wsrc_in = x.y, x.coef, x.wsrc
     require_device(x, "the shared MLP")
     w2 = weight.reshape(weight.shape[0], weight.shape[1])
     x3 = x.reshape(shape[0], shape[1], -1)
@@ -839,8 +855,14 @@ def conv1x1_bn_act(x, weight: torch.Tensor, bias: Optional[torch.Tensor],
         bn.num_batches_tracked.add_(1)
     y, coef = _SharedMLPLayer.apply(x3, xcoef, w2, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                     training, bn.momentum, bn.eps, relu, defer,
-                                    _sink(weight, bias, bn.weight, bn.bias) if training else None, nograd_prefix)
-    return LazyAct(y, coef, relu, oshape) if defer else y.view(oshape)
+                                    _sink(weight, bias, bn.weight, bn.bias) if training else None, nograd_prefix, wsrc_in)
+    if not defer:
+        return y.view(oshape)
+    # a first layer (plain input of <= 8 rows that needs no gradient): its consumer's fused backward may take this layer's
+    # weight-gradient sums on the way (LazyAct.wsrc)
+    first = (training and relu and xcoef is None and not x3.requires_grad and x3.shape[1] <= 8 and x3.is_contiguous()
+             and torch.is_grad_enabled())
+    return LazyAct(y, coef, relu, oshape, wsrc=x3 if first else None)
 
 
 # --------------------------------------------------------------------------- grouping / pooling

@@ -886,6 +886,7 @@ class RedSums:
         self.sums = flat[:2 * blocks * C].view(2, blocks, C)
         self.maxima = flat[2 * blocks * C:]
         self.gsum = None                     # per-neighbourhood sums [2,nb,C,G], when the producer took them too
+        self.wsum = None                     # (wsum, wsum3, source tensor): the producing layer's weight-gradient sums (WSUM)
 
 
 def narrow_backward_supported(Cin: int, Cout: int, P: int, tensors=()) -> bool:
@@ -962,12 +963,14 @@ LAYER_BWD_X2 = _os.environ.get("USIP_LAYER_BWD_X2", "1") not in ("0", "off")
 
 
 def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None, Cin: int = 64, want_red: bool = False,
-                          pool=None, want_gsum: bool = False):
+                          pool=None, want_gsum: bool = False, wsrc=None):
     """Fused backward of a <= 128-wide layer with f32x2 products (csrc/layer_bwd_x2.hip): -> (dx [nb,Cin,P], dW[, red]).
     Arguments as mlp_narrow_backward; coef4 [5,Cout] (with bounds), xcoef [4,Cin]; pool = (dpooled [nb,Cout,G],
     arg i32 [nb,Cout,G], group) with dz None for the pooled form.  red: a RedSums (partial sums [2, blocks, Cin] and the
     workgroups' maxima of |dx [relu on]|); want_gsum (pooled form with red, group % 32 == 0): red.gsum [2,nb,Cin,G] =
-    the per-neighbourhood sums of dx [relu on] and of x that bn_backward_reduce(group=...) would return."""
+    the per-neighbourhood sums of dx [relu on] and of x that bn_backward_reduce(group=...) would return.
+    wsrc ([nb, <= 8, P], the gradient-free INPUT of the layer that produced x; (64, 64) form with want_red): red.wsum = the
+    sums that layer's weight gradient follows from (wsum_finalize) -- it then needs no pass over its own (dZ, Y)."""
     nb, Cout, P = y.shape
     dev = y.device
     for t, n in ((y, "y"), (x, "x"), (w2, "w2"), (coef4, "coef4"), (xcoef, "xcoef")):
@@ -993,6 +996,10 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     else:
         _need(dz, "dz", torch.float32)
     pg = pool is not None and group % 32 == 0
+    wsum = wsum3 = None
+    if want_red and wsum_supported(wsrc, Cin, Cout, P, pool is not None):
+        wsum = torch.empty((blocks, Cin, 16), dtype=torch.float32, device=dev)
+        wsum3 = torch.empty((blocks, 8), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev), _reduce_now(dw_out is None), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
                                              4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin),
                                              4.0 * Cout * Cin * nb * P,
@@ -1002,15 +1009,46 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
                                                  "true" if (Cin == 128 and not (want_red and pg)) else "false",
                                                  "true" if pg else "false",
                                                  "true" if (pg or (Cin == 64 and Cout == 128)) else "false", blocks)):
-        _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
-            _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
-            ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
-            int(dW.shape[1]), _opt(red), _opt(gsum), Cin, Cout, P, nb, _stream(y)), "usip_mlp_layer_backward_x2h_f32")
+        if wsum is not None:
+            _lib.check(lib.usip_mlp_layer_backward_x2h_ws_f32(
+                _ptr(dz), _ptr(y), _ptr(coef4), _ptr(x), int(x.shape[1]), _ptr(xcoef), ctypes.c_void_p(planes.data_ptr()),
+                _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)), int(dW.shape[1]), _ptr(red),
+                _ptr(wsrc), int(wsrc.shape[1]), _ptr(wsum), _ptr(wsum3), Cin, Cout, P, nb, _stream(y)),
+                "usip_mlp_layer_backward_x2h_ws_f32")
+        else:
+            _lib.check(lib.usip_mlp_layer_backward_x2h_f32(
+                _opt(dz), _ptr(y), _ptr(coef4), _opt(pdp), _opt(parg), int(group), _ptr(x), int(x.shape[1]), _ptr(xcoef),
+                ctypes.c_void_p(planes.data_ptr()), _ptr(dx), Cin, _ptr(ws), ctypes.c_void_p(dW.data_ptr() + 4 * int(wcol)),
+                int(dW.shape[1]), _opt(red), _opt(gsum), Cin, Cout, P, nb, _stream(y)), "usip_mlp_layer_backward_x2h_f32")
     if not want_red:
         return dx, dW
     r = RedSums(red, Cin)
     r.gsum = gsum
+    if wsum is not None:
+        r.wsum = (wsum, wsum3, wsrc)
     return dx, dW, r
+
+
+WSUM = _os.environ.get("USIP_WSUM", "1") not in ("0", "off")        # A/B switch of the fused first-layer weight gradient
+
+
+def wsum_supported(wsrc, Cin: int, Cout: int, P: int, pooled: bool) -> bool:
+    """May mlp_layer_backward_x2 take the producing layer's weight-gradient sums against `wsrc` on the way?"""
+    return (WSUM and wsrc is not None and not pooled and Cin == 64 and Cout == 64 and wsrc.dim() == 3 and wsrc.shape[1] <= 8
+            and wsrc.shape[2] == P and wsrc.is_contiguous() and wsrc.data_ptr() % 16 == 0 and wsrc.dtype == torch.float32)
+
+
+def wsum_finalize(wsum_pack, coef4, mean, dW):
+    """dW[:, :rows] = the weight gradient of the layer whose sums `wsum_pack` (RedSums.wsum) holds, from its own coef4 /
+    batch mean (csrc/layer_bwd_x2.hip::wsum_finalize_kernel); dW [C, >= rows] contiguous rows."""
+    wsum, wsum3, wsrc = wsum_pack
+    blocks = wsum3.shape[0]
+    C = wsum.shape[1]
+    with torch.cuda.device(dW.device), prof.kernel("wsum_finalize", 4.0 * blocks * (16 * C + 8)):
+        _lib.check(_lib.lib().usip_mlp_wsum_finalize_f32(_ptr(wsum), _ptr(wsum3), int(blocks), int(C), _ptr(coef4), _ptr(mean),
+                                                         int(wsrc.shape[1]), _ptr(dW), int(dW.stride(0)), _stream(dW)),
+                   "usip_mlp_wsum_finalize_f32")
+    return dW
 
 
 def bn_pool_backward_partials(dpooled, arg, Y4, coef_fwd, mean, invstd, relu: bool, yarg=None):
