@@ -192,6 +192,14 @@ def test_fused_layer_backward_has_no_scratch(tmp_path):
         assert int(re.search(r"amdhsa_next_free_vgpr (\d+)", seg).group(1)) <= 256, m.group(1)
         seen += 1
     assert seen == 7
+    # ... and the form that also takes the first layer's weight-gradient sums (round 6): packed FMAs on natural register
+    # pairs (test_no_packed_fp32_instruction_selects_halves covers their operand selection), no scratch
+    m = re.search(r"\.amdhsa_kernel (\S*layer_bwd_x2ws_kernel\S*)", asm)
+    seg = asm[m.start():m.start() + 4000]
+    assert int(re.search(r"amdhsa_private_segment_fixed_size (\d+)", seg).group(1)) == 0
+    assert int(re.search(r"amdhsa_next_free_vgpr (\d+)", seg).group(1)) <= 256
+    body = [b for n, b in _functions(asm, "_ZN12_GLOBAL__N_121layer_bwd_x2ws_kernel")][0]
+    assert sum(1 for ln in body if ln.startswith("v_pk_fma_f32")) >= 64
 
 
 def test_gathered_knn_layer_kernels_registers_and_streaming_loads(tmp_path):
