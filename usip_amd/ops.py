@@ -1000,15 +1000,15 @@ def mlp_layer_backward_x2(dz, y, coef4, x, xcoef, w2, wcol: int = 0, dw_out=None
     if want_red and wsum_supported(wsrc, Cin, Cout, P, pool is not None):
         wsum = torch.empty((blocks, Cin, 16), dtype=torch.float32, device=dev)
         wsum3 = torch.empty((blocks, 8), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev), _reduce_now(dw_out is None), prof.kernel("shared_mlp_layer_bwd_x2 %dx%d" % (Cout, Cin),
-                                             4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin),
-                                             4.0 * Cout * Cin * nb * P,
-                                             rocprof_key="layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s, %s, %s> |wg=%d" % (
-                                                 Cin, Cout, "true" if pool is not None else "false",
-                                                 "true" if want_red else "false", 8 if Cin == 128 else 4,
-                                                 "true" if (Cin == 128 and not (want_red and pg)) else "false",
-                                                 "true" if pg else "false",
-                                                 "true" if (pg or (Cin == 64 and Cout == 128)) else "false", blocks)):
+    key = ("layer_bwd_x2ws_kernel<%d, %d, 4, 32> |wg=%d" % (Cin, Cout, blocks)) if wsum is not None else (
+        "layer_bwd_x2_kernel<%d, %d, %s, %s, %d, 32, %s, %s, %s> |wg=%d" % (
+            Cin, Cout, "true" if pool is not None else "false", "true" if want_red else "false", 8 if Cin == 128 else 4,
+            "true" if (Cin == 128 and not (want_red and pg)) else "false", "true" if pg else "false",
+            "true" if (pg or (Cin == 64 and Cout == 128)) else "false", blocks))
+    with torch.cuda.device(dev), _reduce_now(dw_out is None), prof.kernel(
+            "shared_mlp_layer_bwd_x2%s %dx%d" % ("ws" if wsum is not None else "", Cout, Cin),
+            4.0 * nb * P * ((1 if pool is not None else 2) * Cout + 2 * Cin + (wsrc.shape[1] if wsum is not None else 0)),
+            4.0 * Cout * Cin * nb * P, rocprof_key=key):
         if wsum is not None:
             _lib.check(lib.usip_mlp_layer_backward_x2h_ws_f32(
                 _ptr(dz), _ptr(y), _ptr(coef4), _ptr(x), int(x.shape[1]), _ptr(xcoef), ctypes.c_void_p(planes.data_ptr()),
