@@ -151,3 +151,32 @@ def test_knn_first_layer_is_what_the_training_module_runs():
     assert "knn_layer_fwd" in names and "knn_layer_bwd" in names and "segment_sum" not in names, names
     with torch.no_grad():                                  # inference keeps the gather + layer form
         assert not Fh.knn_first_layer_supported(feat, idx, mod.layers_before[0].conv.bias, mod.layers_before[0].norm, True)
+
+
+def test_knn_layer_edge_cases():
+    """Empty batch: nothing is launched, empty outputs.  A shape the kernels do not take (M * K not a multiple of 4, or a
+    row of M * K floats beyond 64 KiB of LDS) is refused by usip_knn_layer_supported and the module keeps the gather +
+    layer form; out-of-range indices are clamped (never read outside the cloud)."""
+    from usip_amd import functional as Fh, layers, ops
+    assert not ops.knn_layer_supported(48, 5, 3) and not ops.knn_layer_supported(512, 2048, 16)
+    assert ops.knn_layer_supported(512, 512, 16) and ops.knn_layer_supported(64, 64, 16)
+    U = torch.empty(0, 8, 16, device=DEV)
+    W = torch.randn(8, 3 + 4, device=DEV)
+    Y, stats = ops.knn_layer_forward(U, W, torch.empty(0, 3, 16, device=DEV), torch.empty(0, 3, 4, device=DEV),
+                                     torch.empty(0, 4, 4, dtype=torch.int32, device=DEV))
+    assert Y.shape == (0, 8, 16)
+    B, C, N, M, K, Cout = 2, 6, 20, 5, 3, 8                  # M * K = 15: the module falls back
+    mod = layers.GeneralKNNFusionModule(3 + C, [Cout], [Cout], "relu", "batch").to(DEV).train()
+    feat, database, query, idx, _, _ = _inputs(B, C, N, M, K, Cout)
+    feat.requires_grad_(True)
+    assert not Fh.knn_first_layer_supported(feat, idx, mod.layers_before[0].conv.bias, mod.layers_before[0].norm, True)
+    mod(query, database, feat, K).sum().backward()
+    assert feat.grad is not None and torch.isfinite(feat.grad).all()
+    B, C, N, M, K, Cout = SHAPES[0]
+    feat, database, query, idx, W, bias = _inputs(*SHAPES[0])
+    bad = idx.clone()
+    bad[0, 0, 0], bad[1, 2, 3] = -7, N + 100
+    U = torch.randn(B, Cout, N, device=DEV)
+    Y, _ = ops.knn_layer_forward(U, W.contiguous(), database, query, bad)
+    ref, _ = ops.knn_layer_forward(U, W.contiguous(), database, query, bad.clamp(0, N - 1))
+    assert torch.equal(Y, ref)
